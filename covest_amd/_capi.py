@@ -1,0 +1,123 @@
+"""ctypes binding of include/covest_amd.h (covest_amd/lib/libcovest_amd.so).
+
+Loading the library initialises nothing on the GPU (fork-safe, like importing the
+reference's `covest_poisson` extension); the first compute call does.  There is
+no CPU fallback: if the library is missing or no HIP device is usable the call
+raises CovestHipError -- it never silently computes elsewhere.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcovest_amd.so")
+
+MAX_PARAMS = 5
+MODEL_BASIC, MODEL_REPEATS = 0, 1
+KERNEL_AUTO, KERNEL_DIRECT, KERNEL_RECUR, KERNEL_FACTORED = 0, 1, 2, 3
+KERNELS = {"auto": KERNEL_AUTO, "direct": KERNEL_DIRECT, "recur": KERNEL_RECUR,
+           "factored": KERNEL_FACTORED}
+
+# every symbol include/covest_amd.h declares (tests check the library exports them all)
+EXPORTS = (
+    "covest_abi_version", "covest_device_count", "covest_last_error",
+    "covest_model_create", "covest_model_destroy", "covest_model_param_count",
+    "covest_model_bins_evaluated", "covest_threshold_o", "covest_eval_points",
+    "covest_probabilities", "covest_grid_create", "covest_grid_destroy", "covest_grid_size",
+    "covest_grid_eval", "covest_grid_argmin", "covest_grid_ll_device", "covest_grid_ll_host",
+    "covest_grid_work",
+)
+
+
+class CovestHipError(RuntimeError):
+    pass
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("k", ctypes.c_int32),
+        ("r", ctypes.c_int32),
+        ("n_err", ctypes.c_int32),
+        ("comb", ctypes.POINTER(ctypes.c_double)),
+        ("n_keys", ctypes.c_int64),
+        ("keys", ctypes.POINTER(ctypes.c_int32)),
+        ("counts", ctypes.POINTER(ctypes.c_double)),
+        ("tail", ctypes.c_double),
+        ("lo", ctypes.c_double * MAX_PARAMS),
+        ("hi", ctypes.c_double * MAX_PARAMS),
+        ("threshold", ctypes.c_double),
+        ("has_threshold", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises CovestHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CovestHipError(
+            "HIP library %s is missing: run `python -m covest_amd.build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise CovestHipError("cannot load %s: %s" % (LIB_PATH, e))
+    vp, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)
+    i32, i64 = ctypes.c_int32, ctypes.c_int64
+    L.covest_abi_version.restype = ctypes.c_int
+    L.covest_abi_version.argtypes = []
+    L.covest_device_count.restype = ctypes.c_int
+    L.covest_device_count.argtypes = []
+    L.covest_last_error.restype = ctypes.c_char_p
+    L.covest_last_error.argtypes = []
+    L.covest_model_create.restype = ctypes.c_int
+    L.covest_model_create.argtypes = [ctypes.POINTER(ModelDesc), ctypes.POINTER(vp)]
+    L.covest_model_destroy.restype = None
+    L.covest_model_destroy.argtypes = [vp]
+    L.covest_model_param_count.restype = ctypes.c_int
+    L.covest_model_param_count.argtypes = [vp]
+    L.covest_model_bins_evaluated.restype = i64
+    L.covest_model_bins_evaluated.argtypes = [vp]
+    L.covest_threshold_o.restype = ctypes.c_int
+    L.covest_threshold_o.argtypes = [i64, dp, ctypes.c_double, i32, i32, ctypes.POINTER(i32)]
+    L.covest_eval_points.restype = ctypes.c_int
+    L.covest_eval_points.argtypes = [vp, i64, dp, dp, i32]
+    L.covest_probabilities.restype = ctypes.c_int
+    L.covest_probabilities.argtypes = [vp, dp, i32, dp]
+    L.covest_grid_create.restype = ctypes.c_int
+    L.covest_grid_create.argtypes = [vp, i32, ctypes.POINTER(dp), ctypes.POINTER(i64), i64, i64,
+                                     ctypes.POINTER(vp)]
+    L.covest_grid_destroy.restype = None
+    L.covest_grid_destroy.argtypes = [vp]
+    L.covest_grid_size.restype = i64
+    L.covest_grid_size.argtypes = [vp]
+    L.covest_grid_eval.restype = ctypes.c_int
+    L.covest_grid_eval.argtypes = [vp, i32, vp]
+    L.covest_grid_argmin.restype = ctypes.c_int
+    L.covest_grid_argmin.argtypes = [vp, dp, ctypes.POINTER(i64)]
+    L.covest_grid_ll_device.restype = vp
+    L.covest_grid_ll_device.argtypes = [vp]
+    L.covest_grid_ll_host.restype = ctypes.c_int
+    L.covest_grid_ll_host.argtypes = [vp, dp]
+    L.covest_grid_work.restype = ctypes.c_int
+    L.covest_grid_work.argtypes = [vp, dp, dp, ctypes.POINTER(ctypes.c_char_p)]
+    _lib = L
+    return L
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().covest_last_error()
+        raise CovestHipError("%s failed (%d): %s" % (what, status, (msg or b"").decode()))
+
+
+def device_count():
+    n = lib().covest_device_count()
+    if n < 0:
+        raise CovestHipError("no usable HIP device: %s" % lib().covest_last_error().decode())
+    return n

@@ -1,0 +1,612 @@
+// capi.cpp -- the C ABI of include/covest_amd.h: host-side model preparation,
+// threshold_o, device buffers and kernel dispatch.  Compiled with hipcc, links
+// only the HIP runtime.  There is no CPU compute path in this library: every
+// likelihood value comes out of a gfx950 kernel.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/covest_amd.h"
+#include "device_model.h"
+#include "kernels.h"
+
+using namespace covest;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+               ? COVEST_E_NO_DEVICE
+               : COVEST_E_HIP;
+}
+
+#define HIP_TRY(expr)                                \
+    do {                                             \
+        hipError_t e__ = (expr);                     \
+        if (e__ != hipSuccess)                       \
+            return fail_hip(e__, #expr);             \
+    } while (0)
+
+// A device allocation that grows on demand and is released with its owner.
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e == hipSuccess)
+            cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+} // namespace
+
+struct covest_model {
+    int device = 0;
+    int n_par = 2;
+    DevModel dm{};       // bins = the evaluated view
+    BinView all_bins{};  // every key, in dict order (compute_probabilities)
+    int64_t n_keys = 0;
+    int hist_max = 0;    // max(self.hist)
+    double threshold = 0.0;
+    bool has_threshold = true;
+    // device storage of the two bin views
+    DevBuf bins_eval, bins_all;
+    // scratch for covest_eval_points / covest_probabilities
+    DevBuf ws_params, ws_t, ws_out, ws_p;
+    std::mutex lock;
+};
+
+struct covest_grid {
+    covest_model *model = nullptr;
+    int64_t len[kMaxParams] = {1, 1, 1, 1, 1};
+    int64_t flat_begin = 0, flat_end = 0;
+    PointSource src{};
+    DevBuf axes, t_table, ll, partial_val, partial_idx, result;
+    double sum_t_minus_1 = 0.0; // sum over the block's points of (threshold_o - 1)
+    const char *last_kernel = "none";
+    hipStream_t last_stream = nullptr;
+    bool evaluated = false;
+};
+
+namespace {
+
+// RepeatsModel.get_b_o / get_hist_threshold, covest/models.py:185-208, with libm
+// pow as CPython's float ** int.  b_o is non-increasing in o for o >= 3 when
+// 0 <= 1-q <= 1, so the first crossing is found by bisection and then confirmed
+// against its left neighbours with the very same pow calls the linear scan of
+// the reference would make; outside that domain the scan itself is used.
+double weight_ge3(double head, double one_minus_q, int o)
+{
+    return head * std::pow(one_minus_q, (double)(o - 3));
+}
+
+int threshold_o_host(double q1, double q2, double q, double thr, bool has_thr, int hist_max)
+{
+    if (!has_thr)
+        return hist_max;
+    if (hist_max > 1 && q1 <= thr)
+        return 1;
+    if (hist_max > 2 && (1 - q1) * q2 <= thr)
+        return 2;
+    if (hist_max <= 3)
+        return hist_max;
+    const double head = (1 - q1) * (1 - q2) * q;
+    const double base = 1 - q;
+    const int last = hist_max - 1; // o ranges over 3..last
+    if (!(base >= 0.0 && base <= 1.0) || !(head == head)) {
+        for (int o = 3; o <= last; ++o)
+            if (weight_ge3(head, base, o) <= thr)
+                return o;
+        return hist_max;
+    }
+    if (weight_ge3(head, base, 3) <= thr)
+        return 3;
+    if (!(weight_ge3(head, base, last) <= thr))
+        return hist_max;
+    int lo = 3, hi = last; // f(lo) > thr, f(hi) <= thr
+    while (hi - lo > 1) {
+        const int mid = lo + (hi - lo) / 2;
+        if (weight_ge3(head, base, mid) <= thr)
+            hi = mid;
+        else
+            lo = mid;
+    }
+    while (hi > 3 && weight_ge3(head, base, hi - 1) <= thr)
+        --hi;
+    return hi;
+}
+
+double clamp_one(const DevModel &dm, int d, double v)
+{
+    const double lo = dm.lo[d], hi = dm.hi[d];
+    if (lo == lo && v < lo)
+        return lo;
+    if (hi == hi && v > hi)
+        return hi;
+    return v;
+}
+
+int threshold_for_point(const covest_model *m, const double *par)
+{
+    return threshold_o_host(clamp_one(m->dm, 2, par[2]), clamp_one(m->dm, 3, par[3]),
+                            clamp_one(m->dm, 4, par[4]), m->threshold, m->has_threshold, m->hist_max);
+}
+
+int use_device(const covest_model *m)
+{
+    hipError_t e = hipSetDevice(m->device);
+    if (e != hipSuccess)
+        return fail_hip(e, "hipSetDevice");
+    return COVEST_OK;
+}
+
+int upload_bins(DevBuf &buf, BinView &view, const std::vector<double> &key,
+                const std::vector<double> &lgam, const std::vector<double> &cnt)
+{
+    const size_t n = key.size();
+    view.n = (int64_t)n;
+    view.key = view.lgam = view.cnt = nullptr;
+    if (n == 0)
+        return COVEST_OK;
+    HIP_TRY(buf.reserve(3 * n * sizeof(double)));
+    double *base = buf.as<double>();
+    HIP_TRY(hipMemcpy(base, key.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + n, lgam.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + 2 * n, cnt.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    view.key = base;
+    view.lgam = base + n;
+    view.cnt = base + 2 * n;
+    return COVEST_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int covest_abi_version(void) { return COVEST_ABI_VERSION; }
+
+const char *covest_last_error(void) { return g_last_error.c_str(); }
+
+int covest_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess)
+        return fail_hip(e, "hipGetDeviceCount");
+    return n;
+}
+
+int covest_model_create(const covest_model_desc *d, covest_model **out)
+{
+    if (!d || !out)
+        return fail(COVEST_E_INVALID, "covest_model_create: null argument");
+    *out = nullptr;
+    if (d->kind != COVEST_MODEL_BASIC && d->kind != COVEST_MODEL_REPEATS)
+        return fail(COVEST_E_INVALID, "covest_model_create: unknown model kind");
+    if (d->n_err < 1 || d->n_err > COVEST_MAX_ERROR_CLASSES || d->n_err > d->k + 1)
+        return fail(COVEST_E_INVALID, "covest_model_create: n_err must be in 1..min(k+1, 64)");
+    if (d->r <= 0 || d->k <= 0)
+        return fail(COVEST_E_INVALID, "covest_model_create: k and r must be positive");
+    if (d->n_keys < 0 || (d->n_keys > 0 && (!d->keys || !d->counts)) || !d->comb)
+        return fail(COVEST_E_INVALID, "covest_model_create: null histogram or comb");
+    if (d->kind == COVEST_MODEL_REPEATS && d->n_keys == 0)
+        return fail(COVEST_E_INVALID,
+                    "covest_model_create: repeats model needs a non-empty histogram "
+                    "(max() of an empty dict raises in covest/models.py:186)");
+
+    int device = d->device;
+    if (device < 0) {
+        hipError_t e = hipGetDevice(&device);
+        if (e != hipSuccess)
+            return fail_hip(e, "hipGetDevice");
+    }
+    int n_dev = 0;
+    {
+        hipError_t e = hipGetDeviceCount(&n_dev);
+        if (e != hipSuccess)
+            return fail_hip(e, "hipGetDeviceCount");
+        if (n_dev <= 0 || device >= n_dev)
+            return fail(COVEST_E_NO_DEVICE, "covest_model_create: no such HIP device");
+    }
+
+    covest_model *m = new (std::nothrow) covest_model();
+    if (!m)
+        return fail(COVEST_E_NOMEM, "covest_model_create: out of host memory");
+    m->device = device;
+    m->n_par = d->kind == COVEST_MODEL_BASIC ? 2 : 5;
+    m->n_keys = d->n_keys;
+    m->threshold = d->threshold;
+    m->has_threshold = d->has_threshold != 0;
+    DevModel &dm = m->dm;
+    dm.kind = d->kind;
+    dm.k = d->k;
+    dm.r = d->r;
+    dm.n_err = d->n_err;
+    for (int s = 0; s < kMaxErr; ++s) {
+        dm.comb[s] = s < d->n_err ? d->comb[s] : 0.0;
+        dm.pow3neg[s] = std::pow(3.0, (double)-s); // 3 ** -s, covest/models.py:77
+    }
+    for (int i = 0; i < kMaxParams; ++i) {
+        dm.lo[i] = i < m->n_par ? d->lo[i] : std::numeric_limits<double>::quiet_NaN();
+        dm.hi[i] = i < m->n_par ? d->hi[i] : std::numeric_limits<double>::quiet_NaN();
+    }
+    dm.tail = d->tail;
+
+    // Bin views.  When tail == 0 the tail term of covest/models.py:104 is exactly
+    // 0 whatever sp_j is (0 * log of a positive number, or the else-branch), so
+    // bins with h_j == 0 influence nothing and are dropped from the evaluated view.
+    std::vector<double> key_a, lg_a, cnt_a, key_e, lg_e, cnt_e;
+    key_a.reserve(d->n_keys);
+    int hist_max = std::numeric_limits<int>::min();
+    for (int64_t b = 0; b < d->n_keys; ++b) {
+        const int j = d->keys[b];
+        if (j > hist_max)
+            hist_max = j;
+        const int je = j > 0 ? j : 0; // the product loop of the C extension is empty for j <= 0
+        const double kd = (double)je;
+        const double lg = (double)lgammal((long double)je + 1.0L);
+        const double h = d->counts[b];
+        key_a.push_back(kd);
+        lg_a.push_back(lg);
+        cnt_a.push_back(h);
+        if (d->tail != 0.0 || h != 0.0) {
+            key_e.push_back(kd);
+            lg_e.push_back(lg);
+            cnt_e.push_back(h);
+        }
+    }
+    m->hist_max = d->n_keys > 0 ? hist_max : 0;
+
+    int rc = use_device(m);
+    if (rc == COVEST_OK)
+        rc = upload_bins(m->bins_all, m->all_bins, key_a, lg_a, cnt_a);
+    if (rc == COVEST_OK)
+        rc = upload_bins(m->bins_eval, dm.bins, key_e, lg_e, cnt_e);
+    if (rc != COVEST_OK) {
+        covest_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return COVEST_OK;
+}
+
+void covest_model_destroy(covest_model *m)
+{
+    if (!m)
+        return;
+    (void)hipSetDevice(m->device);
+    m->bins_eval.release();
+    m->bins_all.release();
+    m->ws_params.release();
+    m->ws_t.release();
+    m->ws_out.release();
+    m->ws_p.release();
+    delete m;
+}
+
+int covest_model_param_count(const covest_model *m) { return m ? m->n_par : COVEST_E_INVALID; }
+
+int64_t covest_model_bins_evaluated(const covest_model *m) { return m ? m->dm.bins.n : COVEST_E_INVALID; }
+
+int covest_threshold_o(int64_t n, const double *q123, double threshold, int32_t has_threshold,
+                       int32_t hist_max, int32_t *out)
+{
+    if (n < 0 || (n > 0 && (!q123 || !out)))
+        return fail(COVEST_E_INVALID, "covest_threshold_o: bad argument");
+    for (int64_t i = 0; i < n; ++i)
+        out[i] = threshold_o_host(q123[3 * i], q123[3 * i + 1], q123[3 * i + 2], threshold,
+                                  has_threshold != 0, hist_max);
+    return COVEST_OK;
+}
+
+static int pick_kernel(int32_t kernel)
+{
+    if (kernel == COVEST_KERNEL_AUTO)
+        return COVEST_KERNEL_DIRECT;
+    return kernel;
+}
+
+int covest_eval_points(covest_model *m, int64_t n, const double *params, double *out_ll,
+                       int32_t kernel)
+{
+    if (!m || n < 0 || (n > 0 && (!params || !out_ll)))
+        return fail(COVEST_E_INVALID, "covest_eval_points: bad argument");
+    if (n == 0)
+        return COVEST_OK;
+    if (pick_kernel(kernel) != COVEST_KERNEL_DIRECT)
+        return fail(COVEST_E_INVALID, "covest_eval_points: kernel not available for point lists");
+    std::lock_guard<std::mutex> guard(m->lock);
+    int rc = use_device(m);
+    if (rc != COVEST_OK)
+        return rc;
+    const int P = m->n_par;
+    HIP_TRY(m->ws_params.reserve((size_t)n * P * sizeof(double)));
+    HIP_TRY(m->ws_out.reserve((size_t)n * sizeof(double)));
+    HIP_TRY(hipMemcpy(m->ws_params.ptr, params, (size_t)n * P * sizeof(double), hipMemcpyHostToDevice));
+    PointSource src{};
+    src.is_grid = 0;
+    src.params = m->ws_params.as<double>();
+    if (P == 5) {
+        std::vector<int32_t> t((size_t)n);
+        for (int64_t i = 0; i < n; ++i)
+            t[(size_t)i] = threshold_for_point(m, params + i * P);
+        HIP_TRY(m->ws_t.reserve((size_t)n * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(m->ws_t.ptr, t.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+        src.t_list = m->ws_t.as<int32_t>();
+    }
+    HIP_TRY(launch_ll_direct(m->dm, src, n, m->ws_out.as<double>(), nullptr, nullptr));
+    HIP_TRY(hipMemcpy(out_ll, m->ws_out.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return COVEST_OK;
+}
+
+int covest_probabilities(covest_model *m, const double *params, int32_t clamp, double *out_p)
+{
+    if (!m || !params || (m->n_keys > 0 && !out_p))
+        return fail(COVEST_E_INVALID, "covest_probabilities: bad argument");
+    if (m->n_keys == 0)
+        return COVEST_OK;
+    std::lock_guard<std::mutex> guard(m->lock);
+    int rc = use_device(m);
+    if (rc != COVEST_OK)
+        return rc;
+    const int P = m->n_par;
+    HIP_TRY(m->ws_params.reserve((size_t)P * sizeof(double)));
+    HIP_TRY(m->ws_out.reserve(sizeof(double)));
+    HIP_TRY(m->ws_p.reserve((size_t)m->n_keys * sizeof(double)));
+    HIP_TRY(hipMemcpy(m->ws_params.ptr, params, (size_t)P * sizeof(double), hipMemcpyHostToDevice));
+    PointSource src{};
+    src.params = m->ws_params.as<double>();
+    if (P == 5) {
+        const int32_t t = clamp ? threshold_for_point(m, params)
+                                : threshold_o_host(params[2], params[3], params[4], m->threshold,
+                                                   m->has_threshold, m->hist_max);
+        HIP_TRY(m->ws_t.reserve(sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(m->ws_t.ptr, &t, sizeof(int32_t), hipMemcpyHostToDevice));
+        src.t_list = m->ws_t.as<int32_t>();
+    }
+    DevModel full = m->dm;
+    full.bins = m->all_bins;
+    if (!clamp)
+        for (int i = 0; i < kMaxParams; ++i)
+            full.lo[i] = full.hi[i] = std::numeric_limits<double>::quiet_NaN();
+    HIP_TRY(launch_ll_direct(full, src, 1, m->ws_out.as<double>(), m->ws_p.as<double>(), nullptr));
+    HIP_TRY(hipMemcpy(out_p, m->ws_p.ptr, (size_t)m->n_keys * sizeof(double), hipMemcpyDeviceToHost));
+    return COVEST_OK;
+}
+
+int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axes,
+                       const int64_t *axis_len, int64_t flat_begin, int64_t flat_end,
+                       covest_grid **out)
+{
+    if (!m || !axes || !axis_len || !out)
+        return fail(COVEST_E_INVALID, "covest_grid_create: null argument");
+    *out = nullptr;
+    if (n_axes != m->n_par)
+        return fail(COVEST_E_INVALID, "covest_grid_create: n_axes must equal the model's param_count");
+    int64_t total = 1, n_values = 0;
+    for (int d = 0; d < n_axes; ++d) {
+        if (axis_len[d] < 1 || !axes[d])
+            return fail(COVEST_E_INVALID, "covest_grid_create: every axis needs at least one value");
+        if (total > (int64_t)1 << 40)
+            return fail(COVEST_E_INVALID, "covest_grid_create: grid too large");
+        total *= axis_len[d];
+        n_values += axis_len[d];
+    }
+    if (flat_end < 0)
+        flat_end = total;
+    if (flat_begin < 0 || flat_begin > flat_end || flat_end > total)
+        return fail(COVEST_E_INVALID, "covest_grid_create: bad flat index range");
+
+    covest_grid *g = new (std::nothrow) covest_grid();
+    if (!g)
+        return fail(COVEST_E_NOMEM, "covest_grid_create: out of host memory");
+    g->model = m;
+    g->flat_begin = flat_begin;
+    g->flat_end = flat_end;
+    const int64_t n = flat_end - flat_begin;
+
+    std::lock_guard<std::mutex> guard(m->lock);
+    int rc = use_device(m);
+    auto bail = [&](int code) {
+        g->axes.release();
+        g->t_table.release();
+        g->ll.release();
+        g->partial_val.release();
+        g->partial_idx.release();
+        g->result.release();
+        delete g;
+        return code;
+    };
+    if (rc != COVEST_OK)
+        return bail(rc);
+
+    std::vector<double> flat_axes;
+    flat_axes.reserve((size_t)n_values);
+    for (int d = 0; d < n_axes; ++d) {
+        g->len[d] = axis_len[d];
+        flat_axes.insert(flat_axes.end(), axes[d], axes[d] + axis_len[d]);
+    }
+#define GRID_TRY(expr)                                   \
+    do {                                                 \
+        hipError_t e__ = (expr);                         \
+        if (e__ != hipSuccess)                           \
+            return bail(fail_hip(e__, #expr));           \
+    } while (0)
+    GRID_TRY(g->axes.reserve(flat_axes.size() * sizeof(double)));
+    GRID_TRY(hipMemcpy(g->axes.ptr, flat_axes.data(), flat_axes.size() * sizeof(double),
+                       hipMemcpyHostToDevice));
+    PointSource &src = g->src;
+    src.is_grid = 1;
+    src.flat_begin = flat_begin;
+    {
+        int64_t off = 0;
+        for (int d = 0; d < kMaxParams; ++d) {
+            src.len[d] = d < n_axes ? axis_len[d] : 1;
+            src.axis[d] = d < n_axes ? g->axes.as<double>() + off : nullptr;
+            if (d < n_axes)
+                off += axis_len[d];
+        }
+    }
+
+    // threshold_o over the (q1, q2, q) sub-grid, and the block's sum of (T - 1)
+    g->sum_t_minus_1 = (double)n; // basic: T = 2 everywhere
+    if (m->n_par == 5) {
+        const int64_t n1 = axis_len[2], n2 = axis_len[3], n3 = axis_len[4];
+        const int64_t nq = n1 * n2 * n3;
+        std::vector<int32_t> table((size_t)nq);
+        for (int64_t a = 0; a < n1; ++a)
+            for (int64_t b = 0; b < n2; ++b)
+                for (int64_t c = 0; c < n3; ++c) {
+                    const double par[5] = {0, 0, axes[2][a], axes[3][b], axes[4][c]};
+                    table[(size_t)((a * n2 + b) * n3 + c)] = threshold_for_point(m, par);
+                }
+        GRID_TRY(g->t_table.reserve((size_t)nq * sizeof(int32_t)));
+        GRID_TRY(hipMemcpy(g->t_table.ptr, table.data(), (size_t)nq * sizeof(int32_t),
+                           hipMemcpyHostToDevice));
+        src.t_table = g->t_table.as<int32_t>();
+        // sum of (T-1) over flat indices [begin, end): whole (c,e) rows plus two ragged ends
+        std::vector<double> prefix((size_t)nq + 1, 0.0);
+        for (int64_t i = 0; i < nq; ++i)
+            prefix[(size_t)i + 1] = prefix[(size_t)i] + (double)(table[(size_t)i] > 1 ? table[(size_t)i] - 1 : 0);
+        auto upto = [&](int64_t flat) { // sum over flat indices [0, flat)
+            return (double)(flat / nq) * prefix[(size_t)nq] + prefix[(size_t)(flat % nq)];
+        };
+        g->sum_t_minus_1 = upto(flat_end) - upto(flat_begin);
+    }
+
+    GRID_TRY(g->ll.reserve((size_t)(n > 0 ? n : 1) * sizeof(double)));
+    GRID_TRY(g->partial_val.reserve(kArgminBlocks * sizeof(double)));
+    GRID_TRY(g->partial_idx.reserve(kArgminBlocks * sizeof(int64_t)));
+    GRID_TRY(g->result.reserve(sizeof(ArgminResult)));
+#undef GRID_TRY
+    *out = g;
+    return COVEST_OK;
+}
+
+void covest_grid_destroy(covest_grid *g)
+{
+    if (!g)
+        return;
+    (void)hipSetDevice(g->model->device);
+    g->axes.release();
+    g->t_table.release();
+    g->ll.release();
+    g->partial_val.release();
+    g->partial_idx.release();
+    g->result.release();
+    delete g;
+}
+
+int64_t covest_grid_size(const covest_grid *g) { return g ? g->flat_end - g->flat_begin : COVEST_E_INVALID; }
+
+int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
+{
+    if (!g)
+        return fail(COVEST_E_INVALID, "covest_grid_eval: null grid");
+    covest_model *m = g->model;
+    if (pick_kernel(kernel) != COVEST_KERNEL_DIRECT)
+        return fail(COVEST_E_INVALID, "covest_grid_eval: kernel not available");
+    std::lock_guard<std::mutex> guard(m->lock);
+    int rc = use_device(m);
+    if (rc != COVEST_OK)
+        return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n = g->flat_end - g->flat_begin;
+    HIP_TRY(launch_ll_direct(m->dm, g->src, n, g->ll.as<double>(), nullptr, st));
+    g->last_kernel = "ll_direct";
+    HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->partial_val.as<double>(),
+                          g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), st));
+    g->last_stream = st;
+    g->evaluated = true;
+    return COVEST_OK;
+}
+
+int covest_grid_argmin(covest_grid *g, double *min_negll, int64_t *argmin_flat)
+{
+    if (!g || !min_negll || !argmin_flat)
+        return fail(COVEST_E_INVALID, "covest_grid_argmin: null argument");
+    if (!g->evaluated)
+        return fail(COVEST_E_INVALID, "covest_grid_argmin: covest_grid_eval has not run");
+    int rc = use_device(g->model);
+    if (rc != COVEST_OK)
+        return rc;
+    ArgminResult r;
+    HIP_TRY(hipMemcpyAsync(&r, g->result.ptr, sizeof(r), hipMemcpyDeviceToHost, g->last_stream));
+    HIP_TRY(hipStreamSynchronize(g->last_stream));
+    *min_negll = r.min_negll;
+    *argmin_flat = r.index < 0 ? -1 : g->flat_begin + r.index;
+    return COVEST_OK;
+}
+
+const double *covest_grid_ll_device(const covest_grid *g) { return g ? g->ll.as<double>() : nullptr; }
+
+int covest_grid_ll_host(covest_grid *g, double *out_ll)
+{
+    if (!g || !out_ll)
+        return fail(COVEST_E_INVALID, "covest_grid_ll_host: null argument");
+    if (!g->evaluated)
+        return fail(COVEST_E_INVALID, "covest_grid_ll_host: covest_grid_eval has not run");
+    int rc = use_device(g->model);
+    if (rc != COVEST_OK)
+        return rc;
+    const int64_t n = g->flat_end - g->flat_begin;
+    HIP_TRY(hipStreamSynchronize(g->last_stream));
+    if (n > 0)
+        HIP_TRY(hipMemcpy(out_ll, g->ll.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return COVEST_OK;
+}
+
+int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, const char **kernel)
+{
+    if (!g)
+        return fail(COVEST_E_INVALID, "covest_grid_work: null grid");
+    const covest_model *m = g->model;
+    const double n = (double)(g->flat_end - g->flat_begin);
+    const double bins = (double)m->dm.bins.n;
+    double nz = 0.0; // bins whose log is taken; equals bins when tail == 0
+    nz = bins;
+    const double terms = bins * (double)m->dm.n_err * g->sum_t_minus_1;
+    if (pmf_terms)
+        *pmf_terms = terms;
+    // 4 flop per pmf term + 25 per log + 25 per exp of the prologue
+    if (flops)
+        *flops = 4.0 * terms + 25.0 * nz * n + 25.0 * (double)m->dm.n_err * g->sum_t_minus_1;
+    if (kernel)
+        *kernel = g->last_kernel;
+    return COVEST_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,26 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (ll_direct.hip,
+// argmin.hip, ...).  All launches are asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "device_model.h"
+
+namespace covest {
+
+// K-direct: one wavefront per grid point, one exp per pmf term (ll_direct.hip).
+// out_ll[n]; when out_p != nullptr (n must be 1) also writes p_j for every bin
+// of `m.bins`.
+hipError_t launch_ll_direct(const DevModel &m, const PointSource &src, int64_t n, double *out_ll,
+                            double *out_p, hipStream_t stream);
+
+// (min -LL, lowest index) over ll[n]: two-stage reduction (argmin.hip).
+// partial_val/partial_idx need kArgminBlocks entries; result[0] = {min, bits of idx}.
+constexpr int kArgminBlocks = 256;
+struct ArgminResult {
+    double min_negll;
+    int64_t index; // local index, -1 if no value is < +inf
+};
+hipError_t launch_argmin(const double *ll, int64_t n, double *partial_val, int64_t *partial_idx,
+                         ArgminResult *result, hipStream_t stream);
+
+} // namespace covest

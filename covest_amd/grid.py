@@ -1,0 +1,329 @@
+"""Grid search on the GPU: the counterpart of covest/grid.py.
+
+Two entry points:
+
+* `DenseGrid` -- a rectangular grid given by its axes (itertools.product order,
+  last axis fastest): evaluates every point on this process's GPU block and
+  reduces to (min -LL, lowest flat index).  With torch.distributed initialised
+  (one process per GPU, RCCL over xGMI) the flat index range is block-partitioned
+  over the ranks and ONE tiny exchange picks the global winner.
+
+* `optimize_grid` -- same signature and semantics as covest/grid.py:17-79 (the
+  iterative multiplicative local grid).  When `fn` is the `likelihood_f` of a
+  `CoverageEstimator` over a GPU-backed model, each iteration's whole grid is one
+  batched launch instead of a `Pool.map` of pickled calls; any other callable is
+  evaluated point by point.
+
+Selection rule everywhere: the sequential scan of covest/grid.py:65-70 --
+strict <, first index wins ties, NaN never wins.
+"""
+import ctypes
+import itertools
+import math
+import random
+
+import numpy as np
+
+from . import _capi, constants
+
+_DP = ctypes.POINTER(ctypes.c_double)
+
+
+# --------------------------------------------------------------------------- partition
+def partition_flat_range(total, world_size, weights=None, period=None):
+    """Contiguous blocks [b_r, b_{r+1}) of range(total), one per rank.
+
+    Without weights the blocks differ by at most one point.  With `weights`
+    (cost of the point at flat index i is weights[i % period], e.g. T-1 of the
+    repeats model, which depends only on the (q1,q2,q) sub-index) the cuts are
+    placed so every block carries about the same total cost.
+    Returns a list of world_size+1 non-decreasing bounds, bounds[0]=0, bounds[-1]=total.
+    """
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    if weights is None or total == 0:
+        return [(total * r) // world_size for r in range(world_size + 1)]
+    w = np.asarray(weights, dtype=np.float64)
+    period = len(w) if period is None else period
+    assert period == len(w) and total % period == 0
+    prefix = np.concatenate(([0.0], np.cumsum(w)))
+    per_period = prefix[-1]
+    n_periods = total // period
+    whole = per_period * n_periods
+    bounds = [0]
+    for r in range(1, world_size):
+        target = whole * r / world_size
+        if per_period <= 0:
+            cut = (total * r) // world_size
+        else:
+            full = min(int(target // per_period), n_periods)
+            rem = target - full * per_period
+            inner = int(np.searchsorted(prefix, rem, side="left")) if full < n_periods else 0
+            cut = min(total, full * period + min(inner, period))
+        bounds.append(max(cut, bounds[-1]))
+    bounds.append(total)
+    return bounds
+
+
+def distributed_argmin(local_min, local_idx, group=None, device=None):
+    """Global (min, lowest flat index) from every rank's local pair.
+
+    RCCL has no MINLOC for fp64, so: all_reduce(MIN) on the value, then
+    all_reduce(MIN) on `idx if value == global_min else INT64_MAX`.  NaN is
+    mapped to +inf first (a NaN never wins the scan of covest/grid.py:67).
+    Works with any backend (nccl == RCCL on GPUs, gloo on CPU for tests).
+    Without an initialised process group this is the identity.
+    """
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_min, local_idx
+    no_idx = torch.iinfo(torch.int64).max
+    v = float(local_min)
+    if v != v or local_idx < 0:
+        v, local_idx = math.inf, -1
+    val = torch.tensor([v], dtype=torch.float64, device=device)
+    dist.all_reduce(val, op=dist.ReduceOp.MIN, group=group)
+    gmin = float(val.item())
+    mine = local_idx if (local_idx >= 0 and v == gmin and v < math.inf) else no_idx
+    idx = torch.tensor([mine], dtype=torch.int64, device=device)
+    dist.all_reduce(idx, op=dist.ReduceOp.MIN, group=group)
+    gidx = int(idx.item())
+    if gidx == no_idx:
+        return math.inf, -1
+    return gmin, gidx
+
+
+# --------------------------------------------------------------------------- dense grid
+class DenseGrid:
+    """A block of a dense parameter grid on one GPU (covest_grid* of the C ABI).
+
+    axes: one sequence per model parameter (a fixed parameter is a 1-element axis).
+    flat_range: (begin, end) of the flat itertools.product indices this object
+    evaluates; None = the whole grid.
+    """
+
+    def __init__(self, model, axes, flat_range=None):
+        if len(axes) != model.param_count:
+            raise ValueError("need one axis per model parameter")
+        self.model = model
+        self.axes = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in axes]
+        self.shape = tuple(len(a) for a in self.axes)
+        self.total = int(np.prod(self.shape, dtype=np.int64))
+        begin, end = (0, self.total) if flat_range is None else flat_range
+        self.flat_range = (int(begin), int(end))
+        L = _capi.lib()
+        n = len(self.axes)
+        ptrs = (_DP * n)(*[a.ctypes.data_as(_DP) for a in self.axes])
+        lens = (ctypes.c_int64 * n)(*self.shape)
+        h = ctypes.c_void_p()
+        _capi.check(L.covest_grid_create(model.handle, n, ptrs, lens, self.flat_range[0],
+                                         self.flat_range[1], ctypes.byref(h)), "covest_grid_create")
+        self._handle = h
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            _capi.lib().covest_grid_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.flat_range[1] - self.flat_range[0]
+
+    def evaluate(self, kernel="auto", stream=None):
+        """Launch LL + arg-min for the block (asynchronous on `stream`, a raw
+        hipStream_t value such as torch.cuda.current_stream().cuda_stream)."""
+        _capi.check(_capi.lib().covest_grid_eval(self._handle, _capi.KERNELS[kernel],
+                                                 ctypes.c_void_p(stream or 0)), "covest_grid_eval")
+
+    def argmin(self):
+        """(min -LL, global flat index) of the last evaluate(); index -1 if none < +inf."""
+        v = ctypes.c_double()
+        i = ctypes.c_int64()
+        _capi.check(_capi.lib().covest_grid_argmin(self._handle, ctypes.byref(v), ctypes.byref(i)),
+                    "covest_grid_argmin")
+        return v.value, i.value
+
+    def loglikelihoods(self):
+        """LL of every point of the block (host ndarray, flat order)."""
+        out = np.empty(len(self), dtype=np.float64)
+        _capi.check(_capi.lib().covest_grid_ll_host(self._handle, out.ctypes.data_as(_DP)),
+                    "covest_grid_ll_host")
+        return out
+
+    @property
+    def ll_device_ptr(self):
+        return _capi.lib().covest_grid_ll_device(self._handle)
+
+    def work(self):
+        """(pmf terms, algorithmic flops, kernel name) of the last evaluate()."""
+        t, f, name = ctypes.c_double(), ctypes.c_double(), ctypes.c_char_p()
+        _capi.check(_capi.lib().covest_grid_work(self._handle, ctypes.byref(t), ctypes.byref(f),
+                                                 ctypes.byref(name)), "covest_grid_work")
+        return t.value, f.value, (name.value or b"").decode()
+
+    def point(self, flat_index):
+        """Parameter tuple at a flat itertools.product index."""
+        idx = np.unravel_index(int(flat_index), self.shape)
+        return tuple(float(a[i]) for a, i in zip(self.axes, idx))
+
+
+def repeats_cost_weights(model, axes):
+    """Per-point cost (T-1) over the (q1,q2,q) sub-grid, for load-balanced partitioning."""
+    q = np.array(list(itertools.product(*[np.asarray(a, dtype=np.float64) for a in axes[2:5]])))
+    lo = np.array([b[0] for b in model.bounds[2:5]], dtype=np.float64)
+    hi = np.array([b[1] for b in model.bounds[2:5]], dtype=np.float64)
+    t = model.get_hist_threshold_values(np.clip(q, lo, hi))
+    return np.maximum(t.astype(np.float64) - 1.0, 0.0)
+
+
+def dense_grid_argmin(model, axes, kernel="auto", group=None, balance=True):
+    """Arg-min of -LL over a dense grid, block-partitioned over the process group.
+
+    Returns (min_negll, flat_index, params).  Every rank returns the same answer.
+    """
+    import torch.distributed as dist
+    world, rank = 1, 0
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shape = [len(a) for a in axes]
+    total = int(np.prod(shape, dtype=np.int64))
+    weights = None
+    if world > 1 and balance and model.param_count == 5:
+        weights = repeats_cost_weights(model, axes)
+    bounds = partition_flat_range(total, world, weights)
+    grid = DenseGrid(model, axes, (bounds[rank], bounds[rank + 1]))
+    try:
+        grid.evaluate(kernel=kernel)
+        local_min, local_idx = grid.argmin()
+        device = None
+        if world > 1 and dist.get_backend(group) == "nccl":
+            import torch
+            device = torch.device("cuda", torch.cuda.current_device())
+        gmin, gidx = distributed_argmin(local_min, local_idx, group=group, device=device)
+        params = grid.point(gidx) if gidx >= 0 else None
+    finally:
+        grid.close()
+    return gmin, gidx, params
+
+
+# --------------------------------------------------------------------------- optimize_grid
+def first_wins_scan(vals, min_val, sgn=1):
+    """The selection loop of covest/grid.py:65-70 over a value array.
+
+    Returns (min_val, argmin or -1, diff) exactly as the sequential scan would:
+    only strict improvements are visited, in index order, and `diff`
+    accumulates `min_val - val` at each of them in that order.
+    """
+    v = np.asarray(vals, dtype=np.float64)
+    sv = sgn * v
+    diff = 0.0
+    arg = -1
+    # candidates: strict running-minimum records below the starting value
+    with np.errstate(invalid="ignore"):
+        prev = np.minimum.accumulate(np.where(np.isnan(sv), np.inf, sv))
+        prev = np.concatenate(([np.inf], prev[:-1]))
+        cand = np.flatnonzero((sv < prev) & (sv < min_val))
+    for i in cand:
+        if sv[i] < min_val:
+            diff += min_val - v[i]
+            min_val = sv[i]
+            arg = int(i)
+    return min_val, arg, diff
+
+
+def _batched_negll(fn):
+    """If fn is CoverageEstimator.likelihood_f over a GPU-backed model, return a
+    function evaluating a whole list of axes at once; else None."""
+    est = getattr(fn, "__self__", None)
+    model = getattr(est, "model", None)
+    if est is None or model is None or not hasattr(model, "loglikelihood_points"):
+        return None
+    if getattr(fn, "__name__", "") != "likelihood_f":
+        return None
+    return est.negll_grid
+
+
+def optimize_grid(fn, initial_guess, bounds=None, maximize=False, fix=None,
+                  n_threads=constants.DEFAULT_THREAD_COUNT):
+    """covest/grid.py:17-79.  n_threads is accepted and ignored on the GPU path."""
+    def generate_axes(args, step, max_depth):
+        def single(var, fixed=None):
+            if fixed is None:
+                return [var * step ** d for d in range(-max_depth, max_depth + 1) if d != 0]
+            return [fixed]
+
+        def within(var_grid, i):
+            if bounds is None or len(bounds) <= i or len(bounds[i]) != 2:
+                return var_grid
+            low, high = bounds[i]
+            return [var for var in var_grid
+                    if (low is None or var >= low) and (high is None or var <= high)]
+
+        return [within(single(var, fix[i]), i) for i, var in enumerate(args)]
+
+    if fix is None:
+        fix = [None] * len(initial_guess)
+    sgn = -1 if maximize else 1
+    batched = _batched_negll(fn)
+    min_val = sgn * fn(initial_guess)
+    min_args = initial_guess
+    step = constants.STEP
+    grid_depth = constants.GRID_DEPTH
+    diff = 1
+    n_iter = 0
+    trace = optimize_grid.trace = []
+    try:
+        while diff > 0.1 or step > 1.001:
+            n_iter += 1
+            axes = generate_axes(min_args, step, grid_depth)
+            n_points = int(np.prod([len(a) for a in axes], dtype=np.int64))
+            if n_points == 0:
+                res = np.empty(0)
+            elif batched is not None:
+                res = batched(axes)
+            else:
+                res = np.array([fn(p) for p in itertools.product(*axes)], dtype=np.float64)
+            min_val, arg, diff = first_wins_scan(res, min_val, sgn)
+            if arg >= 0:
+                idx = np.unravel_index(arg, [len(a) for a in axes])
+                min_args = tuple(a[i] for a, i in zip(axes, idx))
+            if diff < 1.0:
+                step = 1 + (step - 1) * 0.75
+            trace.append({"iter": n_iter, "grid_size": n_points, "diff": diff, "step": step,
+                          "args": tuple(min_args), "value": min_val})
+    except KeyboardInterrupt:
+        pass
+    return min_args
+
+
+def initial_grid(initial_guess, count=constants.INITIAL_GRID_COUNT, bounds=None, fix=None):
+    """covest/grid.py:82-114: `count` random multi-start seeds around the guess
+    (point generation only; no likelihood is evaluated here)."""
+    if fix is None:
+        fix = [None] * len(initial_guess)
+    step = constants.INITIAL_GRID_STEP
+
+    def apply_bounds(interval, i):
+        if bounds is None or len(bounds) <= i or len(bounds[i]) != 2:
+            return interval
+        lb, rb = bounds[i]
+        li, ri = interval
+        if lb is not None:
+            li = max(li, lb)
+        if rb is not None:
+            ri = min(ri, rb)
+        return li, ri
+
+    def random_params():
+        intervals = [apply_bounds((var / step, var * step), i) for i, var in enumerate(initial_guess)]
+        return [random.uniform(*iv) if fix[i] is None else fix[i] for i, iv in enumerate(intervals)]
+
+    if count < 1:
+        return []
+    return [initial_guess] + [random_params() for _ in range(count - 1)]

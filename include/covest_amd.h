@@ -1,0 +1,150 @@
+/*
+ * covest_amd.h -- C ABI of the MI355X (gfx950) likelihood grid-search library.
+ *
+ * This is the drop-in boundary for ONE path of mhozza/covest: the truncated-
+ * Poisson mixture log-likelihood evaluated over a parameter grid and reduced to
+ * its arg-min.  Plain C, caller-owned buffers, integer status codes, no torch or
+ * C++ types.  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference checkout, v0.5.6).  The ctypes binding a
+ * maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - All functions return 0 on success, a negative COVEST_E_* code on failure;
+ *     covest_last_error() returns a thread-local message for the last failure.
+ *   - Numeric outcomes are in-band IEEE values exactly as the reference returns
+ *     them: -inf when a non-zero bin has p_j == 0 (covest/utils.py:32-35), NaN
+ *     propagates, parameters outside the model bounds are clamped, never
+ *     rejected (covest/models.py:60-69).
+ *   - The library copies the histogram to the device at create time and keeps no
+ *     pointer of the caller's past any call.
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with COVEST_E_NO_DEVICE.
+ *   - A model handle is immutable after create; calls on one handle are
+ *     serialised internally, distinct handles are independent.
+ */
+#ifndef COVEST_AMD_H
+#define COVEST_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COVEST_ABI_VERSION 1
+
+#define COVEST_MODEL_BASIC 0   /* covest/models.py:17  BasicModel   (coverage, error_rate)          */
+#define COVEST_MODEL_REPEATS 1 /* covest/models.py:173 RepeatsModel (coverage, error_rate, q1,q2,q) */
+#define COVEST_MAX_PARAMS 5
+#define COVEST_MAX_ERROR_CLASSES 64
+
+#define COVEST_OK 0
+#define COVEST_E_INVALID (-1)   /* bad argument */
+#define COVEST_E_NO_DEVICE (-2) /* no HIP device / HIP runtime error at init */
+#define COVEST_E_HIP (-3)       /* HIP runtime error during a call */
+#define COVEST_E_NOMEM (-4)
+
+/* Kernel selection for covest_grid_eval / covest_eval_points (mostly for tests
+ * and benchmarks; AUTO picks the fastest kernel valid for the request). */
+#define COVEST_KERNEL_AUTO 0
+#define COVEST_KERNEL_DIRECT 1   /* one wavefront per grid point, one exp per pmf term        */
+#define COVEST_KERNEL_RECUR 2    /* one wavefront per grid point, pmf recurrence along j      */
+#define COVEST_KERNEL_FACTORED 3 /* repeats, dense grids: (c,e)-outer / (q1,q2,q)-inner reuse */
+
+typedef struct covest_model covest_model; /* opaque */
+typedef struct covest_grid covest_grid;   /* opaque */
+
+/* Arguments of the reference model constructors:
+ *   BasicModel.__init__   covest/models.py:19-31
+ *   RepeatsModel.__init__ covest/models.py:175-183
+ * `comb[s]` is the reference's self.comb[s] = comb(k, s) * 3**s (models.py:25),
+ * passed in so that the caller's scipy decides its rounding, as in the reference.
+ * `lo/hi` are self.bounds; NaN stands for Python None. */
+typedef struct {
+    int32_t kind;   /* COVEST_MODEL_* */
+    int32_t k;      /* k-mer size */
+    int32_t r;      /* read length */
+    int32_t n_err;  /* self.max_error = min(k + 1, max_error): error classes summed, 1..64 */
+    const double *comb;    /* [n_err] */
+    int64_t n_keys;        /* len(hist) */
+    const int32_t *keys;   /* hist keys j in dict order (zero-count keys included) */
+    const double *counts;  /* hist values h_j as doubles */
+    double tail;           /* self.tail */
+    double lo[COVEST_MAX_PARAMS];
+    double hi[COVEST_MAX_PARAMS];
+    double threshold;      /* RepeatsModel threshold (1e-8) */
+    int32_t has_threshold; /* 0: threshold is None */
+    int32_t device;        /* HIP device ordinal; -1 = the calling thread's current device */
+} covest_model_desc;
+
+/* Library / device probes (no reference counterpart). */
+int covest_abi_version(void);
+int covest_device_count(void); /* >= 0, or COVEST_E_NO_DEVICE */
+const char *covest_last_error(void);
+
+/* Model(k, r, hist, tail, max_error=, max_cov=, ...): covest/covest.py:136-140. */
+int covest_model_create(const covest_model_desc *desc, covest_model **out);
+void covest_model_destroy(covest_model *m);
+int covest_model_param_count(const covest_model *m); /* BasicModel.param_count, models.py:40-42 */
+/* number of histogram bins the kernels evaluate: all keys when tail != 0, else
+ * only keys with a non-zero count (the tail term of models.py:104 is then 0). */
+int64_t covest_model_bins_evaluated(const covest_model *m);
+
+/* RepeatsModel.get_hist_threshold(get_b_o(q1,q2,q), threshold): models.py:185-208.
+ * q123 is [n][3] (already clamped to the model bounds); out[n]; hist_max is
+ * max(self.hist); has_threshold == 0 stands for threshold None.  Pure host code
+ * (no device needed): computed with libm pow, as Python does, so that the
+ * integer cut-off cannot differ from the reference by a device ulp. */
+int covest_threshold_o(int64_t n, const double *q123, double threshold, int32_t has_threshold,
+                       int32_t hist_max, int32_t *out);
+
+/* model.compute_loglikelihood(*params) for a list of points: covest/models.py:100-107,
+ * batched like compute_loglikelihood_multi (models.py:109-117).
+ * params is [n][param_count] on the HOST; out_ll[n] on the HOST. */
+int covest_eval_points(covest_model *m, int64_t n, const double *params, double *out_ll,
+                       int32_t kernel);
+
+/* model.compute_probabilities(*params): models.py:81-98, :211-242.  out_p[n_keys]
+ * in key order (host).  clamp != 0 applies fit_to_bounds first, which is how
+ * compute_loglikelihood calls it (models.py:101-102); clamp == 0 is the raw
+ * method as plot_probs calls it.  Used by --plot and by the parity tests. */
+int covest_probabilities(covest_model *m, const double *params, int32_t clamp, double *out_p);
+
+/* Dense grid = itertools.product(*axes), last axis fastest (covest/grid.py:39-43,
+ * notebooks/VisualiseLikelihood.ipynb cell 5).  n_axes must equal param_count; a
+ * fixed parameter is an axis of length 1 (covest/grid.py:27-28).  The handle
+ * evaluates flat indices [flat_begin, flat_end) of the product -- one contiguous
+ * block per GPU (multi-GPU block partition); pass 0 and -1 for the whole grid.
+ * Axes are copied to the device here. */
+int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axes,
+                       const int64_t *axis_len, int64_t flat_begin, int64_t flat_end,
+                       covest_grid **out);
+void covest_grid_destroy(covest_grid *g);
+int64_t covest_grid_size(const covest_grid *g); /* flat_end - flat_begin */
+
+/* Evaluate LL at every point of the block into a device buffer owned by the
+ * handle and reduce it to (min -LL, lowest flat index attaining it) on the
+ * device.  Asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * Replaces the Pool.map + scan of covest/grid.py:63-70. */
+int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream);
+
+/* Wait for the last covest_grid_eval and return the reduction.  Selection is the
+ * scan of covest/grid.py:65-70 with maximize=False starting from +inf: strict <,
+ * lowest GLOBAL flat index wins ties, NaN never wins; argmin -1 if nothing is
+ * < +inf. */
+int covest_grid_argmin(covest_grid *g, double *min_negll, int64_t *argmin_flat);
+
+/* Device pointer of the block's LL values (double[grid_size], valid until
+ * destroy) and a copy to the host. */
+const double *covest_grid_ll_device(const covest_grid *g);
+int covest_grid_ll_host(covest_grid *g, double *out_ll);
+
+/* Work accounting of the last covest_grid_eval, for roofline reporting:
+ * pmf terms evaluated (bins_evaluated * n_err * sum(T-1)), log evaluations,
+ * and the name of the kernel that ran. */
+int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, const char **kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COVEST_AMD_H */

@@ -1,0 +1,414 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container, where /root/reference exists.  It
+  1. compiles the reference's C extension from the sources where they lie
+     (`make -C oracle ref` -> oracle/_ref/, git-ignored, never copied),
+  2. imports covest.models / covest.grid from /root/reference, and
+  3. writes DATA ONLY (inputs + the numbers the reference returned) as JSON and
+     `.hist` files next to this script.
+
+One session-local alias is needed: covest/models.py:10 does
+`from scipy.misc import comb`, which scipy >= 1.12 ships only as
+`scipy.special.comb` (same routine).  Nothing of the reference is modified or
+copied.  Interpreter-dependent semantics are recorded in every fixture's "env".
+
+Usage:  python tests/golden/make_golden.py [section ...]
+Sections: tp basic repeats threshold hists c1 c2 c3 gridtrace   (default: all)
+"""
+import itertools
+import json
+import math
+import multiprocessing
+import os
+import platform
+import random
+import subprocess
+import sys
+import time
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = os.environ.get("COVEST_REFERENCE", "/root/reference")
+REF_BUILD = os.path.join(REPO, "oracle", "_ref")
+
+
+def _import_reference():
+    subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "ref"],
+                          stdout=subprocess.DEVNULL)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    import scipy.misc
+    import scipy.special
+    if not hasattr(scipy.misc, "comb"):
+        scipy.misc.comb = scipy.special.comb
+    sys.path.insert(0, REF_BUILD)
+    sys.path.insert(0, REFERENCE)
+    import covest.constants
+    import covest.grid
+    import covest.models
+    covest.constants.VERBOSE = False
+    return covest
+
+
+covest = _import_reference()
+from covest.models import BasicModel, RepeatsModel  # noqa: E402
+from covest_poisson import truncated_poisson  # noqa: E402
+
+
+def env():
+    import numpy
+    import scipy
+    return {
+        "python": platform.python_version(),
+        "scipy": scipy.__version__,
+        "numpy": numpy.__version__,
+        "machine": platform.machine(),
+        "libc": " ".join(platform.libc_ver()),
+        "long_double_mant_dig": 64,
+        "reference": "mhozza/covest v0.5.6",
+        "note": "builtin sum() is naive left-to-right on this interpreter (< 3.12)",
+    }
+
+
+def dump(name, obj):
+    obj = dict(obj)
+    obj["env"] = env()
+    path = os.path.join(HERE, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, indent=0, separators=(",", ":"))
+        f.write("\n")
+    print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+
+
+def load_hist(path):
+    """Plain reader of the `.hist` text format ("j count" lines, '#' comments):
+    the format of covest/data.py:22-41, re-read here so Bio is not needed."""
+    hist = {}
+    with open(path) as f:
+        for line in f:
+            if not line.strip() or line[0] == "#":
+                continue
+            a, b = line.split()[:2]
+            hist[int(a)] = int(b)
+    return hist
+
+
+def save_hist(path, hist, comment):
+    with open(path, "w") as f:
+        f.write("# %s\n" % comment)
+        for j, v in hist.items():
+            f.write("%d %d\n" % (j, v))
+
+
+REF_HISTS = {
+    "sim_c10_e0.05": "tests/data/simulated_c10_e0.05_r100_k21.hist",
+    "sim_c10_e0.05_sparse": "tests/data/simulated_c10_e0.05_r100_k21_sparse.hist",
+    "sim_c10_e0": "tests/data/simulated_c10_e0_r100_k21.hist",
+}
+
+
+def ref_hist(name):
+    return load_hist(os.path.join(REFERENCE, REF_HISTS[name]))
+
+
+# ----------------------------------------------------------------------------- (1) tp
+def section_tp():
+    lams = [1e-12, 1e-9, 1e-8, 2e-8, 1e-3, 0.5, 1.0, 10.0, 199.9, 200.0, 200.1, 400.0, 1e3,
+            1.13e4, 1.14e4, 1.15e4, 1e5]
+    js = [1, 2, 3, 10, 100, 1000, 10000]
+    rows = [[l, j, truncated_poisson(l, j)] for l in lams for j in js]
+    rnd = random.Random(20240521)
+    for _ in range(400):
+        l = math.exp(rnd.uniform(math.log(1e-6), math.log(8e3)))
+        j = int(math.exp(rnd.uniform(0, math.log(9000)))) + 0
+        rows.append([l, max(1, j), truncated_poisson(l, max(1, j))])
+    dump("tp_table.json", {"what": "covest_poisson.truncated_poisson(l, j)", "rows": rows})
+
+
+# ----------------------------------------------------------------------------- (2) basic
+def basic_points(rnd):
+    pts = [(10.0, 0.0), (10.0, 0.01), (12.5, 0.05), (10.0, 0.05), (0.01, 0.1), (0.001, 0.1),
+           (10.0, 0.5), (10.0, 0.7), (0.01, 0.5), (1.0, 0.25), (50.0, 0.001), (3.0, 0.3),
+           (-1.0, -0.1), (10.0, 1e-9), (10.019077633773197, 0.04999234428925103)]
+    for _ in range(40):
+        pts.append((math.exp(rnd.uniform(math.log(0.5), math.log(60))), rnd.uniform(0, 0.5)))
+    return pts
+
+
+def section_basic():
+    rnd = random.Random(1)
+    cases = []
+    for hname in REF_HISTS:
+        hist = ref_hist(hname)
+        for max_error in (8, None):
+            for tail in (0, 1000):
+                m = BasicModel(21, 100, hist, tail, max_error=max_error)
+                pts = basic_points(rnd)
+                lls = [m.compute_loglikelihood(*p) for p in pts]
+                detail = []
+                for p in pts[:6]:
+                    a = m.fit_to_bounds(p)
+                    detail.append({"point": list(p),
+                                   "lambda_s": list(m._get_lambda_s(m.correct_c(a[0]), a[1])),
+                                   "p_j": [[j, v] for j, v in m.compute_probabilities(*a).items()]})
+                cases.append({"hist": hname, "k": 21, "r": 100, "tail": tail,
+                              "max_error": max_error, "points": [list(p) for p in pts],
+                              "ll": lls, "detail": detail})
+    # a max_cov bound (clamping from above) and another k/r
+    hist = ref_hist("sim_c10_e0.05")
+    m = BasicModel(21, 100, hist, 0, max_error=8, max_cov=8.0)
+    pts = [(10.0, 0.05), (8.0, 0.05), (7.5, 0.04), (100.0, 0.6)]
+    cases.append({"hist": "sim_c10_e0.05", "k": 21, "r": 100, "tail": 0, "max_error": 8,
+                  "max_cov": 8.0, "points": [list(p) for p in pts],
+                  "ll": [m.compute_loglikelihood(*p) for p in pts], "detail": []})
+    m = BasicModel(31, 150, hist, 17, max_error=5)
+    pts = basic_points(rnd)[:20]
+    cases.append({"hist": "sim_c10_e0.05", "k": 31, "r": 150, "tail": 17, "max_error": 5,
+                  "points": [list(p) for p in pts],
+                  "ll": [m.compute_loglikelihood(*p) for p in pts], "detail": []})
+    dump("basic_ll.json", {"what": "BasicModel.compute_loglikelihood", "cases": cases})
+
+
+# ----------------------------------------------------------------------------- (4) repeats
+def repeats_points(rnd):
+    pts = [(10.0, 0.01, 0.9, 0.5, 0.5), (1.0, 0.25, 0.65, 0.5, 0.5),
+           (10.0, 0.05, 0.6, 0.0, 0.3), (10.0, 0.05, 0.6, 0.5, 0.0),
+           (10.0, 0.05, 0.6, 0.5, 1.0), (10.0, 0.05, 1.0, 0.5, 0.5),
+           (10.0, 0.05, 0.3, 1.0, 0.5), (10.0, 0.0, 0.7, 0.4, 0.2),
+           (10.0, 0.05, 0.1, 0.5, 0.5), (10.0, 0.05, 0.5, 0.5, 0.001),
+           (10.007650292975498, 0.04998082334548104, 0.9990165657429007,
+            0.9503033556711812, 0.6552973697071148),
+           (0.001, 0.9, 0.2, 1.5, -0.2)]
+    for _ in range(60):
+        pts.append((math.exp(rnd.uniform(math.log(0.5), math.log(40))), rnd.uniform(0, 0.5),
+                    rnd.uniform(0.3, 1.0), rnd.uniform(0, 1), rnd.uniform(0, 1)))
+    return pts
+
+
+def section_repeats():
+    rnd = random.Random(2)
+    cases = []
+    for hname in REF_HISTS:
+        hist = ref_hist(hname)
+        for max_error, tail in ((8, 0), (8, 1000), (None, 0)):
+            m = RepeatsModel(21, 100, hist, tail, max_error=max_error)
+            pts = repeats_points(rnd)
+            if max_error is None:
+                pts = pts[:30]
+            lls = [m.compute_loglikelihood(*p) for p in pts]
+            detail = []
+            for p in pts[:4]:
+                a = m.fit_to_bounds(p)
+                detail.append({"point": list(p),
+                               "p_j": [[j, v] for j, v in m.compute_probabilities(*a).items()]})
+            cases.append({"hist": hname, "k": 21, "r": 100, "tail": tail, "max_error": max_error,
+                          "threshold": 1e-8, "min_single_copy_ratio": 0.3,
+                          "points": [list(p) for p in pts], "ll": lls, "detail": detail})
+    hist = ref_hist("sim_c10_e0.05")
+    m = RepeatsModel(21, 100, hist, 5, max_error=8, threshold=None, min_single_copy_ratio=0.5)
+    pts = repeats_points(rnd)[:20]
+    cases.append({"hist": "sim_c10_e0.05", "k": 21, "r": 100, "tail": 5, "max_error": 8,
+                  "threshold": None, "min_single_copy_ratio": 0.5,
+                  "points": [list(p) for p in pts],
+                  "ll": [m.compute_loglikelihood(*p) for p in pts], "detail": []})
+    dump("repeats_ll.json", {"what": "RepeatsModel.compute_loglikelihood", "cases": cases})
+
+
+# ----------------------------------------------------------------------------- (3) threshold
+def section_threshold():
+    rows = []
+    q1s = [0.3, 0.5, 0.65, 0.9, 0.999, 1.0]
+    q2s = [0.0, 0.25, 0.5, 0.95, 1.0]
+    qs = [0.0, 0.001, 0.01, 0.05, 0.1, 0.3, 0.5, 0.9, 0.95, 1.0]
+    for hist_max in (15, 256, 10000):
+        m = RepeatsModel(21, 100, {hist_max: 1, 1: 1}, 0, max_error=8)
+        for q1, q2, q in itertools.product(q1s, q2s, qs):
+            rows.append([hist_max, q1, q2, q, m.get_hist_threshold(m.get_b_o(q1, q2, q), 1e-8)])
+        rnd = random.Random(hist_max)
+        for _ in range(300):
+            q1, q2, q = rnd.uniform(0.3, 1), rnd.uniform(0, 1), rnd.uniform(0, 1)
+            rows.append([hist_max, q1, q2, q, m.get_hist_threshold(m.get_b_o(q1, q2, q), 1e-8)])
+    dump("threshold_o.json", {"what": "RepeatsModel.get_hist_threshold(get_b_o(q1,q2,q), 1e-8)",
+                              "columns": ["hist_max", "q1", "q2", "q", "threshold_o"],
+                              "rows": rows})
+
+
+# ----------------------------------------------------------------------------- synthetic hists
+SYNTH = {
+    # name: (model, B, theta*, N)   -- SURVEY.md 8(d)
+    "H256": ("basic", 256, (100.0, 0.02), 10 ** 7),
+    "H10k_basic": ("basic", 10000, (4000.0, 0.02), 10 ** 7),
+    "H10k_rep": ("repeats", 10000, (25.0, 0.02, 0.6, 0.5, 0.1), 10 ** 8),
+}
+
+
+def _tp_row(args):
+    model_name, B, theta, j0, j1 = args
+    keys = {j: 0 for j in range(1, B + 1)}
+    cls = BasicModel if model_name == "basic" else RepeatsModel
+    m = cls(21, 100, keys, 0, max_error=8)
+    m.hist = {j: 0 for j in range(j0, j1)}
+    if model_name == "repeats":  # threshold depends on max(hist): keep it at B
+        m.get_hist_threshold = lambda b_o, thr, _m=m, _B=B: _threshold_with_max(_m, b_o, thr, _B)
+    return list(m.compute_probabilities(*theta).items())
+
+
+def _threshold_with_max(m, b_o, thr, hist_max):
+    for o in range(1, hist_max):
+        if b_o(o) <= thr:
+            return o
+    return hist_max
+
+
+def synth_hist(name, pool):
+    model_name, B, theta, N = SYNTH[name]
+    path = os.path.join(HERE, name + ".hist")
+    if os.path.exists(path):
+        return load_hist(path)
+    t0 = time.time()
+    step = max(1, B // 64)
+    jobs = [(model_name, B, theta, j0, min(B + 1, j0 + step)) for j0 in range(1, B + 1, step)]
+    p = {}
+    for part in pool.map(_tp_row, jobs):
+        p.update(part)
+    hist = {j: int(round(N * p[j])) for j in range(1, B + 1)}
+    save_hist(path, hist, "%s: round(%d * p_j) of the reference %s model at %r, k=21 r=100 S=8, "
+              "keys 1..%d" % (name, N, model_name, theta, B))
+    print("synth", name, "nonzero", sum(1 for v in hist.values() if v), "sum", sum(hist.values()),
+          "%.1fs" % (time.time() - t0), flush=True)
+    return hist
+
+
+def section_hists(pool):
+    for name in SYNTH:
+        synth_hist(name, pool)
+
+
+# ----------------------------------------------------------------------------- (5) C1
+def linspace(a, b, n):
+    return [a + i * (b - a) / (n - 1) for i in range(n)]
+
+
+def _ll_job(args):
+    model_name, hist, tail, point = args
+    cls = BasicModel if model_name == "basic" else RepeatsModel
+    m = cls(21, 100, hist, tail, max_error=8)
+    t0 = time.time()
+    v = m.compute_loglikelihood(*point)
+    return v, time.time() - t0
+
+
+def section_c1(pool):
+    hist = synth_hist("H256", pool)
+    cs = [50 + i * 100 / 49 for i in range(50)]
+    es = [0.001 + i * 0.099 / 49 for i in range(50)]
+    grid = list(itertools.product(cs, es))
+    t0 = time.time()
+    res = pool.map(_ll_job, [("basic", hist, 0, p) for p in grid], chunksize=16)
+    ll = [v for v, _ in res]
+    best, arg = None, -1
+    for i, v in enumerate(ll):
+        if best is None or -v < best:
+            best, arg = -v, i
+    dump("c1_grid.json", {"what": "config 1: BasicModel on H256.hist, 50x50 (c,e) grid, "
+                                  "itertools.product order", "hist": "H256", "k": 21, "r": 100,
+                          "max_error": 8, "tail": 0, "c_axis": cs, "e_axis": es, "ll": ll,
+                          "argmin_flat": arg, "min_negll": best,
+                          "cpu_seconds_total_single_core": sum(t for _, t in res),
+                          "wall_seconds_pool": time.time() - t0})
+
+
+# ----------------------------------------------------------------------------- (6) C2 / C3 samples
+def section_c2(pool):
+    hist = synth_hist("H10k_basic", pool)
+    cs = linspace(2000.0, 6000.0, 1000)
+    es = linspace(0.001, 0.1, 1000)
+    rnd = random.Random(20240521)
+    idx = sorted(rnd.sample(range(10 ** 6), 256))
+    pts = [(cs[i // 1000], es[i % 1000]) for i in idx]
+    res = pool.map(_ll_job, [("basic", hist, 0, p) for p in pts], chunksize=4)
+    dump("c2_sample.json", {"what": "config 2: BasicModel on H10k_basic.hist, 256 seeded points of "
+                                    "the 1000x1000 grid c=linspace(2000,6000) e=linspace(0.001,0.1)",
+                            "hist": "H10k_basic", "k": 21, "r": 100, "max_error": 8, "tail": 0,
+                            "flat_index": idx, "points": [list(p) for p in pts],
+                            "ll": [v for v, _ in res],
+                            "cpu_seconds_per_point": [t for _, t in res]})
+
+
+def section_c3(pool):
+    hist = synth_hist("H10k_rep", pool)
+    cs = linspace(15.0, 30.0, 32)
+    es = linspace(0.005, 0.08, 32)
+    q1s = linspace(0.3, 0.95, 16)
+    qs = linspace(0.05, 0.95, 16)
+    rnd = random.Random(20240522)
+    idx = sorted(rnd.sample(range(32 * 32 * 16 * 16), 64))
+    pts = []
+    for i in idx:
+        ic, ie, iq1, iq = i // (32 * 256), (i // 256) % 32, (i // 16) % 16, i % 16
+        pts.append((cs[ic], es[ie], q1s[iq1], 0.5, qs[iq]))
+    # cheapest first would starve the pool at the end: longest (small q) first
+    order = sorted(range(len(pts)), key=lambda t: pts[t][4])
+    res_sorted = pool.map(_ll_job, [("repeats", hist, 0, pts[t]) for t in order], chunksize=1)
+    res = [None] * len(pts)
+    for t, r in zip(order, res_sorted):
+        res[t] = r
+    dump("c3_sample.json", {"what": "config 3: RepeatsModel on H10k_rep.hist, q2 fixed 0.5, 64 "
+                                    "seeded points of the 32x32x16x16 grid (c,e,q1,q)",
+                            "hist": "H10k_rep", "k": 21, "r": 100, "max_error": 8, "tail": 0,
+                            "flat_index": idx, "points": [list(p) for p in pts],
+                            "ll": [v for v, _ in res],
+                            "cpu_seconds_per_point": [t for _, t in res]})
+
+
+# ----------------------------------------------------------------------------- (7) grid traces
+class NegLogLikelihood:
+    """Picklable adapter with the contract of CoverageEstimator.likelihood_f
+    (covest/covest.py:26-31) for fix=None, err_scale=1: x -> -LL(*x)."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __call__(self, x):
+        return -self.model.compute_loglikelihood(*list(x))
+
+
+def section_gridtrace():
+    import covest.grid as G
+    out = []
+    for model_name in ("basic", "repeats"):
+        hist = ref_hist("sim_c10_e0.05")
+        cls = BasicModel if model_name == "basic" else RepeatsModel
+        m = cls(21, 100, hist, 0, max_error=8)
+        fn = NegLogLikelihood(m)
+        log = []
+        G.verbose_print = log.append
+        guess = [10.0, 0.05] if model_name == "basic" else [10.0, 0.05, 0.65, 0.5, 0.5]
+        t0 = time.time()
+        res = G.optimize_grid(fn, guess, bounds=list(m.bounds), fix=None, n_threads=8)
+        out.append({"model": model_name, "hist": "sim_c10_e0.05", "k": 21, "r": 100,
+                    "max_error": 8, "tail": 0, "initial_guess": guess,
+                    "bounds": [list(b) for b in m.bounds], "result": list(res),
+                    "result_negll": fn(res), "log": log, "wall_seconds": time.time() - t0})
+    dump("grid_trace.json", {"what": "covest.grid.optimize_grid(-LL, guess, bounds) verbose log",
+                             "traces": out})
+
+
+def main():
+    wanted = sys.argv[1:] or ["tp", "basic", "repeats", "threshold", "hists", "c1", "c2", "c3",
+                              "gridtrace"]
+    pool = multiprocessing.Pool(8)
+    for name in wanted:
+        t0 = time.time()
+        fn = globals()["section_" + name]
+        if name in ("hists", "c1", "c2", "c3"):
+            fn(pool)
+        else:
+            fn()
+        print("section", name, "%.1fs" % (time.time() - t0), flush=True)
+    pool.close()
+
+
+if __name__ == "__main__":
+    main()
