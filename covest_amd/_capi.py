@@ -24,7 +24,7 @@ EXPORTS = (
     "covest_model_bins_evaluated", "covest_threshold_o", "covest_eval_points",
     "covest_probabilities", "covest_grid_create", "covest_grid_destroy", "covest_grid_size",
     "covest_grid_eval", "covest_grid_argmin", "covest_grid_ll_device", "covest_grid_ll_host",
-    "covest_grid_work",
+    "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms",
 )
 
 
@@ -106,6 +106,10 @@ def lib():
     L.covest_grid_ll_host.argtypes = [vp, dp]
     L.covest_grid_work.restype = ctypes.c_int
     L.covest_grid_work.argtypes = [vp, dp, dp, ctypes.POINTER(ctypes.c_char_p)]
+    L.covest_grid_profile.restype = ctypes.c_int
+    L.covest_grid_profile.argtypes = [vp, i32]
+    L.covest_grid_kernel_ms.restype = ctypes.c_int
+    L.covest_grid_kernel_ms.argtypes = [vp, dp, ctypes.POINTER(i64)]
     _lib = L
     return L
 

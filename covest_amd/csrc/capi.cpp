@@ -99,6 +99,10 @@ struct covest_grid {
     const char *last_kernel = "none";
     hipStream_t last_stream = nullptr;
     bool evaluated = false;
+    // optional hipEvent bracketing of the likelihood kernel
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_begin, ev_end;
+    size_t ev_used = 0;
 };
 
 namespace {
@@ -527,7 +531,39 @@ void covest_grid_destroy(covest_grid *g)
     g->partial_val.release();
     g->partial_idx.release();
     g->result.release();
+    for (hipEvent_t e : g->ev_begin)
+        (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->ev_end)
+        (void)hipEventDestroy(e);
     delete g;
+}
+
+int covest_grid_profile(covest_grid *g, int32_t enable)
+{
+    if (!g)
+        return fail(COVEST_E_INVALID, "covest_grid_profile: null grid");
+    g->profiling = enable != 0;
+    g->ev_used = 0;
+    return COVEST_OK;
+}
+
+int covest_grid_kernel_ms(covest_grid *g, double *total_ms, int64_t *launches)
+{
+    if (!g || !total_ms || !launches)
+        return fail(COVEST_E_INVALID, "covest_grid_kernel_ms: null argument");
+    int rc = use_device(g->model);
+    if (rc != COVEST_OK)
+        return rc;
+    double sum = 0.0;
+    for (size_t i = 0; i < g->ev_used; ++i) {
+        HIP_TRY(hipEventSynchronize(g->ev_end[i]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g->ev_begin[i], g->ev_end[i]));
+        sum += (double)ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)g->ev_used;
+    return COVEST_OK;
 }
 
 int64_t covest_grid_size(const covest_grid *g) { return g ? g->flat_end - g->flat_begin : COVEST_E_INVALID; }
@@ -545,8 +581,24 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
         return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n = g->flat_end - g->flat_begin;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g->profiling) {
+        if (g->ev_used == g->ev_begin.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            g->ev_begin.push_back(a);
+            g->ev_end.push_back(b);
+        }
+        e0 = g->ev_begin[g->ev_used];
+        e1 = g->ev_end[g->ev_used];
+        g->ev_used++;
+        HIP_TRY(hipEventRecord(e0, st));
+    }
     HIP_TRY(launch_ll_direct(m->dm, g->src, n, g->ll.as<double>(), nullptr, st));
     g->last_kernel = "ll_direct";
+    if (e1)
+        HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->partial_val.as<double>(),
                           g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), st));
     g->last_stream = st;

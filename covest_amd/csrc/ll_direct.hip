@@ -15,7 +15,8 @@
 //   BasicModel.compute_loglikelihood    covest/models.py:100-107
 //   truncated_poisson                   c_src/covest_poissonmodule.c:7-35
 //
-// pmf term in the log domain:  TP(x, j) = exp(j*ln x - lgamma(j+1) - ln(e^x - 1)).
+// pmf term in the log domain:  TP(x, j) = exp(j*ln x - lgamma(j+1) - D(x)), D the log
+// of the normaliser the reference divides by (log_trunc_norm in point_fetch.h).
 // The reference's O(j) long-double product is replaced by this O(1) form; the
 // difference is bounded by the rounding of lgamma(j+1) (<= 1 ulp of ~8e4 at
 // j = 10^4, i.e. ~1e-11 relative on a term).
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(256) void ll_direct_kernel(const DevModel m, const 
     const double lam = error_class_rate(m, par[0], par[1], s);
     const double comb_s = m.comb[s];
 
-    double acc_ll = 0.0, acc_sp = 0.0;
+    double acc_ll = 0.0;
+    CompSum acc_sp = {0.0, 0.0};
     const int64_t n_bins = m.bins.n;
 
     for (int64_t base = 0; base < n_bins; base += (int64_t)kWave * kBinsPerLane) {
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void ll_direct_kernel(const DevModel m, const 
             const int o = o0 + og;
             const bool live = lane_in_tile && o < T;
             const double x = (double)o * lam;         // o * l_s[s]            models.py:238
-            const double ex = exp(-x);                // exp(o * -l_s[s])      models.py:221
+            const double ex = exp_neg_rn(x);          // exp(o * -l_s[s])      models.py:221
             const double n_os = comb_s * (1.0 - ex);  // NOT expm1, as the reference
             double tot = 0.0;                         // naive sum in s order  models.py:225
             for (int t = 0; t < S; ++t)
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void ll_direct_kernel(const DevModel m, const 
             const int64_t idx = base + (int64_t)b * kWave + lane;
             if (idx < n_bins) {
                 const double h = m.bins.cnt[idx];
-                acc_sp += p[b];
+                acc_sp.add(p[b]);
                 if (h != 0.0)
                     acc_ll += h * ((p[b] <= 0.0) ? -INFINITY : log(p[b]));
                 if (WRITE_P)
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void ll_direct_kernel(const DevModel m, const 
     acc_ll = wave_sum(acc_ll);
     double tail_term = 0.0;
     if (m.tail != 0.0) { // tail == 0: the term is 0 * finite = 0 in the reference
-        double sp = wave_sum(acc_sp);
+        double sp = wave_comp_sum(acc_sp);
         if (!(sp < 1.0))
             sp = 1.0; // min(1, fsum(...)), NaN -> 1
         if (sp < 1.0)

@@ -73,16 +73,75 @@ __device__ __forceinline__ double copy_number_weight(double q1, double q2, doubl
     return (1.0 - q1) * (1.0 - q2) * q * pow(1.0 - q, (double)(o - 3));
 }
 
-// log of the truncated-Poisson normaliser e^x - 1, following the reference's two
-// regimes (c_src/covest_poissonmodule.c:20,29-31): for x <= 1e-8 it divides by x
-// itself, above by expl(x) - 1.
+// exp(-x), x >= 0, as the reference's libm returns it.  The mixture weights are
+// n_os = comb[s] * (1.0 - exp(o * -l_s)) (covest/models.py:87,221) -- deliberately
+// NOT expm1 -- so for small x the last bit of exp(-x) decides n_os to a relative
+// 1.1e-16 / x (1e-8 at x = 1e-8).  glibc's exp is correctly rounded there to
+// within a 1e-8 ulp margin, so the correctly rounded value is computed here from
+// the Taylor series in double-double instead of trusting the device library's
+// last bit.  Above 2^-6 that sensitivity is < 1e-14 and the device exp is used.
+__device__ __forceinline__ double exp_neg_rn(double x)
+{
+    if (!(x < 0.015625))
+        return exp(-x);
+    const double p = x * x;
+    const double pe = fma(x, x, -p); // x^2 = p + pe exactly
+    const double tail = (p * x) * (-1.0 / 6 + x * (1.0 / 24 + x * (-1.0 / 120 + x * (1.0 / 720 +
+                        x * (-1.0 / 5040 + x * (1.0 / 40320 + x * (-1.0 / 362880)))))));
+    double s, e, r, e2;
+    const double mx = -x, hp = 0.5 * p;
+    s = mx + hp; // two-sum of -x and x^2/2
+    {
+        const double bb = s - mx;
+        e = (mx - (s - bb)) + (hp - bb);
+    }
+    const double lo = e + (0.5 * pe + tail);
+    r = 1.0 + s; // two-sum of 1 and s
+    {
+        const double bb = r - 1.0;
+        e2 = (1.0 - (r - bb)) + (s - bb);
+    }
+    return r + (e2 + lo);
+}
+
+// log of the normaliser the reference divides the pmf product by
+// (c_src/covest_poissonmodule.c:20,25-31).  It is NOT log(e^x - 1) for x > 200:
+// the extension divides by e^200 once per 200 taken off x and then by
+// expl(x_res) - 1 of the residual x_res in (0, 200], i.e. by
+// e^(200 n) * (e^x_res - 1), which is SMALLER than e^x - 1 by the factor
+// (1 - e^-x_res): the reference's pmf is too large by up to 1/(1 - e^-x_res) when
+// x is just above a multiple of 200.  Parity is with what the reference computes,
+// so this is reproduced, together with its two small-argument branches: x <= 1e-8 divides by
+// x itself (:20,29), and a residual <= 1e-8 divides by the ORIGINAL x (:29-31).
 __device__ __forceinline__ double log_trunc_norm(double x, double log_x)
 {
     if (x <= 1e-8)
         return log_x;
-    if (x < 1.0)
-        return log(expm1(x));
-    return x + log1p(-exp(-x));
+    double base = 0.0, xr = x;
+    if (x > 200.0) {
+        double n = ceil(x / 200.0) - 1.0;
+        xr = fma(-200.0, n, x); // exact: x and 200 n are multiples of ulp(x)
+        if (xr > 200.0) {
+            n += 1.0;
+            xr -= 200.0;
+        } else if (xr <= 0.0) {
+            n -= 1.0;
+            xr += 200.0;
+        }
+        base = 200.0 * n;
+        if (xr <= 1e-8)
+            return base + log_x;
+    }
+    if (xr < 1.0) {
+        // expl(x) - 1 in x87 long double: e^x is rounded to a 2^-63 grid BEFORE the
+        // subtraction (:30), a relative noise of up to 2^-64 / x (5e-12 at 1e-8) that
+        // the tail term tail*log(1 - sp_j) amplifies when sp_j is close to 1.
+        double m = expm1(xr);
+        if (xr < 0x1p-10)
+            m = rint(m * 0x1p63) * 0x1p-63;
+        return base + log(m);
+    }
+    return base + (xr + log1p(-exp(-xr)));
 }
 
 } // namespace covest

@@ -26,4 +26,38 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Error-free transformation: a + b = s + e exactly (Knuth two-sum, 6 flops).
+__device__ __forceinline__ void two_sum(double a, double b, double &s, double &e)
+{
+    s = a + b;
+    const double bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
+}
+
+// Compensated accumulator (hi + lo): the stand-in for math.fsum at
+// covest/models.py:103.  Adding n non-negative terms leaves an error of O(eps^2 n),
+// i.e. hi + lo is the correctly rounded sum for every n that occurs here.
+struct CompSum {
+    double hi, lo;
+    __device__ __forceinline__ void add(double x)
+    {
+        double e;
+        two_sum(hi, x, hi, e);
+        lo += e;
+    }
+};
+
+__device__ __forceinline__ double wave_comp_sum(CompSum v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ohi = __shfl_xor(v.hi, off, kWave);
+        const double olo = __shfl_xor(v.lo, off, kWave);
+        double e;
+        two_sum(v.hi, ohi, v.hi, e);
+        v.lo += olo + e;
+    }
+    return v.hi + v.lo;
+}
+
 } // namespace covest

@@ -167,6 +167,18 @@ class DenseGrid:
                                                  ctypes.byref(name)), "covest_grid_work")
         return t.value, f.value, (name.value or b"").decode()
 
+    def profile(self, enable=True):
+        """Bracket every likelihood launch with hipEvents (see kernel_ms)."""
+        _capi.check(_capi.lib().covest_grid_profile(self._handle, 1 if enable else 0),
+                    "covest_grid_profile")
+
+    def kernel_ms(self):
+        """(summed device ms of the likelihood kernel, launches) since profile(True)."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        _capi.check(_capi.lib().covest_grid_kernel_ms(self._handle, ctypes.byref(ms), ctypes.byref(n)),
+                    "covest_grid_kernel_ms")
+        return ms.value, n.value
+
     def point(self, flat_index):
         """Parameter tuple at a flat itertools.product index."""
         idx = np.unravel_index(int(flat_index), self.shape)

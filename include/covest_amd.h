@@ -144,6 +144,14 @@ int covest_grid_ll_host(covest_grid *g, double *out_ll);
  * and the name of the kernel that ran. */
 int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, const char **kernel);
 
+/* Device-side timing of the likelihood kernel alone (not the arg-min pass), for
+ * roofline reporting: with profiling enabled every covest_grid_eval brackets its
+ * likelihood launch with hipEvents on the launch stream; covest_grid_kernel_ms
+ * waits for them and returns the summed duration and the number of launches
+ * since profiling was (re-)enabled. */
+int covest_grid_profile(covest_grid *g, int32_t enable);
+int covest_grid_kernel_ms(covest_grid *g, double *total_ms, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

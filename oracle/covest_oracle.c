@@ -10,7 +10,7 @@
  * (reference tests/test_models.py:8-19 only checks the model registry), so the
  * oracle is pinned by golden vectors generated in the build container by
  * importing the reference itself (tests/golden/make_golden.py, fixtures under
- * tests/golden/*.json) and, when oracle/_ref/ is built, by calling the
+ * tests/golden/ *.json) and, when oracle/_ref/ is built, by calling the
  * reference's compiled C extension side by side (tests/test_oracle_vs_ref.py).
  *
  * Every function cites the reference file:line it restates.  Paths are relative
