@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""bench.py -- grid-point log-likelihood evals/s of the likelihood grid search.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1] [--kernel auto]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: every
+point of this rank's block of a dense parameter grid is evaluated on the GPU
+(likelihood kernel), reduced to (min -LL, lowest index) on the GPU (arg-min
+kernels), the 16-byte result is read back, and -- for N > 1 -- the global winner
+is agreed with one RCCL all-reduce(min) pair.  The histogram (model handle) and
+the grid axes are resident in HBM before the timed region starts.
+
+Workloads; the default is the one BASELINE.json's metric is
+quoted on (repeat model, 10k-bin histogram):
+  c3  RepeatsModel, H10k_rep.hist (10 000 keys), 32x32x16x1x16 grid (c,e,q1,q2=0.5,q)
+  c2  BasicModel,   H10k_basic.hist (10 000 keys), 1000x1000 grid (c,e)
+  c1  BasicModel,   H256.hist, 50x50 grid (the reference's CPU-runnable case)
+Weak scaling: with N ranks the c axis has N times as many values over the same
+range and the flat index range is block-partitioned, one contiguous block of the
+single-GPU size per rank.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == dense fp64 matrix peak (AMD spec; 256 CU x 128 flop/clk x 2.4 GHz)
+HBM_PEAK_GBPS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def load_hist(name):
+    hist = {}
+    with open(os.path.join(REPO, "tests", "golden", name + ".hist")) as f:
+        for line in f:
+            if not line.strip() or line[0] == "#":
+                continue
+            a, b = line.split()[:2]
+            hist[int(a)] = int(b)
+    return hist
+
+
+def workload(name, n_ranks):
+    """(model kind, histogram name, axes) -- SURVEY.md 8(d)."""
+    if name == "c3":
+        axes = [np.linspace(15.0, 30.0, 32 * n_ranks), np.linspace(0.005, 0.08, 32),
+                np.linspace(0.3, 0.95, 16), np.array([0.5]), np.linspace(0.05, 0.95, 16)]
+        return "repeats", "H10k_rep", axes
+    if name == "c2":
+        return "basic", "H10k_basic", [np.linspace(2000.0, 6000.0, 1000 * n_ranks),
+                                       np.linspace(0.001, 0.1, 1000)]
+    if name == "c1":
+        return "basic", "H256", [np.array([50 + i * 100 / (50 * n_ranks - 1) for i in range(50 * n_ranks)]),
+                                 np.array([0.001 + i * 0.099 / 49 for i in range(50)])]
+    raise SystemExit("unknown workload %r" % name)
+
+
+def host_threads(cap=16):
+    """Threads the CPU baseline may use: CPU affinity, limited by the cgroup quota
+    (the GPU box grants a 16-CPU share whatever the affinity mask says)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(kind, hist, axes, budget_s, seed=20240521):
+    """The oracle (faithful restatement of the reference's O(j) long-double pmf
+    product) timed on this host's cores on a bounded, seeded sample of the same
+    grid.  Its cost per point is exactly proportional to (T-1) [x S x sum of
+    keys], so the sample is drawn from the points whose predicted cost fits the
+    budget and the rate is extrapolated to the whole grid BY WORK."""
+    from oracle import covest_oracle as orc
+    import itertools
+    threads = host_threads()
+    om = orc.OracleModel(kind, 21, 100, hist, 0, max_error=8)
+    shape = [len(a) for a in axes]
+    total = int(np.prod(shape))
+    rng = np.random.default_rng(seed)
+    if kind == "repeats":
+        qs = np.array(list(itertools.product(*axes[2:5])))
+        t_sub = np.array([orc.threshold_o(q1, q2, q, 1e-8, max(hist)) for q1, q2, q in qs])
+        cost_sub = np.maximum(t_sub - 1, 0).astype(np.float64)
+        mean_cost = float(cost_sub.mean())
+    else:
+        cost_sub = np.ones(1)
+        mean_cost = 1.0
+    n_sub = len(cost_sub)
+    # calibrate seconds per unit of (T-1) on one cheapest point, single thread
+    probe_sub = int(np.argmin(np.where(cost_sub > 0, cost_sub, np.inf)))
+    probe_flat = probe_sub  # (c, e) index 0
+    probe = [float(a[i]) for a, i in zip(axes, np.unravel_index(probe_flat, shape))]
+    t0 = time.perf_counter()
+    om.compute_loglikelihood_many(np.array([probe]), n_threads=1)
+    sec_per_unit = (time.perf_counter() - t0) / max(cost_sub[probe_sub], 1.0)
+    cap_units = max(1.0, budget_s / sec_per_unit)               # no single point longer than the budget
+    want_units = budget_s * threads / sec_per_unit              # whole sample ~ budget on all threads
+    order = rng.permutation(total)
+    picked, units = [], 0.0
+    for flat in order:
+        u = float(cost_sub[flat % n_sub])
+        if u <= 0 or u > cap_units:
+            continue
+        picked.append(int(flat))
+        units += u
+        if units >= want_units or len(picked) >= 4096:
+            break
+    pts = np.array([[float(a[i]) for a, i in zip(axes, np.unravel_index(f, shape))] for f in picked])
+    t0 = time.perf_counter()
+    om.compute_loglikelihood_many(pts, n_threads=threads)
+    wall = time.perf_counter() - t0
+    evals_per_s = (units / wall) / mean_cost
+    model_name = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": evals_per_s, "unit": "evals/s", "cores": threads, "kind": "port",
+        "sample": "%d seeded grid points (sum(T-1)=%d, each <= %d) in %.1f s on %d threads of %s; "
+                  "whole-grid rate extrapolated by work (grid mean T-1 = %.2f); oracle = faithful "
+                  "O(j) long-double restatement of the reference" % (
+                      len(picked), int(units), int(cap_units), wall, threads, model_name or "host CPU",
+                      mean_cost),
+        "sample_points": len(picked), "sample_wall_s": wall,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3"])
+    ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from covest_amd import BasicModel, DenseGrid, RepeatsModel
+    from covest_amd.grid import distributed_argmin
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    kind, hist_name, axes = workload(args.workload, world)
+    hist = load_hist(hist_name)
+    cls = BasicModel if kind == "basic" else RepeatsModel
+
+    # ---- time-to-argmin: host axes + histogram -> global (min, index) on the host ----
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model = cls(21, 100, hist, 0, max_error=8, device=local_rank)
+    shape = [len(a) for a in axes]
+    total = int(np.prod(shape))
+    per_rank = total // world
+    block = (rank * per_rank, (rank + 1) * per_rank if rank < world - 1 else total)
+    grid = DenseGrid(model, axes, block)
+    stream = torch.cuda.current_stream().cuda_stream
+    grid.evaluate(kernel=args.kernel, stream=stream)
+    lmin, lidx = grid.argmin()
+    gmin, gidx = distributed_argmin(lmin, lidx, device=device)
+    time_to_argmin_first = time.perf_counter() - t0   # includes HIP module load on first use
+
+    def step():
+        grid.evaluate(kernel=args.kernel, stream=stream)
+        lm, li = grid.argmin()
+        return distributed_argmin(lm, li, device=device)
+
+    for _ in range(args.warmup):
+        step()
+    # warm time-to-argmin (library and context warm; model + grid handles re-created)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model2 = cls(21, 100, hist, 0, max_error=8, device=local_rank)
+    grid2 = DenseGrid(model2, axes, block)
+    grid2.evaluate(kernel=args.kernel, stream=stream)
+    lm, li = grid2.argmin()
+    distributed_argmin(lm, li, device=device)
+    time_to_argmin_warm = time.perf_counter() - t0
+    grid2.close()
+    model2.close()
+
+    grid.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gmin, gidx = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, launches = grid.kernel_ms()
+    grid.profile(False)
+    terms, flops, kernel_name = grid.work()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total * args.steps / elapsed
+        avg_kernel_s = 1e-3 * kernel_ms / max(launches, 1)
+        achieved_tflops = flops / avg_kernel_s / 1e12
+        n_local = block[1] - block[0]
+        # algorithmic HBM bytes of one launch: axes in, 8 B/point LL out, histogram once
+        alg_bytes = 8.0 * sum(shape) + 8.0 * n_local + 24.0 * model.bins_evaluated
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get(args.workload, {}).get(kernel_name)
+            except (OSError, ValueError):
+                traffic = None
+        out = {
+            "metric": "grid-point log-likelihood evals/s, repeat model, 10k-bin hist"
+                      if args.workload == "c3" else "grid-point log-likelihood evals/s (%s)" % args.workload,
+            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": {"c3": "C3: RepeatsModel k=21 r=100 S=8, H10k_rep.hist (10000 keys, %d evaluated: tail=0), "
+                                   "grid c%dxe32xq1 16xq2 1xq 16" % (model.bins_evaluated, shape[0]),
+                             "c2": "C2: BasicModel k=21 r=100 S=8, H10k_basic.hist (10000 keys, %d evaluated: tail=0), "
+                                   "grid c%dxe1000" % (model.bins_evaluated, shape[0]),
+                             "c1": "C1: BasicModel k=21 r=100 S=8, H256.hist, grid c%dxe50" % shape[0]}[args.workload],
+                "grid_points": total, "points_per_gpu": n_local, "kernel": kernel_name,
+                "partition": "contiguous flat-index block per GPU, one RCCL all-reduce(min) pair per step",
+            },
+            "argmin": {"min_negll": gmin, "flat_index": gidx},
+            "time_to_argmin_ms": {"first_call_incl_module_load": 1e3 * time_to_argmin_first,
+                                  "warm": 1e3 * time_to_argmin_warm},
+            "roofline": {
+                "bound": "mfma", "pipe": "fp64 VALU; 78.6 TFLOP/s is both the fp64 vector and the dense fp64 MFMA peak of MI355X",
+                "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
+                "kernel": kernel_name, "kernel_ms_avg": 1e3 * avg_kernel_s, "launches": launches,
+                "algorithmic_flops_per_launch": flops, "pmf_terms_per_launch": terms,
+                "hbm": {"achieved": alg_bytes / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": alg_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBPS,
+                        "algorithmic_bytes_per_launch": alg_bytes},
+            },
+        }
+        if world == 1 and args.cpu_budget > 0:
+            out["cpu_baseline"] = cpu_baseline(kind, hist, axes, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+
+    grid.close()
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
