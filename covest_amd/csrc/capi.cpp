@@ -4,6 +4,7 @@
 // likelihood value comes out of a gfx950 kernel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -84,6 +85,10 @@ struct covest_model {
     bool has_threshold = true;
     // device storage of the two bin views
     DevBuf bins_eval, bins_all;
+    // tile table of the pmf recurrence (fast kernels); has_tiles == false -> direct kernel only
+    DevBuf tiles_buf;
+    TileView tv{};
+    bool has_tiles = false;
     // scratch for covest_eval_points / covest_probabilities
     DevBuf ws_params, ws_t, ws_out, ws_p;
     std::mutex lock;
@@ -196,6 +201,103 @@ int upload_bins(DevBuf &buf, BinView &view, const std::vector<double> &key,
     return COVEST_OK;
 }
 
+// Tile table of streams.h over the evaluated bins: keys sorted ascending, split
+// into runs of consecutive keys (gaps of up to kGapFill keys are bridged with
+// filler keys that are stepped over but neither logged nor summed), each run cut
+// into tiles of <= 32 keys.  Returns false when the fast kernels do not apply.
+constexpr int kGapFill = 12;
+constexpr int kMaxFastKey = 16384;
+
+struct HostBin {
+    int key;
+    double cnt;
+};
+
+int build_tiles(covest_model *m, std::vector<HostBin> bins)
+{
+    m->has_tiles = false;
+    if (m->dm.n_err != 8 || bins.empty())
+        return COVEST_OK;
+    std::sort(bins.begin(), bins.end(), [](const HostBin &a, const HostBin &b) { return a.key < b.key; });
+    if (bins.front().key < 1 || bins.back().key > kMaxFastKey)
+        return COVEST_OK;
+    struct Tile {
+        int k0, nb, run_start;
+    };
+    std::vector<Tile> tiles;
+    std::vector<double> scal, cnt, insp;
+    size_t i = 0;
+    while (i < bins.size()) {
+        // one run: keys bins[i..j) with gaps <= kGapFill
+        size_t j = i + 1;
+        while (j < bins.size() && bins[j].key - bins[j - 1].key <= kGapFill + 1)
+            ++j;
+        const int first = bins[i].key, last = bins[j - 1].key;
+        size_t cur = i;
+        for (int k0 = first; k0 <= last; k0 += kTileBins) {
+            const int nb = std::min(kTileBins, last - k0 + 1);
+            tiles.push_back({k0, nb, k0 == first ? 1 : 0});
+            long double sc = ldexpl(1.0L, -kScaleBits);
+            for (int b = 0; b < kTileBins; ++b) {
+                double sv = 0.0, cv = 0.0, iv = 0.0;
+                if (b < nb) {
+                    const int key = k0 + b;
+                    sc /= (long double)key;
+                    sv = (double)sc;
+                    if (cur < j && bins[cur].key == key) {
+                        cv = bins[cur].cnt;
+                        iv = 1.0;
+                        ++cur;
+                    }
+                }
+                scal.push_back(sv);
+                cnt.push_back(cv);
+                insp.push_back(iv);
+            }
+        }
+        i = j;
+    }
+    const size_t nt = tiles.size();
+    // layout: [first_key | lgam_prev | lgam_last | renorm] doubles, then scal/cnt/in_sp, then int32 n_bins/run_start
+    std::vector<double> dbl(4 * nt);
+    std::vector<int32_t> ints(2 * nt);
+    for (size_t t = 0; t < nt; ++t) {
+        const Tile &tl = tiles[t];
+        dbl[t] = (double)tl.k0;
+        dbl[nt + t] = (double)lgammal((long double)tl.k0);
+        dbl[2 * nt + t] = (double)lgammal((long double)(tl.k0 + tl.nb));
+        long double rn = 1.0L;
+        for (int b = 0; b < tl.nb; ++b)
+            rn /= (long double)(tl.k0 + b);
+        dbl[3 * nt + t] = (double)rn;
+        ints[t] = tl.nb;
+        ints[nt + t] = tl.run_start;
+    }
+    const size_t n_dbl = 4 * nt + 3 * nt * kTileBins;
+    HIP_TRY(m->tiles_buf.reserve(n_dbl * sizeof(double) + 2 * nt * sizeof(int32_t)));
+    double *base = m->tiles_buf.as<double>();
+    HIP_TRY(hipMemcpy(base, dbl.data(), 4 * nt * sizeof(double), hipMemcpyHostToDevice));
+    double *per_bin = base + 4 * nt;
+    HIP_TRY(hipMemcpy(per_bin, scal.data(), nt * kTileBins * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(per_bin + nt * kTileBins, cnt.data(), nt * kTileBins * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(per_bin + 2 * nt * kTileBins, insp.data(), nt * kTileBins * sizeof(double), hipMemcpyHostToDevice));
+    int32_t *ibase = reinterpret_cast<int32_t *>(base + n_dbl);
+    HIP_TRY(hipMemcpy(ibase, ints.data(), 2 * nt * sizeof(int32_t), hipMemcpyHostToDevice));
+    TileView &tv = m->tv;
+    tv.n_tiles = (int32_t)nt;
+    tv.first_key = base;
+    tv.lgam_prev = base + nt;
+    tv.lgam_last = base + 2 * nt;
+    tv.renorm = base + 3 * nt;
+    tv.scal = per_bin;
+    tv.cnt = per_bin + nt * kTileBins;
+    tv.in_sp = per_bin + 2 * nt * kTileBins;
+    tv.n_bins = ibase;
+    tv.run_start = ibase + nt;
+    m->has_tiles = true;
+    return COVEST_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -273,6 +375,7 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
     // 0 whatever sp_j is (0 * log of a positive number, or the else-branch), so
     // bins with h_j == 0 influence nothing and are dropped from the evaluated view.
     std::vector<double> key_a, lg_a, cnt_a, key_e, lg_e, cnt_e;
+    std::vector<HostBin> eval_bins;
     key_a.reserve(d->n_keys);
     int hist_max = std::numeric_limits<int>::min();
     for (int64_t b = 0; b < d->n_keys; ++b) {
@@ -290,6 +393,7 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
             key_e.push_back(kd);
             lg_e.push_back(lg);
             cnt_e.push_back(h);
+            eval_bins.push_back({j, h});
         }
     }
     m->hist_max = d->n_keys > 0 ? hist_max : 0;
@@ -299,6 +403,8 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
         rc = upload_bins(m->bins_all, m->all_bins, key_a, lg_a, cnt_a);
     if (rc == COVEST_OK)
         rc = upload_bins(m->bins_eval, dm.bins, key_e, lg_e, cnt_e);
+    if (rc == COVEST_OK)
+        rc = build_tiles(m, std::move(eval_bins));
     if (rc != COVEST_OK) {
         covest_model_destroy(m);
         return rc;
@@ -314,6 +420,7 @@ void covest_model_destroy(covest_model *m)
     (void)hipSetDevice(m->device);
     m->bins_eval.release();
     m->bins_all.release();
+    m->tiles_buf.release();
     m->ws_params.release();
     m->ws_t.release();
     m->ws_out.release();
@@ -336,11 +443,36 @@ int covest_threshold_o(int64_t n, const double *q123, double threshold, int32_t 
     return COVEST_OK;
 }
 
-static int pick_kernel(int32_t kernel)
+// Resolve COVEST_KERNEL_* for a request.  Returns the kernel to run or a negative error.
+static int resolve_kernel(const covest_model *m, int32_t kernel, bool is_grid)
 {
-    if (kernel == COVEST_KERNEL_AUTO)
+    (void)is_grid;
+    const bool basic_fast = m->has_tiles && m->dm.kind == COVEST_MODEL_BASIC;
+    switch (kernel) {
+    case COVEST_KERNEL_AUTO:
+        return basic_fast ? COVEST_KERNEL_RECUR : COVEST_KERNEL_DIRECT;
+    case COVEST_KERNEL_DIRECT:
         return COVEST_KERNEL_DIRECT;
-    return kernel;
+    case COVEST_KERNEL_RECUR:
+        if (basic_fast)
+            return COVEST_KERNEL_RECUR;
+        return fail(COVEST_E_INVALID, "recurrence kernel needs the basic model, max_error 8 and keys in 1..16384");
+    default:
+        return fail(COVEST_E_INVALID, "kernel not available for this request");
+    }
+}
+
+static hipError_t launch_ll(const covest_model *m, int kernel, const PointSource &src, int64_t n,
+                            double *out, hipStream_t st, const char **name)
+{
+    if (kernel == COVEST_KERNEL_RECUR) {
+        if (name)
+            *name = "ll_basic";
+        return launch_ll_basic(m->dm, m->tv, src, n, out, st);
+    }
+    if (name)
+        *name = "ll_direct";
+    return launch_ll_direct(m->dm, src, n, out, nullptr, st);
 }
 
 int covest_eval_points(covest_model *m, int64_t n, const double *params, double *out_ll,
@@ -350,8 +482,9 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         return fail(COVEST_E_INVALID, "covest_eval_points: bad argument");
     if (n == 0)
         return COVEST_OK;
-    if (pick_kernel(kernel) != COVEST_KERNEL_DIRECT)
-        return fail(COVEST_E_INVALID, "covest_eval_points: kernel not available for point lists");
+    const int kern = resolve_kernel(m, kernel, false);
+    if (kern < 0)
+        return kern;
     std::lock_guard<std::mutex> guard(m->lock);
     int rc = use_device(m);
     if (rc != COVEST_OK)
@@ -371,7 +504,7 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         HIP_TRY(hipMemcpy(m->ws_t.ptr, t.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
         src.t_list = m->ws_t.as<int32_t>();
     }
-    HIP_TRY(launch_ll_direct(m->dm, src, n, m->ws_out.as<double>(), nullptr, nullptr));
+    HIP_TRY(launch_ll(m, kern, src, n, m->ws_out.as<double>(), nullptr, nullptr));
     HIP_TRY(hipMemcpy(out_ll, m->ws_out.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return COVEST_OK;
 }
@@ -573,8 +706,9 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
     if (!g)
         return fail(COVEST_E_INVALID, "covest_grid_eval: null grid");
     covest_model *m = g->model;
-    if (pick_kernel(kernel) != COVEST_KERNEL_DIRECT)
-        return fail(COVEST_E_INVALID, "covest_grid_eval: kernel not available");
+    const int kern = resolve_kernel(m, kernel, true);
+    if (kern < 0)
+        return kern;
     std::lock_guard<std::mutex> guard(m->lock);
     int rc = use_device(m);
     if (rc != COVEST_OK)
@@ -595,8 +729,7 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
         g->ev_used++;
         HIP_TRY(hipEventRecord(e0, st));
     }
-    HIP_TRY(launch_ll_direct(m->dm, g->src, n, g->ll.as<double>(), nullptr, st));
-    g->last_kernel = "ll_direct";
+    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), st, &g->last_kernel));
     if (e1)
         HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->partial_val.as<double>(),

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "device_model.h"
+#include "tiles.h"
 
 namespace covest {
 
@@ -12,6 +13,11 @@ namespace covest {
 // of `m.bins`.
 hipError_t launch_ll_direct(const DevModel &m, const PointSource &src, int64_t n, double *out_ll,
                             double *out_p, hipStream_t stream);
+
+// K-basic: basic model, one lane per grid point, pmf recurrence (ll_basic.hip).
+// Needs n_err == 8 and a tile table (keys in 1..16384).
+hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSource &src, int64_t n,
+                           double *out_ll, hipStream_t stream);
 
 // (min -LL, lowest index) over ll[n]: two-stage reduction (argmin.hip).
 // partial_val/partial_idx need kArgminBlocks entries; result[0] = {min, bits of idx}.

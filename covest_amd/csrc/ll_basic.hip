@@ -1,0 +1,106 @@
+// ll_basic.hip -- K-basic: the fast likelihood kernel of the BASIC model.
+//
+// One LANE per grid point: a wave64 evaluates 64 consecutive points of the flat
+// grid order (or of a point list).  Every lane walks the histogram keys in
+// ascending order with the pmf recurrence of streams.h (S error-class streams in
+// registers, 2 fp64 instructions per pmf term), so the key, its count h_j and
+// the per-key scale are WAVE-UNIFORM: they come from the tile table through the
+// scalar cache into SGPRs, there is no LDS traffic, no cross-lane operation and
+// no divergence (neighbouring lanes differ only in (c, e)).  One log per
+// (point, non-zero bin) -- the dominant cost of this kernel once the terms are
+// down to 2 instructions.
+//
+// Reference restated: BasicModel.compute_probabilities / compute_loglikelihood,
+// covest/models.py:81-107, over the grid of covest/grid.py:59-64.
+//
+// Roofline: fp64 VALU.  Per point: S*B pmf terms (2 instr each) + B logs.
+// Algorithmic HBM bytes: 16 in (or the two axes) + 8 out per point.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "point_fetch.h"
+#include "streams.h"
+#include "wave.h"
+
+namespace covest {
+
+namespace {
+
+template <int S>
+__global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const TileView tv,
+                                                       const PointSource src, const int64_t n,
+                                                       double *__restrict__ out_ll)
+{
+    const int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = pt < n;
+    const int64_t ptc = live ? pt : n - 1; // idle lanes shadow the last point: every lane stays in the wave ops
+
+    double par[kMaxParams];
+    int T;
+    fetch_point<2>(src, ptc, par, T);
+    clamp_point<2>(m, par);
+    const bool finite = isfinite(par[0]) && isfinite(par[1]);
+
+    double lam[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        lam[s] = error_class_rate(m, par[0], par[1], s);
+    StreamSet<S> st;
+    st.init(m, lam, 1, finite);
+
+    double acc_ll = 0.0;
+    CompSum acc_sp = {0.0, 0.0};
+    const bool want_sp = m.tail != 0.0;
+
+    for (int t = 0; t < tv.n_tiles; ++t) {
+        const double k0 = tv.first_key[t];
+        const int nb = tv.n_bins[t];
+        st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
+                      tv.run_start[t] != 0);
+        const double *scal = tv.scal + (int64_t)t * kTileBins;
+        const double *cnt = tv.cnt + (int64_t)t * kTileBins;
+        const double *insp = tv.in_sp + (int64_t)t * kTileBins;
+        for (int b = 0; b < nb; ++b) {
+            const double p = st.step() * scal[b]; // p_j, flushed like the reference's double
+            if (insp[b] != 0.0) {                 // wave-uniform
+                if (want_sp)
+                    acc_sp.add(p);
+                const double h = cnt[b];
+                if (h != 0.0)
+                    acc_ll += h * ((p <= 0.0) ? -INFINITY : log(p)); // utils.safe_log
+            }
+        }
+        st.leave_tile(tv.renorm[t]);
+    }
+
+    double tail_term = 0.0;
+    if (want_sp) {
+        double sp = acc_sp.hi + acc_sp.lo;
+        if (!(sp < 1.0))
+            sp = 1.0;
+        if (sp < 1.0)
+            tail_term = m.tail * log(1.0 - sp);
+    }
+    double ll = acc_ll + tail_term;
+    if (!finite)
+        ll = NAN; // a NaN parameter poisons every p_j in the reference
+    if (live)
+        out_ll[pt] = ll;
+}
+
+} // namespace
+
+hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSource &src, int64_t n,
+                           double *out_ll, hipStream_t stream)
+{
+    if (n <= 0)
+        return hipSuccess;
+    if (m.n_err != 8 || m.kind != 0)
+        return hipErrorInvalidValue;
+    const dim3 block(256);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL((ll_basic_kernel<8>), grid, block, 0, stream, m, tv, src, n, out_ll);
+    return hipGetLastError();
+}
+
+} // namespace covest

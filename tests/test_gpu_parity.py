@@ -85,11 +85,18 @@ def test_golden_loglikelihood(hip_lib, oracle, kind, fname):
         n_slack += sum(1 for v in slack if v > 0)
         worst = max(worst, _check(got, case["ll"], "%s %s tail=%s S=%s" % (
             kind, case["hist"], case["tail"], case["max_error"]), slack=slack))
+        if kind == "basic" and case["max_error"] == 8:  # the recurrence kernel (K-basic) on the same points
+            fast = m.loglikelihood_points(np.array(case["points"]), kernel="recur")
+            worst = max(worst, _check(fast, case["ll"], "recur %s tail=%s" % (case["hist"], case["tail"]),
+                                      slack=slack))
+            assert np.array_equal(fast, m.loglikelihood_points(np.array(case["points"]), kernel="auto"),
+                                  equal_nan=True)
         # scalar API == batch API, and the dict form of compute_loglikelihood_multi
+        auto = m.loglikelihood_points(np.array(case["points"][:3]))
         p0 = case["points"][0]
-        assert m.compute_loglikelihood(*p0) == got[0]
+        assert m.compute_loglikelihood(*p0) == auto[0]
         multi = m.compute_loglikelihood_multi([tuple(p) for p in case["points"][:3]])
-        assert list(multi.values()) == [float(v) for v in got[:3]]
+        assert list(multi.values()) == [float(v) for v in auto]
         for d in case["detail"]:
             probs = m.compute_probabilities(*d["point"], clamp=True)
             _check([probs[j] for j, _ in d["p_j"]], [v for _, v in d["p_j"]], "p_j %r" % d["point"])
@@ -97,12 +104,13 @@ def test_golden_loglikelihood(hip_lib, oracle, kind, fname):
     print(kind, "worst rel err", worst, "points whose reference tail term is rounding noise:", n_slack)
 
 
-def test_config1_full_grid_and_argmin(hip_lib):
+@pytest.mark.parametrize("kernel", ["direct", "recur"])
+def test_config1_full_grid_and_argmin(hip_lib, kernel):
     from covest_amd import DenseGrid
     g = load_golden("c1_grid.json")
     m = _gpu_model("basic", g)
     grid = DenseGrid(m, [g["c_axis"], g["e_axis"]])
-    grid.evaluate(kernel="direct")
+    grid.evaluate(kernel=kernel)
     ll = grid.loglikelihoods()
     worst = _check(ll, g["ll"], "C1")
     val, arg = grid.argmin()
@@ -111,24 +119,25 @@ def test_config1_full_grid_and_argmin(hip_lib):
     assert grid.point(arg) == (g["c_axis"][24], g["e_axis"][9])
     # list API agrees with grid API bit for bit (same kernel, same point values)
     pts = np.array([(c, e) for c in g["c_axis"] for e in g["e_axis"]])
-    assert np.array_equal(m.loglikelihood_points(pts, kernel="direct"), ll, equal_nan=True)
-    print("C1 worst rel err", worst)
+    assert np.array_equal(m.loglikelihood_points(pts, kernel=kernel), ll, equal_nan=True)
+    print("C1", kernel, "worst rel err", worst)
 
 
-def test_config2_sample_and_argmin(hip_lib, oracle):
+@pytest.mark.parametrize("kernel", ["direct", "recur"])
+def test_config2_sample_and_argmin(hip_lib, oracle, kernel):
     from covest_amd import DenseGrid
     g = load_golden("c2_sample.json")
     m = _gpu_model("basic", g)
     assert m.bins_evaluated == 367  # tail == 0: only the non-zero bins are evaluated
-    got = m.loglikelihood_points(np.array(g["points"]), kernel="direct")
+    got = m.loglikelihood_points(np.array(g["points"]), kernel=kernel)
     worst = _check(got, g["ll"], "C2 sample")
     assert sum(1 for v in g["ll"] if v == -math.inf) > 50  # the fixture does exercise -inf
-    print("C2 sample worst rel err", worst)
+    print("C2 sample", kernel, "worst rel err", worst)
     # full 1000 x 1000 grid: sampled points equal the list API, arg-min verified by the oracle
     cs = np.linspace(2000.0, 6000.0, 1000)
     es = np.linspace(0.001, 0.1, 1000)
     grid = DenseGrid(m, [cs, es])
-    grid.evaluate(kernel="direct")
+    grid.evaluate(kernel=kernel)
     ll = grid.loglikelihoods()
     val, arg = grid.argmin()
     assert val == -ll[arg] and arg == int(np.nanargmin(np.where(np.isnan(ll), np.inf, -ll)))
@@ -210,9 +219,18 @@ def test_edge_cases(hip_lib, oracle):
         pts5 = np.array([(10.0, 0.05, 0.7, 0.5, 0.5), (30.0, 0.1, 0.3, 0.0, 0.9),
                          (5.0, 0.0, 1.0, 0.5, 0.5), (8.0, 0.3, 0.5, 1.0, 0.01)])
         _check(r.loglikelihood_points(pts5), orr.compute_loglikelihood_many(pts5), "ragged rep S=%d" % S)
+    # the recurrence kernel on ragged keys: gaps bridged (2..7), gaps re-anchored (40 -> 1000), tail and no tail
+    for tail in (0, 7):
+        m = BasicModel(21, 100, hist, tail, max_error=8)
+        om = oracle.OracleModel("basic", 21, 100, hist, tail, max_error=8)
+        pts = np.array([(10.0, 0.05), (300.0, 0.2), (0.01, 0.5), (40.0, 0.0), (1200.0, 0.01), (900.0, 0.3)])
+        ref = om.compute_loglikelihood_many(pts)
+        _check(m.loglikelihood_points(pts, kernel="recur"), ref, "ragged recur tail=%d" % tail,
+               slack=_tail_noise(om, pts, ref, tail))
     # NaN parameters poison the result, as in the reference
     m = BasicModel(21, 100, {1: 5, 2: 3}, 0, max_error=8)
     assert math.isnan(m.compute_loglikelihood(float("nan"), 0.05))
+    assert math.isnan(m.loglikelihood_points([[float("nan"), 0.05]], kernel="direct")[0])
     # a non-zero bin with p_j == 0 -> -inf
     m = BasicModel(21, 100, {5000: 1, 1: 10}, 0, max_error=8)
     assert m.compute_loglikelihood(1.0, 0.01) == -math.inf
