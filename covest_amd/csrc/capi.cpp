@@ -99,9 +99,13 @@ struct covest_grid {
     int64_t len[kMaxParams] = {1, 1, 1, 1, 1};
     int64_t flat_begin = 0, flat_end = 0;
     PointSource src{};
-    DevBuf axes, t_table, ll, partial_val, partial_idx, result;
+    DevBuf axes, t_table, ll, partial_val, partial_idx, result, plan_buf;
+    FactoredPlan plan{};        // K-factored work description (repeats model, dense grid)
+    bool has_plan = false;
+    double q_sum_t_minus_1 = 0.0; // sum over the Q weight vectors of (threshold_o - 1)
     double sum_t_minus_1 = 0.0; // sum over the block's points of (threshold_o - 1)
     const char *last_kernel = "none";
+    int last_kernel_id = 0;
     hipStream_t last_stream = nullptr;
     bool evaluated = false;
     // optional hipEvent bracketing of the likelihood kernel
@@ -298,6 +302,88 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     return COVEST_OK;
 }
 
+// RepeatsModel.get_b_o, covest/models.py:193-208, with libm pow as CPython's float ** int.
+double copy_number_weight_host(double q1, double q2, double q, int o)
+{
+    if (o == 1)
+        return q1;
+    if (o == 2)
+        return (1 - q1) * q2;
+    return (1 - q1) * (1 - q2) * q * std::pow(1 - q, (double)(o - 3));
+}
+
+// FactoredPlan of tiles.h for the (q1, q2, q) product of a dense repeats grid.
+int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t *axis_len,
+                        const std::vector<int32_t> &t_table)
+{
+    covest_model *m = g->model;
+    g->has_plan = false;
+    if (!m->has_tiles || m->n_par != 5)
+        return COVEST_OK;
+    const int64_t n1 = axis_len[2], n2 = axis_len[3], n3 = axis_len[4];
+    const int64_t nq = n1 * n2 * n3;
+    if (nq > (int64_t)1 << 24)
+        return COVEST_OK;
+    int t_max = 1;
+    for (int64_t i = 0; i < nq; ++i)
+        t_max = std::max(t_max, (int)t_table[(size_t)i]);
+    if (t_max - 1 > 512)
+        return COVEST_OK; // more copy-number classes than a workgroup has lanes: direct kernel
+    std::vector<int32_t> order((size_t)nq);
+    for (int64_t i = 0; i < nq; ++i)
+        order[(size_t)i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t a, int32_t b) { return t_table[(size_t)a] > t_table[(size_t)b]; });
+    const int32_t n_qtiles = (int32_t)((nq + 15) / 16);
+    const size_t n_slots = (size_t)n_qtiles * 16;
+    std::vector<int32_t> nsteps((size_t)n_qtiles, 0), q_t(n_slots, 0), q_orig(n_slots, -1);
+    std::vector<double> first8(8 * n_slots, 0.0), r4(n_slots, 0.0);
+    for (size_t slot = 0; slot < (size_t)nq; ++slot) {
+        const int64_t qi = order[slot];
+        const int64_t a = qi / (n2 * n3), b = (qi / n3) % n2, c = qi % n3;
+        const double q1 = clamp_one(m->dm, 2, axes[2][a]);
+        const double q2 = clamp_one(m->dm, 3, axes[3][b]);
+        const double q = clamp_one(m->dm, 4, axes[4][c]);
+        const int t = t_table[(size_t)qi];
+        q_t[slot] = t;
+        q_orig[slot] = (int32_t)qi;
+        for (int o = 1; o <= 8; ++o)
+            first8[(size_t)(o - 1) * n_slots + slot] = copy_number_weight_host(q1, q2, q, o);
+        r4[slot] = std::pow(1 - q, 4.0);
+        const int steps = t > 1 ? (t - 1 + 3) / 4 : 0;
+        nsteps[slot / 16] = std::max(nsteps[slot / 16], steps);
+    }
+    // one buffer: doubles first (first8 | r4), then int32 (nsteps | q_T | q_orig)
+    const size_t n_dbl = 9 * n_slots;
+    const size_t n_int = (size_t)n_qtiles + 2 * n_slots;
+    HIP_TRY(g->plan_buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
+    double *dbase = g->plan_buf.as<double>();
+    int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
+    HIP_TRY(hipMemcpy(dbase, first8.data(), 8 * n_slots * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dbase + 8 * n_slots, r4.data(), n_slots * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ibase, nsteps.data(), (size_t)n_qtiles * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ibase + n_qtiles, q_t.data(), n_slots * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ibase + n_qtiles + n_slots, q_orig.data(), n_slots * sizeof(int32_t), hipMemcpyHostToDevice));
+    FactoredPlan &pl = g->plan;
+    pl.c_axis = g->src.axis[0];
+    pl.e_axis = g->src.axis[1];
+    pl.n_e = axis_len[1];
+    pl.n_q = nq;
+    pl.ce_begin = g->flat_begin / nq;
+    pl.ce_end = (g->flat_end + nq - 1) / nq;
+    pl.n_qtiles = n_qtiles;
+    pl.max_o = t_max - 1;
+    pl.q_first8 = dbase;
+    pl.q_r4 = dbase + 8 * n_slots;
+    pl.qtile_nsteps = ibase;
+    pl.q_T = ibase + n_qtiles;
+    pl.q_orig = ibase + n_qtiles + n_slots;
+    pl.flat_begin = g->flat_begin;
+    pl.flat_end = g->flat_end;
+    g->has_plan = pl.max_o >= 1;
+    return COVEST_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -443,28 +529,45 @@ int covest_threshold_o(int64_t n, const double *q123, double threshold, int32_t 
     return COVEST_OK;
 }
 
-// Resolve COVEST_KERNEL_* for a request.  Returns the kernel to run or a negative error.
-static int resolve_kernel(const covest_model *m, int32_t kernel, bool is_grid)
+// Resolve COVEST_KERNEL_* for a request (g == nullptr: a point list).  Returns the
+// kernel to run or a negative error.
+static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_grid *g)
 {
-    (void)is_grid;
     const bool basic_fast = m->has_tiles && m->dm.kind == COVEST_MODEL_BASIC;
+    const bool factored_ok = g && g->has_plan;
     switch (kernel) {
     case COVEST_KERNEL_AUTO:
-        return basic_fast ? COVEST_KERNEL_RECUR : COVEST_KERNEL_DIRECT;
+        if (basic_fast)
+            return COVEST_KERNEL_RECUR;
+        // the factored kernel pays when many weight vectors share each (c, e)
+        if (factored_ok && g->plan.n_q >= 32)
+            return COVEST_KERNEL_FACTORED;
+        return COVEST_KERNEL_DIRECT;
     case COVEST_KERNEL_DIRECT:
         return COVEST_KERNEL_DIRECT;
     case COVEST_KERNEL_RECUR:
         if (basic_fast)
             return COVEST_KERNEL_RECUR;
         return fail(COVEST_E_INVALID, "recurrence kernel needs the basic model, max_error 8 and keys in 1..16384");
+    case COVEST_KERNEL_FACTORED:
+        if (factored_ok)
+            return COVEST_KERNEL_FACTORED;
+        return fail(COVEST_E_INVALID, "factored kernel needs a dense repeats-model grid, max_error 8, keys in "
+                                      "1..16384 and threshold_o <= 513");
     default:
-        return fail(COVEST_E_INVALID, "kernel not available for this request");
+        return fail(COVEST_E_INVALID, "unknown kernel");
     }
 }
 
 static hipError_t launch_ll(const covest_model *m, int kernel, const PointSource &src, int64_t n,
-                            double *out, hipStream_t st, const char **name)
+                            double *out, hipStream_t st, const char **name,
+                            const covest_grid *g = nullptr)
 {
+    if (kernel == COVEST_KERNEL_FACTORED) {
+        if (name)
+            *name = "ll_factored";
+        return launch_ll_factored(m->dm, m->tv, g->plan, out, st);
+    }
     if (kernel == COVEST_KERNEL_RECUR) {
         if (name)
             *name = "ll_basic";
@@ -482,7 +585,7 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         return fail(COVEST_E_INVALID, "covest_eval_points: bad argument");
     if (n == 0)
         return COVEST_OK;
-    const int kern = resolve_kernel(m, kernel, false);
+    const int kern = resolve_kernel(m, kernel, nullptr);
     if (kern < 0)
         return kern;
     std::lock_guard<std::mutex> guard(m->lock);
@@ -584,6 +687,7 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
         g->partial_val.release();
         g->partial_idx.release();
         g->result.release();
+        g->plan_buf.release();
         delete g;
         return code;
     };
@@ -642,6 +746,10 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
             return (double)(flat / nq) * prefix[(size_t)nq] + prefix[(size_t)(flat % nq)];
         };
         g->sum_t_minus_1 = upto(flat_end) - upto(flat_begin);
+        g->q_sum_t_minus_1 = prefix[(size_t)nq];
+        const int prc = build_factored_plan(g, axes, axis_len, table);
+        if (prc != COVEST_OK)
+            return bail(prc);
     }
 
     GRID_TRY(g->ll.reserve((size_t)(n > 0 ? n : 1) * sizeof(double)));
@@ -664,6 +772,7 @@ void covest_grid_destroy(covest_grid *g)
     g->partial_val.release();
     g->partial_idx.release();
     g->result.release();
+    g->plan_buf.release();
     for (hipEvent_t e : g->ev_begin)
         (void)hipEventDestroy(e);
     for (hipEvent_t e : g->ev_end)
@@ -706,7 +815,7 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
     if (!g)
         return fail(COVEST_E_INVALID, "covest_grid_eval: null grid");
     covest_model *m = g->model;
-    const int kern = resolve_kernel(m, kernel, true);
+    const int kern = resolve_kernel(m, kernel, g);
     if (kern < 0)
         return kern;
     std::lock_guard<std::mutex> guard(m->lock);
@@ -729,7 +838,8 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
         g->ev_used++;
         HIP_TRY(hipEventRecord(e0, st));
     }
-    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), st, &g->last_kernel));
+    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), st, &g->last_kernel, g));
+    g->last_kernel_id = kern;
     if (e1)
         HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->partial_val.as<double>(),
@@ -781,14 +891,25 @@ int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, con
     const covest_model *m = g->model;
     const double n = (double)(g->flat_end - g->flat_begin);
     const double bins = (double)m->dm.bins.n;
-    double nz = 0.0; // bins whose log is taken; equals bins when tail == 0
-    nz = bins;
-    const double terms = bins * (double)m->dm.n_err * g->sum_t_minus_1;
+    const double S = (double)m->dm.n_err;
+    // SURVEY 8(d) unit: pmf terms of the per-point formulation, bins * S * sum(T - 1)
+    const double terms = bins * S * g->sum_t_minus_1;
     if (pmf_terms)
         *pmf_terms = terms;
-    // 4 flop per pmf term + 25 per log + 25 per exp of the prologue
-    if (flops)
-        *flops = 4.0 * terms + 25.0 * nz * n + 25.0 * (double)m->dm.n_err * g->sum_t_minus_1;
+    if (flops) {
+        if (g->last_kernel_id == COVEST_KERNEL_FACTORED) {
+            // algorithmic minimum of the factored formulation (ll_factored.hip header):
+            // per (c,e): G build 2 flop per (key, o, s), contraction 2 flop per (key, q, o < T_q),
+            // one log (25 flop) per (key, q), prologue exps 25 per (o, s)
+            const double n_ce = (double)(g->plan.ce_end - g->plan.ce_begin);
+            const double max_o = (double)g->plan.max_o;
+            *flops = n_ce * (bins * S * max_o * 2.0 + bins * g->q_sum_t_minus_1 * 2.0 +
+                             bins * (double)g->plan.n_q * 25.0 + 25.0 * S * max_o);
+        } else {
+            // 4 flop per pmf term + 25 per log + 25 per exp of the prologue
+            *flops = 4.0 * terms + 25.0 * bins * n + 25.0 * S * g->sum_t_minus_1;
+        }
+    }
     if (kernel)
         *kernel = g->last_kernel;
     return COVEST_OK;

@@ -19,6 +19,11 @@ hipError_t launch_ll_direct(const DevModel &m, const PointSource &src, int64_t n
 hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSource &src, int64_t n,
                            double *out_ll, hipStream_t stream);
 
+// K-factored: repeats model on a dense grid, one workgroup per (c, e)
+// (ll_factored.hip).  out_ll is the block's LL buffer (index flat - plan.flat_begin).
+hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
+                              double *out_ll, hipStream_t stream);
+
 // (min -LL, lowest index) over ll[n]: two-stage reduction (argmin.hip).
 // partial_val/partial_idx need kArgminBlocks entries; result[0] = {min, bits of idx}.
 constexpr int kArgminBlocks = 256;

@@ -26,4 +26,24 @@ struct TileView {
     const double *in_sp;       // [n_tiles][32] 1.0 if the key is a histogram key (counts in sp_j), else 0.0
 };
 
+// Work description of K-factored (ll_factored.hip), built at covest_grid_create
+// for a dense repeats-model grid.  The Q = |q1| x |q2| x |q| weight vectors are
+// sorted by threshold_o (descending) into "slots", 16 per q-tile.
+constexpr int kMaxQTiles = 4; // q-tiles a wave carries (accumulators in registers)
+
+struct FactoredPlan {
+    const double *c_axis, *e_axis; // device copies of axes 0 and 1
+    int64_t n_e;                   // len(e axis): ce = ic * n_e + ie
+    int64_t ce_begin, ce_end;      // (c, e) pairs this block covers
+    int64_t n_q;                   // Q
+    int32_t n_qtiles;              // ceil(Q / 16)
+    int32_t max_o;                 // max threshold_o - 1: copy numbers to build
+    const int32_t *qtile_nsteps;   // [n_qtiles] ceil((max T in tile - 1) / 4)
+    const int32_t *q_T;            // [n_qtiles*16] threshold_o per slot (0 = padding)
+    const int32_t *q_orig;         // [n_qtiles*16] index into the (q1,q2,q) product (-1 = padding)
+    const double *q_first8;        // [8][n_qtiles*16] b_o, o = 1..8   (covest/models.py:193-208)
+    const double *q_r4;            // [n_qtiles*16] (1 - q)^4
+    int64_t flat_begin, flat_end;  // flat indices whose LL is written (ragged block ends)
+};
+
 } // namespace covest

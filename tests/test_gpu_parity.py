@@ -165,7 +165,8 @@ def _verify_argmin_with_oracle(oracle, om, grid, ll, arg, top):
     assert cand[k] == arg
 
 
-def test_config3_sample_and_argmin(hip_lib, oracle):
+@pytest.mark.parametrize("kernel", ["direct", "factored"])
+def test_config3_sample_and_argmin(hip_lib, oracle, kernel):
     from covest_amd import DenseGrid
     g = load_golden("c3_sample.json")
     m = _gpu_model("repeats", g)
@@ -175,7 +176,8 @@ def test_config3_sample_and_argmin(hip_lib, oracle):
     axes = [np.linspace(15.0, 30.0, 32), np.linspace(0.005, 0.08, 32), np.linspace(0.3, 0.95, 16),
             [0.5], np.linspace(0.05, 0.95, 16)]
     grid = DenseGrid(m, axes)
-    grid.evaluate(kernel="direct")
+    grid.evaluate(kernel=kernel)
+    assert grid.work()[2] == "ll_" + kernel
     ll = grid.loglikelihoods()
     # the fixture's flat indices address the same points
     for i, p, want in zip(g["flat_index"], g["points"], g["ll"]):
@@ -183,6 +185,43 @@ def test_config3_sample_and_argmin(hip_lib, oracle):
         assert rel_err(float(ll[i]), want) <= TOL
     val, arg = grid.argmin()
     assert val == -ll[arg] and arg == int(np.argmin(np.where(np.isnan(ll), np.inf, -ll)))
+    if kernel == "factored":  # whole grid against the direct kernel (itself pinned to the fixture above)
+        ref = DenseGrid(m, axes)
+        ref.evaluate(kernel="direct")
+        worst = _check(ll, ref.loglikelihoods(), "C3 factored vs direct", tol=1e-11)
+        assert ref.argmin() == (val, arg) or ref.argmin()[1] == arg
+        print("C3 factored vs direct worst rel err", worst)
+
+
+@pytest.mark.parametrize("tail", [0, 1000])
+@pytest.mark.parametrize("hname", ["sim_c10_e0.05", "sim_c10_e0.05_sparse", "sim_c10_e0"])
+def test_factored_small_histograms(hip_lib, oracle, hname, tail):
+    """K-factored on the reference's own test histograms: every point of a dense
+    5-D grid against the oracle, whole and in ragged flat-index blocks."""
+    from covest_amd import DenseGrid, RepeatsModel
+    hist = load_hist(hname)
+    m = RepeatsModel(21, 100, hist, tail, max_error=8)
+    om = oracle.OracleModel("repeats", 21, 100, hist, tail, max_error=8)
+    axes = [np.array([6.0, 10.0, 14.5]), np.array([0.0, 0.02, 0.05, 0.3]), np.array([0.2, 0.5, 0.8, 1.0]),
+            np.array([0.0, 0.4, 1.0]), np.array([0.0, 0.05, 0.3, 0.7, 1.0])]
+    grid = DenseGrid(m, axes)
+    grid.evaluate(kernel="factored")
+    ll = grid.loglikelihoods()
+    pts = np.array([grid.point(i) for i in range(grid.total)])
+    ref = om.compute_loglikelihood_many(pts, n_threads=16)
+    worst = _check(ll, ref, "factored %s tail=%d" % (hname, tail), slack=_tail_noise(om, pts, ref, tail))
+    k, best = oracle.first_min(-ref)
+    val, arg = grid.argmin()
+    assert arg == k or ll[arg] == ll[k]
+    # ragged blocks: cuts inside a (c, e) row
+    cuts = [0, 7, 61, 200, grid.total - 1, grid.total]
+    parts = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        blk = DenseGrid(m, axes, (a, b))
+        blk.evaluate(kernel="factored")
+        parts.append(blk.loglikelihoods())
+    assert np.array_equal(np.concatenate(parts), ll, equal_nan=True)
+    print("factored", hname, tail, "worst rel err", worst)
 
 
 def test_threshold_fixture_through_capi(hip_lib):
