@@ -1,0 +1,108 @@
+"""Host-side logic of the grid search, on the CPU: partitioning, the first-wins
+scan, threshold_o through the C ABI (pure host code), and optimize_grid driven by
+the oracle as an opaque callable against the reference's own trace."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, load_hist
+
+
+def test_partition_uniform():
+    from covest_amd.grid import partition_flat_range
+    for total in (0, 1, 7, 100, 262144):
+        for world in (1, 2, 3, 8):
+            b = partition_flat_range(total, world)
+            assert b[0] == 0 and b[-1] == total and len(b) == world + 1
+            sizes = np.diff(b)
+            assert (sizes >= 0).all() and sizes.max() - sizes.min() <= 1
+
+
+def test_partition_weighted_balances_cost():
+    from covest_amd.grid import partition_flat_range
+    rng = np.random.default_rng(0)
+    w = rng.integers(1, 300, size=256).astype(float)
+    total = 256 * 1024
+    for world in (2, 3, 8):
+        b = partition_flat_range(total, world, w)
+        assert b[0] == 0 and b[-1] == total and all(x <= y for x, y in zip(b, b[1:]))
+        full = np.tile(w, 1024)
+        costs = [full[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(costs) - min(costs) <= 2 * w.max()
+    assert partition_flat_range(10, 4, np.zeros(5)) == [0, 2, 5, 7, 10]
+
+
+def test_first_wins_scan_matches_oracle(oracle):
+    from covest_amd.grid import first_wins_scan
+    rng = np.random.default_rng(1)
+    inf, nan = math.inf, math.nan
+    cases = [[3.0, 1.0, 1.0, 2.0], [nan, 5.0, nan, 4.0], [inf, inf], [1.0, -inf, -inf], [],
+             [5.0, 6.0]]
+    for _ in range(200):
+        v = rng.normal(size=rng.integers(1, 60))
+        v[rng.random(len(v)) < 0.1] = nan
+        v[rng.random(len(v)) < 0.05] = inf
+        v = np.round(v, 1)  # many ties
+        cases.append(v.tolist())
+    for v in cases:
+        for start in (inf, 0.3):
+            mv, arg, diff = first_wins_scan(v, start)
+            k, best = oracle.first_min(v, start)
+            assert (arg, mv) == (k, best)
+            # diff = the sequential accumulation of covest/grid.py:68
+            d, cur = 0.0, start
+            for x in v:
+                if x < cur:
+                    d += cur - x
+                    cur = x
+            assert diff == d or (math.isnan(diff) and math.isnan(d))
+
+
+def test_threshold_through_capi_on_host(hip_lib):
+    from covest_amd import RepeatsModel
+    g = load_golden("threshold_o.json")
+    rows = np.array(g["rows"])
+    for hist_max in (15, 256, 10000):
+        sel = rows[rows[:, 0] == hist_max]
+        m = RepeatsModel(21, 100, {hist_max: 1, 1: 1}, 0, max_error=8)
+        assert np.array_equal(m.get_hist_threshold_values(sel[:, 1:4]), sel[:, 4].astype(np.int32))
+    m = RepeatsModel(21, 100, {50: 1}, 0, max_error=8, threshold=None)
+    assert m.get_hist_threshold_values([[0.5, 0.5, 0.5]])[0] == 50
+
+
+class _OracleNegLL:
+    def __init__(self, om):
+        self.om = om
+
+    def __call__(self, x):
+        return -self.om.compute_loglikelihood(*list(x))
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_optimize_grid_reproduces_reference_trace(oracle, which):
+    """covest_amd.grid.optimize_grid with an opaque callable (the oracle) must walk
+    exactly the iterations the reference's optimize_grid logged."""
+    from covest_amd.grid import optimize_grid
+    tr = load_golden("grid_trace.json")["traces"][which]
+    hist = load_hist(tr["hist"])
+    om = oracle.OracleModel(tr["model"], tr["k"], tr["r"], hist, tr["tail"], max_error=tr["max_error"])
+    res = optimize_grid(_OracleNegLL(om), list(tr["initial_guess"]),
+                        bounds=[tuple(b) for b in tr["bounds"]])
+    sizes = [int(line.split("Grid size:")[1]) for line in tr["log"] if "Grid size" in line]
+    news = [line for line in tr["log"] if line.startswith("New args")]
+    assert [t["grid_size"] for t in optimize_grid.trace] == sizes
+    assert list(res) == tr["result"]
+    last = optimize_grid.trace[-1]
+    assert "ll: %r" % last["value"] in news[-1] or "ll: %s" % last["value"] in news[-1]
+
+
+def test_initial_grid_shape():
+    from covest_amd.grid import initial_grid
+    pts = initial_grid([10.0, 0.05], count=5, bounds=[(0.01, None), (0, 0.5)])
+    assert len(pts) == 5 and pts[0] == [10.0, 0.05]
+    for c, e in pts[1:]:
+        assert 10.0 / 3 <= c <= 30.0 and 0.05 / 3 <= e <= 0.15
+    assert initial_grid([1.0, 0.1], count=0) == []
+    pts = initial_grid([10.0, 0.05], count=3, fix=[None, 0.07])
+    assert all(p[1] == 0.07 for p in pts[1:])
