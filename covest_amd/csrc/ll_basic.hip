@@ -5,7 +5,7 @@
 // ascending order with the pmf recurrence of streams.h (S error-class streams in
 // registers, 2 fp64 instructions per pmf term), so the key, its count h_j and
 // the per-key scale are WAVE-UNIFORM: they come from the tile table through the
-// scalar cache into SGPRs, there is no LDS traffic, no cross-lane operation and
+// scalar cache into SGPRs, there is no LDS traffic beyond the 512-byte log table, no cross-lane operation and
 // no divergence (neighbouring lanes differ only in (c, e)).  One log per
 // (point, non-zero bin) -- the dominant cost of this kernel once the terms are
 // down to 2 instructions.
@@ -17,6 +17,7 @@
 // Algorithmic HBM bytes: 16 in (or the two axes) + 8 out per point.
 #include <hip/hip_runtime.h>
 
+#include "fastmath.h"
 #include "kernels.h"
 #include "point_fetch.h"
 #include "streams.h"
@@ -31,6 +32,9 @@ __global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const T
                                                        const PointSource src, const int64_t n,
                                                        double *__restrict__ out_ll)
 {
+    __shared__ __attribute__((aligned(16))) double log_tab[64];
+    load_log_table(log_tab);
+    __syncthreads();
     const int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = pt < n;
     const int64_t ptc = live ? pt : n - 1; // idle lanes shadow the last point: every lane stays in the wave ops
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const T
                     acc_sp.add(p);
                 const double h = cnt[b];
                 if (h != 0.0)
-                    acc_ll += h * ((p <= 0.0) ? -INFINITY : log(p)); // utils.safe_log
+                    acc_ll += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
             }
         }
         st.leave_tile(tv.renorm[t]);

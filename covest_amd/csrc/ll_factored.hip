@@ -35,6 +35,7 @@
 // covest/grid.py:59-64 (the grid map).
 #include <hip/hip_runtime.h>
 
+#include "fastmath.h"
 #include "kernels.h"
 #include "point_fetch.h"
 #include "streams.h"
@@ -54,6 +55,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     constexpr int NW = NT / kWave;
     constexpr int LD = NT + 2; // G row stride in doubles: 2*NT + 4 dwords = 4 (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [kTileBins][LD]
+    __shared__ __attribute__((aligned(16))) double log_tab[64];
+    load_log_table(log_tab);
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                             if (TAIL)
                                 spacc[i].add(p);
                             if (h != 0.0)
-                                llacc[i] += h * ((p <= 0.0) ? -INFINITY : log(p)); // utils.safe_log
+                                llacc[i] += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
                         }
                     }
                 }
