@@ -353,9 +353,61 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         const int steps = t > 1 ? (t - 1 + 3) / 4 : 0;
         nsteps[slot / 16] = std::max(nsteps[slot / 16], steps);
     }
-    // one buffer: doubles first (first8 | r4), then int32 (nsteps | q_T | q_orig)
+    // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
+    const int n_units = 2 * n_qtiles;
+    const int nt = (t_max - 1 <= 256 && n_units <= 4 * kMaxUnits) ? 256 : 512;
+    const int nw = nt / 64;
+    const int cap_block = nw * kMaxUnits;
+    const int n_qblocks = (n_units + cap_block - 1) / cap_block;
+    std::vector<int32_t> unit_tile((size_t)n_qblocks * cap_block, -1), unit_half((size_t)n_qblocks * cap_block, 0);
+    for (int blk = 0; blk < n_qblocks; ++blk) {
+        struct Unit {
+            int tile, half, cost;
+        };
+        std::vector<Unit> units;
+        for (int qt = blk; qt < n_qtiles; qt += n_qblocks) // tiles are sorted by T: interleave over blocks
+            for (int h = 0; h < 2; ++h)
+                units.push_back({qt, h, std::max(1, (int)nsteps[(size_t)qt])});
+        std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.cost > b.cost; });
+        // stage 1: SIMD bins (waves w and w + 4 share a SIMD), longest first into the lightest bin with room
+        const int n_bins = std::min(4, nw), waves_per_bin = nw / n_bins;
+        std::vector<std::vector<Unit>> bins((size_t)n_bins);
+        std::vector<long> bin_load((size_t)n_bins, 0);
+        for (const Unit &u : units) {
+            int best = -1;
+            for (int b = 0; b < n_bins; ++b)
+                if ((int)bins[(size_t)b].size() < waves_per_bin * kMaxUnits &&
+                    (best < 0 || bin_load[(size_t)b] < bin_load[(size_t)best]))
+                    best = b;
+            bins[(size_t)best].push_back(u);
+            bin_load[(size_t)best] += u.cost;
+        }
+        // stage 2: the waves of each bin, same rule
+        for (int b = 0; b < n_bins; ++b) {
+            std::vector<std::vector<Unit>> wv((size_t)waves_per_bin);
+            std::vector<long> wload((size_t)waves_per_bin, 0);
+            for (const Unit &u : bins[(size_t)b]) {
+                int best = -1;
+                for (int w = 0; w < waves_per_bin; ++w)
+                    if ((int)wv[(size_t)w].size() < kMaxUnits && (best < 0 || wload[(size_t)w] < wload[(size_t)best]))
+                        best = w;
+                wv[(size_t)best].push_back(u);
+                wload[(size_t)best] += u.cost;
+            }
+            for (int w = 0; w < waves_per_bin; ++w) {
+                const int wave = b + w * n_bins;
+                for (size_t k = 0; k < wv[(size_t)w].size(); ++k) {
+                    const size_t at = ((size_t)blk * nw + wave) * kMaxUnits + k;
+                    unit_tile[at] = wv[(size_t)w][k].tile;
+                    unit_half[at] = wv[(size_t)w][k].half;
+                }
+            }
+        }
+    }
+    // one buffer: doubles first (first8 | r4), then int32 (nsteps | q_T | q_orig | unit_tile | unit_half)
     const size_t n_dbl = 9 * n_slots;
-    const size_t n_int = (size_t)n_qtiles + 2 * n_slots;
+    const size_t n_unit = unit_tile.size();
+    const size_t n_int = (size_t)n_qtiles + 2 * n_slots + 2 * n_unit;
     HIP_TRY(g->plan_buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
     double *dbase = g->plan_buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
@@ -364,6 +416,8 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     HIP_TRY(hipMemcpy(ibase, nsteps.data(), (size_t)n_qtiles * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ibase + n_qtiles, q_t.data(), n_slots * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ibase + n_qtiles + n_slots, q_orig.data(), n_slots * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ibase + n_qtiles + 2 * n_slots, unit_tile.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ibase + n_qtiles + 2 * n_slots + n_unit, unit_half.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
     FactoredPlan &pl = g->plan;
     pl.c_axis = g->src.axis[0];
     pl.e_axis = g->src.axis[1];
@@ -373,6 +427,10 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     pl.ce_end = (g->flat_end + nq - 1) / nq;
     pl.n_qtiles = n_qtiles;
     pl.max_o = t_max - 1;
+    pl.n_threads = nt;
+    pl.n_qblocks = n_qblocks;
+    pl.unit_tile = ibase + n_qtiles + 2 * n_slots;
+    pl.unit_half = ibase + n_qtiles + 2 * n_slots + n_unit;
     pl.q_first8 = dbase;
     pl.q_r4 = dbase + 8 * n_slots;
     pl.qtile_nsteps = ibase;

@@ -9,25 +9,27 @@
 // enter through the weights b_o and the cut-off T (models.py:185-208).  A dense
 // grid (covest/grid.py:39-43: itertools.product of the axes) evaluates every
 // (c, e) with the same Q = |q1| x |q2| x |q| weight vectors, so one workgroup
-// takes one (c, e) and all Q of them:
+// takes one (c, e) and all Q of them, key tile by key tile (32 keys):
 //
-//   phase A  lane = copy number o: the 8 error-class streams of streams.h walk a
-//            tile of 32 keys (2 fp64 instr per pmf term) and store G[key][o] to LDS
+//   phase A  lane = copy number o: the 8 error-class streams of streams.h walk the
+//            32 keys (2 fp64 instr per pmf term) and store G[key][o] to LDS.  Waves
+//            whose lanes are all beyond Tmax skip it.
 //   phase B  P[key][q] = sum_o G[key][o] * b_o(q) on the fp64 matrix pipe:
 //            v_mfma_f64_16x16x4_f64, A = 16 keys x 4 o from LDS (conflict-free
-//            ds_read_b64, row stride = 4 dwords mod 64), B = 4 o x 16 q generated
-//            IN REGISTERS: b_{o+4} = b_o (1-q)^4 is one multiply per MFMA pair, the
-//            first 8 weights and the cut-off T come from the host (libm pow, as
-//            CPython) -- so the contraction reads no weights from memory at all
+//            ds_read_b64: row stride = 4 dwords mod 64), B = 4 o x 16 q generated
+//            IN REGISTERS: b_{o+4} = b_o (1-q)^4 is one multiply per MFMA, the first
+//            8 weights and the cut-off T come from the host (libm pow, as CPython)
+//            -- the contraction reads no weights from memory at all.
 //   phase C  h_j * log P[key][q] straight from the accumulator registers: in the
-//            f64 C/D layout a lane keeps ONE q column, so the running LL of a
-//            q-tile is a single register per lane
+//            f64 C/D layout a lane keeps ONE q column, so the running LL of a unit
+//            is a single register per lane (fast_log, fastmath.h).
 //
-// q points are sorted by T (descending) and dealt to the waves in tiles of 16, so
-// a wave's o-loop stops at its own tile's T.  gfx950 measured (tools/
+// The unit of phases B/C is (q-tile of 16 weight vectors, half of the key tile);
+// the host deals units to waves longest-first, balanced per SIMD (tiles.h), and a
+// wave's o-loop stops at its own unit's T.  gfx950 measured (tools/
 // microbench_f64.hip): v_fma_f64 62 TFLOP/s, v_mfma_f64_16x16x4 75 TFLOP/s, and
-// the two do NOT overlap (same fp64 datapath), so the phases are simply
-// sequential and the kernel is bound by the fp64 pipe:
+// the two do NOT overlap (one fp64 datapath), so the phases are sequential and the
+// kernel is bound by the fp64 pipe:
 //   flops per (c,e) = B*8*(Tmax-1)*2  +  B*sum_q(T_q-1)*2  +  B*Q*(one log)
 // against B*8*sum_q(T_q-1)*4 for the per-point formulation of SURVEY 8(d).
 //
@@ -54,13 +56,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 {
     constexpr int NW = NT / kWave;
     constexpr int LD = NT + 2; // G row stride in doubles: 2*NT + 4 dwords = 4 (mod 64) -> conflict-free A reads
-    extern __shared__ double Gs[]; // [kTileBins][LD]
+    extern __shared__ double Gs[]; // [kTileBins][LD]; reused for the final per-q combine
     __shared__ __attribute__((aligned(16))) double log_tab[64];
     load_log_table(log_tab);
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const int wave = tid / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
 
     // ---- the (c, e) of this workgroup ----
     const int64_t ce = plan.ce_begin + blockIdx.x;
@@ -79,55 +81,64 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     __syncthreads();
 
     // ---- phase-A state: lane = copy number o = tid + 1 ----
+    const bool wave_builds = wave * kWave < plan.max_o; // wave-uniform
     StreamSet<8> st;
-    st.init(m, lam, tid + 1, finite && (tid + 1) <= plan.max_o);
+    st.init(m, lam, tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o);
+    if (!wave_builds) { // these columns of G stay zero for the whole kernel
+        for (int b = 0; b < kTileBins; ++b)
+            Gs[b * LD + tid] = 0.0;
+    }
 
-    // ---- phase-B/C state: this wave's q-tiles (interleaved over waves and q-blocks) ----
+    // ---- phase-B/C state: this wave's (q-tile, half) units ----
     const int col = lane & 15; // q column inside a tile / key row of the A fragment
     const int kq = lane >> 4;  // which of the 4 o of an MFMA step
-    int nsteps[kMaxQTiles], tq[kMaxQTiles], qslot[kMaxQTiles];
-    double r4[kMaxQTiles], llacc[kMaxQTiles];
-    CompSum spacc[kMaxQTiles];
     const int n_slots = plan.n_qtiles * 16;
+    int nsteps[kMaxUnits], uhalf[kMaxUnits], tq[kMaxUnits], qslot[kMaxUnits];
+    double r4[kMaxUnits], llacc[kMaxUnits];
+    CompSum spacc[kMaxUnits];
+    int max_steps = 0;
 #pragma unroll
-    for (int i = 0; i < kMaxQTiles; ++i) {
-        const int qt = __builtin_amdgcn_readfirstlane((i * NW + wave) * (int)gridDim.y + (int)blockIdx.y);
-        const bool on = qt < plan.n_qtiles;
+    for (int k = 0; k < kMaxUnits; ++k) {
+        const int at = ((int)blockIdx.y * NW + wave) * kMaxUnits + k;
+        const int qt = __builtin_amdgcn_readfirstlane(plan.unit_tile[at]);
+        const bool on = qt >= 0;
         const int slot = (on ? qt : 0) * 16 + col;
-        qslot[i] = on ? slot : -1;
-        nsteps[i] = __builtin_amdgcn_readfirstlane(on ? plan.qtile_nsteps[qt] : 0);
-        tq[i] = on ? plan.q_T[slot] : 0;
-        r4[i] = plan.q_r4[slot];
-        llacc[i] = 0.0;
-        spacc[i].hi = 0.0;
-        spacc[i].lo = 0.0;
+        uhalf[k] = __builtin_amdgcn_readfirstlane(plan.unit_half[at]);
+        qslot[k] = on ? slot : -1;
+        nsteps[k] = __builtin_amdgcn_readfirstlane(on ? plan.qtile_nsteps[qt] : 0);
+        tq[k] = on ? plan.q_T[slot] : 0;
+        r4[k] = plan.q_r4[slot];
+        llacc[k] = 0.0;
+        spacc[k].hi = 0.0;
+        spacc[k].lo = 0.0;
+        max_steps = max(max_steps, nsteps[k]);
     }
-    const int max_steps = nsteps[0]; // tiles are sorted by T: this wave's first tile is its longest
 
     for (int t = 0; t < tv.n_tiles; ++t) {
         // ================= phase A: G[key][o] for 32 keys =================
-        const double k0 = tv.first_key[t];
-        const int nb = tv.n_bins[t];
-        st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                      tv.run_start[t] != 0);
-        const double *scal = tv.scal + (int64_t)t * kTileBins;
-        for (int b = 0; b < nb; ++b)
-            Gs[b * LD + tid] = st.step() * scal[b];
-        for (int b = nb; b < kTileBins; ++b)
-            Gs[b * LD + tid] = 0.0;
-        st.leave_tile(tv.renorm[t]);
+        if (wave_builds) {
+            const double k0 = tv.first_key[t];
+            const int nb = tv.n_bins[t];
+            st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
+                          tv.run_start[t] != 0);
+            const double *scal = tv.scal + (int64_t)t * kTileBins;
+            for (int b = 0; b < nb; ++b)
+                Gs[b * LD + tid] = st.step() * scal[b];
+            for (int b = nb; b < kTileBins; ++b)
+                Gs[b * LD + tid] = 0.0;
+            st.leave_tile(tv.renorm[t]);
+        }
         __syncthreads();
 
         // ================= phase B: P = G x b on the matrix pipe =================
-        d4 acc[kMaxQTiles][2];
-        double wfirst[kMaxQTiles], wrun[kMaxQTiles]; // b_o for o = 1+kq and 5+kq (L1-resident, reloaded per tile)
+        d4 acc[kMaxUnits];
+        double wfirst[kMaxUnits], wrun[kMaxUnits]; // b_o for o = 1+kq and 5+kq (L1-resident, reloaded per tile)
 #pragma unroll
-        for (int i = 0; i < kMaxQTiles; ++i) {
-            acc[i][0] = (d4){0.0, 0.0, 0.0, 0.0};
-            acc[i][1] = (d4){0.0, 0.0, 0.0, 0.0};
-            const int slot = qslot[i] >= 0 ? qslot[i] : col;
-            wfirst[i] = plan.q_first8[(int64_t)kq * n_slots + slot];
-            wrun[i] = plan.q_first8[(int64_t)(4 + kq) * n_slots + slot];
+        for (int k = 0; k < kMaxUnits; ++k) {
+            acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
+            const int slot = qslot[k] >= 0 ? qslot[k] : col;
+            wfirst[k] = plan.q_first8[(int64_t)kq * n_slots + slot];
+            wrun[k] = plan.q_first8[(int64_t)(4 + kq) * n_slots + slot];
         }
         const double *arow0 = Gs + col * LD + kq;
         const double *arow1 = Gs + (16 + col) * LD + kq;
@@ -136,15 +147,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             const double a1 = arow1[4 * step];
             const int o_here = 1 + 4 * step + kq;
 #pragma unroll
-            for (int i = 0; i < kMaxQTiles; ++i) {
-                if (step < nsteps[i]) { // wave-uniform
+            for (int k = 0; k < kMaxUnits; ++k) {
+                if (step < nsteps[k]) { // wave-uniform
                     // b_o: o = 1..8 from the host, then b_{o+4} = b_o * (1-q)^4  (models.py:198-206)
-                    double w = (step == 0) ? wfirst[i] : wrun[i];
+                    double w = (step == 0) ? wfirst[k] : wrun[k];
                     if (step >= 1)
-                        wrun[i] *= r4[i];
-                    w = (o_here < tq[i]) ? w : 0.0; // o ranges over 1..T-1 (models.py:239)
-                    acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, w, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, w, acc[i][1], 0, 0, 0);
+                        wrun[k] *= r4[k];
+                    w = (o_here < tq[k]) ? w : 0.0; // o ranges over 1..T-1 (models.py:239)
+                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(uhalf[k] ? a1 : a0, w, acc[k], 0, 0, 0);
                 }
             }
         }
@@ -152,37 +162,38 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // ================= phase C: h_j * log p_j from the accumulators =================
         // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int k = 0; k < kMaxUnits; ++k) {
+            if (qslot[k] >= 0) { // wave-uniform: the unit exists
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int bin = 16 * u + kq + 4 * r;
-                const double h = tv.cnt[(int64_t)t * kTileBins + bin];
-                const bool in_sp = tv.in_sp[(int64_t)t * kTileBins + bin] != 0.0;
-#pragma unroll
-                for (int i = 0; i < kMaxQTiles; ++i) {
-                    if (qslot[i] >= 0) { // wave-uniform: the tile exists
-                        const double p = acc[i][u][r];
-                        if (in_sp) {
-                            if (TAIL)
-                                spacc[i].add(p);
-                            if (h != 0.0)
-                                llacc[i] += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    const int bin = 16 * uhalf[k] + kq + 4 * r;
+                    const double h = tv.cnt[(int64_t)t * kTileBins + bin];
+                    const bool in_sp = tv.in_sp[(int64_t)t * kTileBins + bin] != 0.0;
+                    const double p = acc[k][r];
+                    if (in_sp) {
+                        if (TAIL)
+                            spacc[k].add(p);
+                        if (h != 0.0)
+                            llacc[k] += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
                     }
                 }
             }
+        }
         __syncthreads(); // Gs is rewritten by the next tile's phase A
     }
 
-    // ---- per-q results: reduce over the 4 row groups of the accumulator layout ----
+    // ---- per-q results: sum the 4 row groups of the accumulator layout, then the two
+    //      halves of each q-tile (they may live on different waves) through LDS ----
+    double *part_ll = Gs;                               // [NW][kMaxUnits][16]
+    double *part_hi = Gs + (size_t)NW * kMaxUnits * 16; // compensated sp_j parts
+    double *part_lo = part_hi + (size_t)NW * kMaxUnits * 16;
 #pragma unroll
-    for (int i = 0; i < kMaxQTiles; ++i) {
-        double ll = llacc[i];
+    for (int k = 0; k < kMaxUnits; ++k) {
+        double ll = llacc[k];
         ll += __shfl_xor(ll, 16, kWave);
         ll += __shfl_xor(ll, 32, kWave);
-        double tail_term = 0.0;
+        CompSum sp = spacc[k];
         if (TAIL) {
-            CompSum sp = spacc[i];
 #pragma unroll
             for (int off = 16; off <= 32; off <<= 1) {
                 const double ohi = __shfl_xor(sp.hi, off, kWave);
@@ -191,26 +202,60 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 two_sum(sp.hi, ohi, sp.hi, e);
                 sp.lo += olo + e;
             }
-            double s = sp.hi + sp.lo;
+        }
+        if (lane < 16) {
+            const int at = (wave * kMaxUnits + k) * 16 + lane;
+            part_ll[at] = ll;
+            if (TAIL) {
+                part_hi[at] = sp.hi;
+                part_lo[at] = sp.lo;
+            }
+        }
+    }
+    __syncthreads();
+    // one thread per (wave, unit, q) entry of a half-0 unit; it looks up the half-1 partner
+    for (int e = tid; e < NW * kMaxUnits * 16; e += NT) {
+        const int w = e / (kMaxUnits * 16), k = (e / 16) % kMaxUnits, c = e & 15;
+        const int at = ((int)blockIdx.y * NW + w) * kMaxUnits + k;
+        const int qt = plan.unit_tile[at];
+        if (qt < 0 || plan.unit_half[at] != 0)
+            continue;
+        int pe = -1; // the unit with the same tile and half 1 (always in the same workgroup)
+        for (int w2 = 0; w2 < NW && pe < 0; ++w2)
+            for (int k2 = 0; k2 < kMaxUnits; ++k2) {
+                const int at2 = ((int)blockIdx.y * NW + w2) * kMaxUnits + k2;
+                if (plan.unit_tile[at2] == qt && plan.unit_half[at2] == 1) {
+                    pe = (w2 * kMaxUnits + k2) * 16 + c;
+                    break;
+                }
+            }
+        const double ll = part_ll[e] + (pe >= 0 ? part_ll[pe] : 0.0);
+        double tail_term = 0.0;
+        if (TAIL) {
+            double hi = part_hi[e], lo = part_lo[e];
+            if (pe >= 0) {
+                double err;
+                two_sum(hi, part_hi[pe], hi, err);
+                lo += part_lo[pe] + err;
+            }
+            double s = hi + lo;
             if (!(s < 1.0))
-                s = 1.0;
+                s = 1.0; // min(1, fsum(...)), NaN -> 1
             if (s < 1.0)
                 tail_term = m.tail * log(1.0 - s);
         }
-        if (lane < 16 && qslot[i] >= 0) {
-            const int32_t qo = plan.q_orig[qslot[i]];
-            if (qo >= 0) {
-                const int64_t flat = ce * plan.n_q + qo;
-                if (flat >= plan.flat_begin && flat < plan.flat_end)
-                    out_ll[flat - plan.flat_begin] = finite ? ll + tail_term : NAN;
-            }
+        const int32_t qo = plan.q_orig[qt * 16 + c];
+        if (qo >= 0) {
+            const int64_t flat = ce * plan.n_q + qo;
+            if (flat >= plan.flat_begin && flat < plan.flat_end)
+                out_ll[flat - plan.flat_begin] = finite ? ll + tail_term : NAN;
         }
     }
 }
 
 template <int NT, bool TAIL>
-hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredPlan &plan, double *out_ll,
-                     hipStream_t stream)
+hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
+                          double *out_ll, hipStream_t stream)
 {
     const size_t lds = (size_t)kTileBins * (NT + 2) * sizeof(double);
     static bool configured = false;
@@ -221,9 +266,7 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
             return e;
         configured = true;
     }
-    const int tiles_per_block = kMaxQTiles * (NT / kWave);
-    const unsigned n_qblocks = (unsigned)((plan.n_qtiles + tiles_per_block - 1) / tiles_per_block);
-    const dim3 grid((unsigned)(plan.ce_end - plan.ce_begin), n_qblocks);
+    const dim3 grid((unsigned)(plan.ce_end - plan.ce_begin), (unsigned)plan.n_qblocks);
     hipLaunchKernelGGL((ll_factored_kernel<NT, TAIL>), grid, dim3(NT), lds, stream, m, tv, plan, out_ll);
     return hipGetLastError();
 }
@@ -243,13 +286,13 @@ hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const Facto
 {
     if (plan.ce_end <= plan.ce_begin)
         return hipSuccess;
-    if (m.n_err != 8 || m.kind != 1 || plan.max_o > 512)
+    if (m.n_err != 8 || m.kind != 1 || plan.max_o > plan.n_threads)
         return hipErrorInvalidValue;
-    if (plan.max_o <= 256)
+    if (plan.n_threads == 256)
         return launch_nt<256>(m, tv, plan, out_ll, stream);
-    if (plan.max_o <= 384)
-        return launch_nt<384>(m, tv, plan, out_ll, stream);
-    return launch_nt<512>(m, tv, plan, out_ll, stream);
+    if (plan.n_threads == 512)
+        return launch_nt<512>(m, tv, plan, out_ll, stream);
+    return hipErrorInvalidValue;
 }
 
 } // namespace covest

@@ -28,8 +28,12 @@ struct TileView {
 
 // Work description of K-factored (ll_factored.hip), built at covest_grid_create
 // for a dense repeats-model grid.  The Q = |q1| x |q2| x |q| weight vectors are
-// sorted by threshold_o (descending) into "slots", 16 per q-tile.
-constexpr int kMaxQTiles = 4; // q-tiles a wave carries (accumulators in registers)
+// sorted by threshold_o (descending) into "slots", 16 per q-tile.  The unit of
+// matrix work is (q-tile, half) -- 16 weight vectors x 16 of a tile's 32 keys --
+// costing ceil((T-1)/4) MFMAs per key tile; units are dealt to the waves of a
+// workgroup by longest-processing-time first, balanced per SIMD (waves w and w+4
+// share one), so that the one tile with T ~ 285 does not serialise the workgroup.
+constexpr int kMaxUnits = 6; // (q-tile, half) units a wave carries (accumulators in registers)
 
 struct FactoredPlan {
     const double *c_axis, *e_axis; // device copies of axes 0 and 1
@@ -38,6 +42,10 @@ struct FactoredPlan {
     int64_t n_q;                   // Q
     int32_t n_qtiles;              // ceil(Q / 16)
     int32_t max_o;                 // max threshold_o - 1: copy numbers to build
+    int32_t n_threads;             // workgroup size the unit tables were built for (256 or 512)
+    int32_t n_qblocks;             // workgroups per (c, e) (gridDim.y); each rebuilds G
+    const int32_t *unit_tile;      // [n_qblocks][n_threads/64][kMaxUnits] q-tile of the unit, -1 = none
+    const int32_t *unit_half;      // same shape: 0 = keys 0..15 of the key tile, 1 = keys 16..31
     const int32_t *qtile_nsteps;   // [n_qtiles] ceil((max T in tile - 1) / 4)
     const int32_t *q_T;            // [n_qtiles*16] threshold_o per slot (0 = padding)
     const int32_t *q_orig;         // [n_qtiles*16] index into the (q1,q2,q) product (-1 = padding)
