@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -287,17 +288,7 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     HIP_TRY(hipMemcpy(per_bin + 2 * nt * kTileBins, insp.data(), nt * kTileBins * sizeof(double), hipMemcpyHostToDevice));
     int32_t *ibase = reinterpret_cast<int32_t *>(base + n_dbl);
     HIP_TRY(hipMemcpy(ibase, ints.data(), 2 * nt * sizeof(int32_t), hipMemcpyHostToDevice));
-    TileView &tv = m->tv;
-    tv.n_tiles = (int32_t)nt;
-    tv.first_key = base;
-    tv.lgam_prev = base + nt;
-    tv.lgam_last = base + 2 * nt;
-    tv.renorm = base + 3 * nt;
-    tv.scal = per_bin;
-    tv.cnt = per_bin + nt * kTileBins;
-    tv.in_sp = per_bin + 2 * nt * kTileBins;
-    tv.n_bins = ibase;
-    tv.run_start = ibase + nt;
+    m->tv = tile_view_from((int32_t)nt, base, ibase);
     m->has_tiles = true;
     return COVEST_OK;
 }
@@ -336,7 +327,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
                      [&](int32_t a, int32_t b) { return t_table[(size_t)a] > t_table[(size_t)b]; });
     const int32_t n_qtiles = (int32_t)((nq + 15) / 16);
     const size_t n_slots = (size_t)n_qtiles * 16;
-    std::vector<int32_t> nsteps((size_t)n_qtiles, 0), q_t(n_slots, 0), q_orig(n_slots, -1);
+    std::vector<int32_t> nsteps((size_t)n_qtiles, 0), nfull((size_t)n_qtiles, 1 << 30), q_t(n_slots, 0), q_orig(n_slots, -1);
     std::vector<double> first8(8 * n_slots, 0.0), r4(n_slots, 0.0);
     for (size_t slot = 0; slot < (size_t)nq; ++slot) {
         const int64_t qi = order[slot];
@@ -352,14 +343,17 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         r4[slot] = std::pow(1 - q, 4.0);
         const int steps = t > 1 ? (t - 1 + 3) / 4 : 0;
         nsteps[slot / 16] = std::max(nsteps[slot / 16], steps);
+        nfull[slot / 16] = std::min(nfull[slot / 16], t > 1 ? (t - 1) / 4 : 0);
     }
+    if (nq % 16 != 0)
+        nfull[(size_t)n_qtiles - 1] = 0; // padding columns (T = 0) are cut off from the first step
     // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
     const int n_units = 2 * n_qtiles;
     const int nt = (t_max - 1 <= 256 && n_units <= 4 * kMaxUnits) ? 256 : 512;
     const int nw = nt / 64;
     const int cap_block = nw * kMaxUnits;
     const int n_qblocks = (n_units + cap_block - 1) / cap_block;
-    std::vector<int32_t> unit_tile((size_t)n_qblocks * cap_block, -1), unit_half((size_t)n_qblocks * cap_block, 0);
+    std::vector<int32_t> unit_tile((size_t)n_qblocks * cap_block, -1);
     for (int blk = 0; blk < n_qblocks; ++blk) {
         struct Unit {
             int tile, half, cost;
@@ -369,45 +363,36 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
             for (int h = 0; h < 2; ++h)
                 units.push_back({qt, h, std::max(1, (int)nsteps[(size_t)qt])});
         std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.cost > b.cost; });
-        // stage 1: SIMD bins (waves w and w + 4 share a SIMD), longest first into the lightest bin with room
-        const int n_bins = std::min(4, nw), waves_per_bin = nw / n_bins;
-        std::vector<std::vector<Unit>> bins((size_t)n_bins);
-        std::vector<long> bin_load((size_t)n_bins, 0);
+        // longest first into the lightest SIMD (waves w and w + 4 share one) that still has a
+        // free slot for the unit's half, then into the lighter of that SIMD's waves with such a slot
+        const int n_bins = std::min(4, nw);
+        std::vector<long> bin_load((size_t)n_bins, 0), wave_load((size_t)nw, 0);
+        std::vector<int> used((size_t)nw * 2, 0); // [wave][half] slots taken
         for (const Unit &u : units) {
-            int best = -1;
-            for (int b = 0; b < n_bins; ++b)
-                if ((int)bins[(size_t)b].size() < waves_per_bin * kMaxUnits &&
-                    (best < 0 || bin_load[(size_t)b] < bin_load[(size_t)best]))
-                    best = b;
-            bins[(size_t)best].push_back(u);
-            bin_load[(size_t)best] += u.cost;
-        }
-        // stage 2: the waves of each bin, same rule
-        for (int b = 0; b < n_bins; ++b) {
-            std::vector<std::vector<Unit>> wv((size_t)waves_per_bin);
-            std::vector<long> wload((size_t)waves_per_bin, 0);
-            for (const Unit &u : bins[(size_t)b]) {
-                int best = -1;
-                for (int w = 0; w < waves_per_bin; ++w)
-                    if ((int)wv[(size_t)w].size() < kMaxUnits && (best < 0 || wload[(size_t)w] < wload[(size_t)best]))
-                        best = w;
-                wv[(size_t)best].push_back(u);
-                wload[(size_t)best] += u.cost;
-            }
-            for (int w = 0; w < waves_per_bin; ++w) {
-                const int wave = b + w * n_bins;
-                for (size_t k = 0; k < wv[(size_t)w].size(); ++k) {
-                    const size_t at = ((size_t)blk * nw + wave) * kMaxUnits + k;
-                    unit_tile[at] = wv[(size_t)w][k].tile;
-                    unit_half[at] = wv[(size_t)w][k].half;
+            int best_wave = -1;
+            for (int w = 0; w < nw; ++w) {
+                if (used[(size_t)w * 2 + u.half] >= kHalfUnits)
+                    continue;
+                if (best_wave < 0) {
+                    best_wave = w;
+                    continue;
                 }
+                const long lb = bin_load[(size_t)(w % n_bins)], bb = bin_load[(size_t)(best_wave % n_bins)];
+                if (lb < bb || (lb == bb && wave_load[(size_t)w] < wave_load[(size_t)best_wave]))
+                    best_wave = w;
             }
+            const size_t at = ((size_t)blk * nw + best_wave) * kMaxUnits + (size_t)u.half * kHalfUnits +
+                              (size_t)used[(size_t)best_wave * 2 + u.half];
+            unit_tile[at] = u.tile;
+            used[(size_t)best_wave * 2 + u.half]++;
+            bin_load[(size_t)(best_wave % n_bins)] += u.cost;
+            wave_load[(size_t)best_wave] += u.cost;
         }
     }
-    // one buffer: doubles first (first8 | r4), then int32 (nsteps | q_T | q_orig | unit_tile | unit_half)
+    // one buffer: doubles first (first8 | r4), then int32 (nsteps | q_T | q_orig | unit_tile | nfull)
     const size_t n_dbl = 9 * n_slots;
     const size_t n_unit = unit_tile.size();
-    const size_t n_int = (size_t)n_qtiles + 2 * n_slots + 2 * n_unit;
+    const size_t n_int = 2 * (size_t)n_qtiles + 2 * n_slots + n_unit;
     HIP_TRY(g->plan_buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
     double *dbase = g->plan_buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
@@ -417,7 +402,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     HIP_TRY(hipMemcpy(ibase + n_qtiles, q_t.data(), n_slots * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ibase + n_qtiles + n_slots, q_orig.data(), n_slots * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ibase + n_qtiles + 2 * n_slots, unit_tile.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ibase + n_qtiles + 2 * n_slots + n_unit, unit_half.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ibase + n_qtiles + 2 * n_slots + n_unit, nfull.data(), (size_t)n_qtiles * sizeof(int32_t), hipMemcpyHostToDevice));
     FactoredPlan &pl = g->plan;
     pl.c_axis = g->src.axis[0];
     pl.e_axis = g->src.axis[1];
@@ -430,7 +415,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     pl.n_threads = nt;
     pl.n_qblocks = n_qblocks;
     pl.unit_tile = ibase + n_qtiles + 2 * n_slots;
-    pl.unit_half = ibase + n_qtiles + 2 * n_slots + n_unit;
+    pl.qtile_nfull = ibase + n_qtiles + 2 * n_slots + n_unit;
     pl.q_first8 = dbase;
     pl.q_r4 = dbase + 8 * n_slots;
     pl.qtile_nsteps = ibase;
@@ -438,6 +423,10 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     pl.q_orig = ibase + n_qtiles + n_slots;
     pl.flat_begin = g->flat_begin;
     pl.flat_end = g->flat_end;
+    {
+        const char *skip = std::getenv("COVEST_FACTORED_SKIP"); // profiling aid, see tiles.h
+        pl.skip_phases = skip ? std::atoi(skip) : 0;
+    }
     g->has_plan = pl.max_o >= 1;
     return COVEST_OK;
 }

@@ -28,10 +28,13 @@ namespace covest {
 namespace {
 
 template <int S>
-__global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const TileView tv,
+__global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const int32_t n_tiles,
+                                                       const double *__restrict__ tile_dbl,
+                                                       const int32_t *__restrict__ tile_int,
                                                        const PointSource src, const int64_t n,
                                                        double *__restrict__ out_ll)
 {
+    const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
     __shared__ __attribute__((aligned(16))) double log_tab[64];
     load_log_table(log_tab);
     __syncthreads();
@@ -103,7 +106,8 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
         return hipErrorInvalidValue;
     const dim3 block(256);
     const dim3 grid((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL((ll_basic_kernel<8>), grid, block, 0, stream, m, tv, src, n, out_ll);
+    hipLaunchKernelGGL((ll_basic_kernel<8>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base, tv.int_base, src, n,
+                       out_ll);
     return hipGetLastError();
 }
 

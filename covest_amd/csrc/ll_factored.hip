@@ -50,10 +50,13 @@ namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <int NT, bool TAIL>
-__global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const TileView tv,
+__global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const int32_t n_tiles,
+                                                         const double *__restrict__ tile_dbl,
+                                                         const int32_t *__restrict__ tile_int,
                                                          const FactoredPlan plan,
                                                          double *__restrict__ out_ll)
 {
+    const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
     constexpr int NW = NT / kWave;
     constexpr int LD = NT + 2; // G row stride in doubles: 2*NT + 4 dwords = 4 (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [kTileBins][LD]; reused for the final per-q combine
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int col = lane & 15; // q column inside a tile / key row of the A fragment
     const int kq = lane >> 4;  // which of the 4 o of an MFMA step
     const int n_slots = plan.n_qtiles * 16;
-    int nsteps[kMaxUnits], uhalf[kMaxUnits], tq[kMaxUnits], qslot[kMaxUnits];
+    int nsteps[kMaxUnits], nfull[kMaxUnits], tq[kMaxUnits], qslot[kMaxUnits];
     double r4[kMaxUnits], llacc[kMaxUnits];
     CompSum spacc[kMaxUnits];
     int max_steps = 0;
@@ -103,9 +106,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const int qt = __builtin_amdgcn_readfirstlane(plan.unit_tile[at]);
         const bool on = qt >= 0;
         const int slot = (on ? qt : 0) * 16 + col;
-        uhalf[k] = __builtin_amdgcn_readfirstlane(plan.unit_half[at]);
         qslot[k] = on ? slot : -1;
         nsteps[k] = __builtin_amdgcn_readfirstlane(on ? plan.qtile_nsteps[qt] : 0);
+        nfull[k] = __builtin_amdgcn_readfirstlane(on ? plan.qtile_nfull[qt] : 0);
         tq[k] = on ? plan.q_T[slot] : 0;
         r4[k] = plan.q_r4[slot];
         llacc[k] = 0.0;
@@ -116,45 +119,72 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 
     for (int t = 0; t < tv.n_tiles; ++t) {
         // ================= phase A: G[key][o] for 32 keys =================
-        if (wave_builds) {
+        if (wave_builds && !(plan.skip_phases & 1)) {
             const double k0 = tv.first_key[t];
             const int nb = tv.n_bins[t];
             st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
                           tv.run_start[t] != 0);
             const double *scal = tv.scal + (int64_t)t * kTileBins;
-            for (int b = 0; b < nb; ++b)
-                Gs[b * LD + tid] = st.step() * scal[b];
-            for (int b = nb; b < kTileBins; ++b)
-                Gs[b * LD + tid] = 0.0;
+            if (nb == kTileBins) { // the common case: straight-line code, scales in SGPRs
+#pragma unroll
+                for (int b = 0; b < kTileBins; ++b)
+                    Gs[b * LD + tid] = st.step() * scal[b];
+            } else {
+                for (int b = 0; b < nb; ++b)
+                    Gs[b * LD + tid] = st.step() * scal[b];
+                for (int b = nb; b < kTileBins; ++b)
+                    Gs[b * LD + tid] = 0.0;
+            }
             st.leave_tile(tv.renorm[t]);
         }
         __syncthreads();
 
         // ================= phase B: P = G x b on the matrix pipe =================
+        // counts of the 8 rows this lane will log (latency hidden under the MFMAs)
+        double hrow[2][4];
+        bool inrow[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bin = 16 * u + kq + 4 * r;
+                hrow[u][r] = tv.cnt[(int64_t)t * kTileBins + bin];
+                inrow[u][r] = TAIL ? tv.in_sp[(int64_t)t * kTileBins + bin] != 0.0 : true;
+            }
         d4 acc[kMaxUnits];
-        double wfirst[kMaxUnits], wrun[kMaxUnits]; // b_o for o = 1+kq and 5+kq (L1-resident, reloaded per tile)
+        double wrun[kMaxUnits]; // b_o for o = 5 + kq, advanced by (1-q)^4 per step
+        const double *arow0 = Gs + col * LD + kq;
+        const double *arow1 = Gs + (16 + col) * LD + kq;
+        double a0 = arow0[0], a1 = arow1[0];
+        // step 0 (o = 1 + kq): weights b_1..b_4 from the host table (L1-resident)
 #pragma unroll
         for (int k = 0; k < kMaxUnits; ++k) {
             acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
             const int slot = qslot[k] >= 0 ? qslot[k] : col;
-            wfirst[k] = plan.q_first8[(int64_t)kq * n_slots + slot];
+            double w = plan.q_first8[(int64_t)kq * n_slots + slot];
             wrun[k] = plan.q_first8[(int64_t)(4 + kq) * n_slots + slot];
+            if (nsteps[k] > 0) { // wave-uniform
+                w = (1 + kq < tq[k]) ? w : 0.0;
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < kHalfUnits ? a0 : a1, w, acc[k], 0, 0, 0);
+            }
         }
-        const double *arow0 = Gs + col * LD + kq;
-        const double *arow1 = Gs + (16 + col) * LD + kq;
-        for (int step = 0; step < max_steps; ++step) {
-            const double a0 = arow0[4 * step];
-            const double a1 = arow1[4 * step];
+        double a0n = arow0[4], a1n = arow1[4]; // software prefetch of the next A fragments
+        const int steps_run = (plan.skip_phases & 2) ? 0 : max_steps;
+        for (int step = 1; step < steps_run; ++step) {
+            a0 = a0n;
+            a1 = a1n;
+            a0n = arow0[4 * step + 4]; // one step past the end stays inside the row (LD = NT + 2)
+            a1n = arow1[4 * step + 4];
             const int o_here = 1 + 4 * step + kq;
 #pragma unroll
             for (int k = 0; k < kMaxUnits; ++k) {
                 if (step < nsteps[k]) { // wave-uniform
-                    // b_o: o = 1..8 from the host, then b_{o+4} = b_o * (1-q)^4  (models.py:198-206)
-                    double w = (step == 0) ? wfirst[k] : wrun[k];
-                    if (step >= 1)
-                        wrun[k] *= r4[k];
-                    w = (o_here < tq[k]) ? w : 0.0; // o ranges over 1..T-1 (models.py:239)
-                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(uhalf[k] ? a1 : a0, w, acc[k], 0, 0, 0);
+                    // b_{o+4} = b_o * (1-q)^4 for o >= 3  (models.py:198-206)
+                    double w = wrun[k];
+                    wrun[k] *= r4[k];
+                    if (step >= nfull[k]) // only the last steps of a tile have columns past their T
+                        w = (o_here < tq[k]) ? w : 0.0; // o ranges over 1..T-1 (models.py:239)
+                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < kHalfUnits ? a0 : a1, w, acc[k], 0, 0, 0);
                 }
             }
         }
@@ -163,19 +193,15 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
         for (int k = 0; k < kMaxUnits; ++k) {
-            if (qslot[k] >= 0) { // wave-uniform: the unit exists
+            if (qslot[k] >= 0 && !(plan.skip_phases & 4)) { // wave-uniform: the unit exists
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int bin = 16 * uhalf[k] + kq + 4 * r;
-                    const double h = tv.cnt[(int64_t)t * kTileBins + bin];
-                    const bool in_sp = tv.in_sp[(int64_t)t * kTileBins + bin] != 0.0;
+                    const double h = hrow[k < kHalfUnits ? 0 : 1][r];
                     const double p = acc[k][r];
-                    if (in_sp) {
-                        if (TAIL)
-                            spacc[k].add(p);
-                        if (h != 0.0)
-                            llacc[k] += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
-                    }
+                    if (TAIL && inrow[k < kHalfUnits ? 0 : 1][r])
+                        spacc[k].add(p);
+                    if (h != 0.0) // filler and padding keys have h == 0
+                        llacc[k] += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
                 }
             }
         }
@@ -218,13 +244,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const int w = e / (kMaxUnits * 16), k = (e / 16) % kMaxUnits, c = e & 15;
         const int at = ((int)blockIdx.y * NW + w) * kMaxUnits + k;
         const int qt = plan.unit_tile[at];
-        if (qt < 0 || plan.unit_half[at] != 0)
+        if (qt < 0 || k >= kHalfUnits)
             continue;
         int pe = -1; // the unit with the same tile and half 1 (always in the same workgroup)
         for (int w2 = 0; w2 < NW && pe < 0; ++w2)
             for (int k2 = 0; k2 < kMaxUnits; ++k2) {
                 const int at2 = ((int)blockIdx.y * NW + w2) * kMaxUnits + k2;
-                if (plan.unit_tile[at2] == qt && plan.unit_half[at2] == 1) {
+                if (k2 >= kHalfUnits && plan.unit_tile[at2] == qt) {
                     pe = (w2 * kMaxUnits + k2) * 16 + c;
                     break;
                 }
@@ -257,7 +283,8 @@ template <int NT, bool TAIL>
 hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                           double *out_ll, hipStream_t stream)
 {
-    const size_t lds = (size_t)kTileBins * (NT + 2) * sizeof(double);
+    // + 8 doubles: the A-fragment prefetch of phase B reads one MFMA step past the last row's end
+    const size_t lds = ((size_t)kTileBins * (NT + 2) + 8) * sizeof(double);
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ll_factored_kernel<NT, TAIL>),
@@ -267,7 +294,8 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
         configured = true;
     }
     const dim3 grid((unsigned)(plan.ce_end - plan.ce_begin), (unsigned)plan.n_qblocks);
-    hipLaunchKernelGGL((ll_factored_kernel<NT, TAIL>), grid, dim3(NT), lds, stream, m, tv, plan, out_ll);
+    hipLaunchKernelGGL((ll_factored_kernel<NT, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.dbl_base,
+                       tv.int_base, plan, out_ll);
     return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // tiles.h -- the tile table of the pmf recurrence (see streams.h), shared by the
 // host builder (capi.cpp: build_tiles) and the fast kernels.
 #pragma once
+#include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
 namespace covest {
@@ -15,6 +16,12 @@ constexpr double kWindowLn = -760.0; // terms below e^-760 are 0 in double
 // indexed by tile is wave-uniform and read through the scalar cache.
 struct TileView {
     int32_t n_tiles;
+    // raw buffers behind the views below: [4*nt + 3*nt*32] doubles, [2*nt] int32.  The fast
+    // kernels take these two as separate `const __restrict__` kernel arguments and rebuild the
+    // view from them (tile_view_from): only then does hipcc know the table is read-only and
+    // never aliased, and fetches the wave-uniform entries with s_load into SGPRs.
+    const double *dbl_base;
+    const int32_t *int_base;
     const double *first_key;   // [n_tiles] k0 as a double
     const int32_t *n_bins;     // [n_tiles] keys in the tile (1..32)
     const int32_t *run_start;  // [n_tiles] 1: keys are not contiguous with the previous tile -> re-anchor
@@ -26,6 +33,25 @@ struct TileView {
     const double *in_sp;       // [n_tiles][32] 1.0 if the key is a histogram key (counts in sp_j), else 0.0
 };
 
+// The layout of capi.cpp: build_tiles.
+inline __host__ __device__ TileView tile_view_from(int32_t nt, const double *dbl, const int32_t *ints)
+{
+    TileView tv;
+    tv.n_tiles = nt;
+    tv.dbl_base = dbl;
+    tv.int_base = ints;
+    tv.first_key = dbl;
+    tv.lgam_prev = dbl + nt;
+    tv.lgam_last = dbl + 2 * (int64_t)nt;
+    tv.renorm = dbl + 3 * (int64_t)nt;
+    tv.scal = dbl + 4 * (int64_t)nt;
+    tv.cnt = tv.scal + (int64_t)nt * kTileBins;
+    tv.in_sp = tv.cnt + (int64_t)nt * kTileBins;
+    tv.n_bins = ints;
+    tv.run_start = ints + nt;
+    return tv;
+}
+
 // Work description of K-factored (ll_factored.hip), built at covest_grid_create
 // for a dense repeats-model grid.  The Q = |q1| x |q2| x |q| weight vectors are
 // sorted by threshold_o (descending) into "slots", 16 per q-tile.  The unit of
@@ -33,7 +59,8 @@ struct TileView {
 // costing ceil((T-1)/4) MFMAs per key tile; units are dealt to the waves of a
 // workgroup by longest-processing-time first, balanced per SIMD (waves w and w+4
 // share one), so that the one tile with T ~ 285 does not serialise the workgroup.
-constexpr int kMaxUnits = 6; // (q-tile, half) units a wave carries (accumulators in registers)
+constexpr int kHalfUnits = 3;             // units a wave carries per half of the key tile
+constexpr int kMaxUnits = 2 * kHalfUnits; // slots 0..2: keys 0..15 of the tile, slots 3..5: keys 16..31
 
 struct FactoredPlan {
     const double *c_axis, *e_axis; // device copies of axes 0 and 1
@@ -44,14 +71,16 @@ struct FactoredPlan {
     int32_t max_o;                 // max threshold_o - 1: copy numbers to build
     int32_t n_threads;             // workgroup size the unit tables were built for (256 or 512)
     int32_t n_qblocks;             // workgroups per (c, e) (gridDim.y); each rebuilds G
-    const int32_t *unit_tile;      // [n_qblocks][n_threads/64][kMaxUnits] q-tile of the unit, -1 = none
-    const int32_t *unit_half;      // same shape: 0 = keys 0..15 of the key tile, 1 = keys 16..31
-    const int32_t *qtile_nsteps;   // [n_qtiles] ceil((max T in tile - 1) / 4)
+    const int32_t *unit_tile;      // [n_qblocks][n_threads/64][kMaxUnits] q-tile of the unit, -1 = none;
+                                   //   the slot index gives the half (see kHalfUnits)
+    const int32_t *qtile_nsteps;   // [n_qtiles] ceil((max T in tile - 1) / 4): MFMA steps of the tile
+    const int32_t *qtile_nfull;    // [n_qtiles] floor((min T in tile - 1) / 4): steps with no column cut off
     const int32_t *q_T;            // [n_qtiles*16] threshold_o per slot (0 = padding)
     const int32_t *q_orig;         // [n_qtiles*16] index into the (q1,q2,q) product (-1 = padding)
     const double *q_first8;        // [8][n_qtiles*16] b_o, o = 1..8   (covest/models.py:193-208)
     const double *q_r4;            // [n_qtiles*16] (1 - q)^4
     int64_t flat_begin, flat_end;  // flat indices whose LL is written (ragged block ends)
+    int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
 };
 
 } // namespace covest

@@ -48,6 +48,21 @@ __global__ __launch_bounds__(256) void k_mfma(double *out, double a, double b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// dependent-accumulator chains: NACC independent accumulators per wave, WAVES_PER_SIMD set by the launch
+template <int NACC>
+__global__ __launch_bounds__(512) void k_mfma_chain(double *out, double a, double b)
+{
+    d4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
+    double av = a + threadIdx.x * 1e-9, bv = b;
+    for (int it = 0; it < ITERS * 4 / NACC; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
+    }
+    double s = 0; for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int NFMA>
 __global__ __launch_bounds__(256) void k_both(double *out, double a, double b)
 {
@@ -134,6 +149,22 @@ int main()
     printf("mfma + 8 fma each: %8.3f ms  mfma %7.2f + valu %7.2f TFLOP/s\n", ms, mfma_flop / ms / 1e9, lanes * ITERS * 32 * 2 / ms / 1e9);
     ms = time_kernel([&] { hipLaunchKernelGGL(k_both<16>, dim3(blocks), dim3(threads), 0, 0, out, 1.0, 0.999999); });
     printf("mfma +16 fma each: %8.3f ms  mfma %7.2f + valu %7.2f TFLOP/s\n", ms, mfma_flop / ms / 1e9, lanes * ITERS * 64 * 2 / ms / 1e9);
+    {   // one 512-thread workgroup per CU = 2 waves per SIMD, as K-factored runs
+        const double fl = 256.0 * 8 * ITERS * 4 * (16 * 16 * 4 * 2);
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_mfma_chain<1>, dim3(256), dim3(512), 0, 0, out, 1.0, 0.999999); });
+        printf("mfma chain x1, 2 waves/SIMD: %8.3f ms %7.2f TFLOP/s\n", ms, fl / ms / 1e9);
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_mfma_chain<2>, dim3(256), dim3(512), 0, 0, out, 1.0, 0.999999); });
+        printf("mfma chain x2, 2 waves/SIMD: %8.3f ms %7.2f TFLOP/s\n", ms, fl / ms / 1e9);
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_mfma_chain<4>, dim3(256), dim3(512), 0, 0, out, 1.0, 0.999999); });
+        printf("mfma chain x4, 2 waves/SIMD: %8.3f ms %7.2f TFLOP/s\n", ms, fl / ms / 1e9);
+        const double fl1 = 256.0 * 4 * ITERS * 4 * (16 * 16 * 4 * 2);
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_mfma_chain<1>, dim3(256), dim3(256), 0, 0, out, 1.0, 0.999999); });
+        printf("mfma chain x1, 1 wave/SIMD : %8.3f ms %7.2f TFLOP/s\n", ms, fl1 / ms / 1e9);
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_mfma_chain<2>, dim3(256), dim3(256), 0, 0, out, 1.0, 0.999999); });
+        printf("mfma chain x2, 1 wave/SIMD : %8.3f ms %7.2f TFLOP/s\n", ms, fl1 / ms / 1e9);
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_mfma_chain<4>, dim3(256), dim3(256), 0, 0, out, 1.0, 0.999999); });
+        printf("mfma chain x4, 1 wave/SIMD : %8.3f ms %7.2f TFLOP/s\n", ms, fl1 / ms / 1e9);
+    }
     ms = time_kernel([&] { hipLaunchKernelGGL(k_exp, dim3(blocks), dim3(threads), 0, 0, out, 1.0); });
     printf("exp(f64)         : %8.3f ms  %7.2f Gexp/s  (= %.1f fma-equivalents each)\n", ms, lanes * (ITERS / 8) * 4 / ms / 1e6, 0.0);
     float ms_e = ms;
