@@ -27,7 +27,7 @@ namespace covest {
 
 namespace {
 
-template <int S>
+template <int S, bool TAIL>
 __global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const int32_t n_tiles,
                                                        const double *__restrict__ tile_dbl,
                                                        const int32_t *__restrict__ tile_int,
@@ -57,7 +57,15 @@ __global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const i
 
     double acc_ll = 0.0;
     CompSum acc_sp = {0.0, 0.0};
-    const bool want_sp = m.tail != 0.0;
+
+    // one key: advance the streams, scale, sum into sp_j, log (all branches wave-uniform)
+    auto visit = [&](double scal, double h, bool in_sp) {
+        const double p = st.step() * scal; // p_j, flushed like the reference's double
+        if (TAIL && in_sp)
+            acc_sp.add(p);
+        if (h != 0.0) // filler keys and zero counts: no log (`if h`, covest/models.py:106)
+            acc_ll += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
+    };
 
     for (int t = 0; t < tv.n_tiles; ++t) {
         const double k0 = tv.first_key[t];
@@ -67,21 +75,32 @@ __global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const i
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         const double *cnt = tv.cnt + (int64_t)t * kTileBins;
         const double *insp = tv.in_sp + (int64_t)t * kTileBins;
-        for (int b = 0; b < nb; ++b) {
-            const double p = st.step() * scal[b]; // p_j, flushed like the reference's double
-            if (insp[b] != 0.0) {                 // wave-uniform
-                if (want_sp)
-                    acc_sp.add(p);
-                const double h = cnt[b];
-                if (h != 0.0)
-                    acc_ll += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
+        if (nb == kTileBins) {
+            // full tile: two straight-line halves of 16 keys, their scales and counts fetched
+            // into SGPRs up front (s_load_dwordx16) so no key waits on the scalar cache
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                double sc[16], hc[16];
+                bool in[16];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    sc[b] = scal[16 * half + b];
+                    hc[b] = cnt[16 * half + b];
+                    in[b] = TAIL ? insp[16 * half + b] != 0.0 : true;
+                }
+#pragma unroll
+                for (int b = 0; b < 16; ++b)
+                    visit(sc[b], hc[b], in[b]);
             }
+        } else {
+            for (int b = 0; b < nb; ++b)
+                visit(scal[b], cnt[b], TAIL ? insp[b] != 0.0 : true);
         }
         st.leave_tile(tv.renorm[t]);
     }
 
     double tail_term = 0.0;
-    if (want_sp) {
+    if (TAIL) {
         double sp = acc_sp.hi + acc_sp.lo;
         if (!(sp < 1.0))
             sp = 1.0;
@@ -106,8 +125,12 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
         return hipErrorInvalidValue;
     const dim3 block(256);
     const dim3 grid((unsigned)((n + 255) / 256));
-    hipLaunchKernelGGL((ll_basic_kernel<8>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base, tv.int_base, src, n,
-                       out_ll);
+    if (m.tail != 0.0)
+        hipLaunchKernelGGL((ll_basic_kernel<8, true>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base,
+                           tv.int_base, src, n, out_ll);
+    else
+        hipLaunchKernelGGL((ll_basic_kernel<8, false>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base,
+                           tv.int_base, src, n, out_ll);
     return hipGetLastError();
 }
 
