@@ -24,7 +24,7 @@ EXPORTS = (
     "covest_model_bins_evaluated", "covest_threshold_o", "covest_eval_points",
     "covest_probabilities", "covest_grid_create", "covest_grid_destroy", "covest_grid_size",
     "covest_grid_eval", "covest_grid_argmin", "covest_grid_ll_device", "covest_grid_ll_host",
-    "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms",
+    "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
 )
 
 
@@ -110,6 +110,8 @@ def lib():
     L.covest_grid_profile.argtypes = [vp, i32]
     L.covest_grid_kernel_ms.restype = ctypes.c_int
     L.covest_grid_kernel_ms.argtypes = [vp, dp, ctypes.POINTER(i64)]
+    L.covest_grid_diag.restype = i64
+    L.covest_grid_diag.argtypes = [vp, ctypes.POINTER(i64), i64]
     _lib = L
     return L
 

@@ -348,6 +348,8 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     if (nq % 16 != 0)
         nfull[(size_t)n_qtiles - 1] = 0; // padding columns (T = 0) are cut off from the first step
     // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
+    const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
+    const int n_buf = (2 * (size_t)kTileBins * ld + 8) * sizeof(double) + 1024 <= 160 * 1024 ? 2 : 1;
     const int n_units = 2 * n_qtiles;
     const int nt = (t_max - 1 <= 256 && n_units <= 4 * kMaxUnits) ? 256 : 512;
     const int nw = nt / 64;
@@ -367,6 +369,11 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         // free slot for the unit's half, then into the lighter of that SIMD's waves with such a slot
         const int n_bins = std::min(4, nw);
         std::vector<long> bin_load((size_t)n_bins, 0), wave_load((size_t)nw, 0);
+        if (n_buf == 2) // builders contract less: they fill the next key tile in the same interval
+            for (int w = 0; w < nw && w * 64 < t_max - 1; ++w) {
+                bin_load[(size_t)(w % n_bins)] += kBuildCost;
+                wave_load[(size_t)w] += kBuildCost;
+            }
         std::vector<int> used((size_t)nw * 2, 0); // [wave][half] slots taken
         for (const Unit &u : units) {
             int best_wave = -1;
@@ -414,6 +421,8 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     pl.max_o = t_max - 1;
     pl.n_threads = nt;
     pl.n_qblocks = n_qblocks;
+    pl.ld = ld;
+    pl.n_buf = std::getenv("COVEST_FACTORED_NBUF") ? std::atoi(std::getenv("COVEST_FACTORED_NBUF")) : n_buf;
     pl.unit_tile = ibase + n_qtiles + 2 * n_slots;
     pl.qtile_nfull = ibase + n_qtiles + 2 * n_slots + n_unit;
     pl.q_first8 = dbase;
@@ -426,6 +435,15 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     {
         const char *skip = std::getenv("COVEST_FACTORED_SKIP"); // profiling aid, see tiles.h
         pl.skip_phases = skip ? std::atoi(skip) : 0;
+        pl.diag = nullptr;
+        if (std::getenv("COVEST_FACTORED_DIAG")) { // profiling aid: leaked on purpose, diagnostic runs only
+            void *dp = nullptr;
+            const size_t bytes = (size_t)(pl.ce_end - pl.ce_begin) * n_qblocks * nw * 8 * sizeof(long long);
+            if (hipMalloc(&dp, bytes) == hipSuccess && hipMemset(dp, 0, bytes) == hipSuccess) {
+                pl.diag = static_cast<long long *>(dp);
+                std::fprintf(stderr, "COVEST_FACTORED_DIAG %p %zu\n", dp, bytes);
+            }
+        }
     }
     g->has_plan = pl.max_o >= 1;
     return COVEST_OK;
@@ -929,6 +947,19 @@ int covest_grid_ll_host(covest_grid *g, double *out_ll)
     if (n > 0)
         HIP_TRY(hipMemcpy(out_ll, g->ll.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return COVEST_OK;
+}
+
+int64_t covest_grid_diag(covest_grid *g, int64_t *out, int64_t n)
+{
+    if (!g || !g->has_plan || !g->plan.diag)
+        return 0;
+    const int nw = g->plan.n_threads / 64;
+    const int64_t total = (g->plan.ce_end - g->plan.ce_begin) * g->plan.n_qblocks * nw * 8;
+    if (out && n > 0) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(out, g->plan.diag, (size_t)std::min(n, total) * sizeof(int64_t), hipMemcpyDeviceToHost);
+    }
+    return total;
 }
 
 int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, const char **kernel)

@@ -58,8 +58,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 {
     const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
     constexpr int NW = NT / kWave;
-    constexpr int LD = NT + 2; // G row stride in doubles: 2*NT + 4 dwords = 4 (mod 64) -> conflict-free A reads
-    extern __shared__ double Gs[]; // [kTileBins][LD]; reused for the final per-q combine
+    const int LD = plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
+    extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
     __shared__ __attribute__((aligned(16))) double log_tab[64];
     load_log_table(log_tab);
 
@@ -87,10 +87,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const bool wave_builds = wave * kWave < plan.max_o; // wave-uniform
     StreamSet<8> st;
     st.init(m, lam, tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o);
-    if (!wave_builds) { // these columns of G stay zero for the whole kernel
-        for (int b = 0; b < kTileBins; ++b)
-            Gs[b * LD + tid] = 0.0;
-    }
+    const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
 
     // ---- phase-B/C state: this wave's (q-tile, half) units ----
     const int col = lane & 15; // q column inside a tile / key row of the A fragment
@@ -117,27 +114,63 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         max_steps = max(max_steps, nsteps[k]);
     }
 
-    for (int t = 0; t < tv.n_tiles; ++t) {
-        // ================= phase A: G[key][o] for 32 keys =================
-        if (wave_builds && !(plan.skip_phases & 1)) {
-            const double k0 = tv.first_key[t];
-            const int nb = tv.n_bins[t];
-            st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                          tv.run_start[t] != 0);
-            const double *scal = tv.scal + (int64_t)t * kTileBins;
-            if (nb == kTileBins) { // the common case: straight-line code, scales in SGPRs
+    // ================= phase A: G[key][o] of key tile t into `dst` =================
+    auto build_tile = [&](int t, double *dst) {
+        if (plan.skip_phases & 1)
+            return;
+        const double k0 = tv.first_key[t];
+        const int nb = tv.n_bins[t];
+        st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
+                      tv.run_start[t] != 0);
+        const double *scal = tv.scal + (int64_t)t * kTileBins;
+        double *colp = dst + (lane_in_row ? tid : 0);
+        if (nb == kTileBins) { // the common case: straight-line code, scales in SGPRs
 #pragma unroll
-                for (int b = 0; b < kTileBins; ++b)
-                    Gs[b * LD + tid] = st.step() * scal[b];
-            } else {
-                for (int b = 0; b < nb; ++b)
-                    Gs[b * LD + tid] = st.step() * scal[b];
-                for (int b = nb; b < kTileBins; ++b)
-                    Gs[b * LD + tid] = 0.0;
+            for (int b = 0; b < kTileBins; ++b) {
+                const double g = st.step() * scal[b];
+                if (lane_in_row)
+                    colp[b * LD] = g;
             }
-            st.leave_tile(tv.renorm[t]);
+        } else {
+            for (int b = 0; b < kTileBins; ++b) {
+                const double g = b < nb ? st.step() * scal[b] : 0.0;
+                if (lane_in_row)
+                    colp[b * LD] = g;
+            }
         }
+        st.leave_tile(tv.renorm[t]);
+    };
+
+    // in-kernel stamps (diagnostic runs only): cycles per wave in build / contract / log / barrier
+    long long dg_a = 0, dg_b = 0, dg_c = 0, dg_w = 0, dg_t0 = 0;
+    const bool diag = plan.diag != nullptr;
+#define STAMP(acc)                                    \
+    if (diag) {                                       \
+        const long long now__ = (long long)clock64(); \
+        acc += now__ - dg_t0;                         \
+        dg_t0 = now__;                                \
+    }
+    if (diag)
+        dg_t0 = (long long)clock64();
+
+    // With two buffers the builders fill tile t+1 while every wave contracts tile t: one
+    // barrier per tile, and the host's unit assignment charges the builders for phase A.
+    const bool dbuf = plan.n_buf == 2;
+    if (dbuf) {
+        if (wave_builds)
+            build_tile(0, Gs);
         __syncthreads();
+    }
+    for (int t = 0; t < tv.n_tiles; ++t) {
+        const double *cur = Gs + (dbuf ? (t & 1) * kTileBins * LD : 0);
+        if (!dbuf) {
+            if (wave_builds)
+                build_tile(t, Gs);
+            __syncthreads();
+        } else if (wave_builds && t + 1 < tv.n_tiles) {
+            build_tile(t + 1, Gs + ((t + 1) & 1) * kTileBins * LD);
+        }
+        STAMP(dg_a)
 
         // ================= phase B: P = G x b on the matrix pipe =================
         // counts of the 8 rows this lane will log (latency hidden under the MFMAs)
@@ -153,8 +186,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
         d4 acc[kMaxUnits];
         double wrun[kMaxUnits]; // b_o for o = 5 + kq, advanced by (1-q)^4 per step
-        const double *arow0 = Gs + col * LD + kq;
-        const double *arow1 = Gs + (16 + col) * LD + kq;
+        const double *arow0 = cur + col * LD + kq;
+        const double *arow1 = cur + (16 + col) * LD + kq;
         double a0 = arow0[0], a1 = arow1[0];
         // step 0 (o = 1 + kq): weights b_1..b_4 from the host table (L1-resident)
 #pragma unroll
@@ -189,6 +222,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
         }
 
+        STAMP(dg_b)
         // ================= phase C: h_j * log p_j from the accumulators =================
         // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
@@ -205,9 +239,19 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
             }
         }
-        __syncthreads(); // Gs is rewritten by the next tile's phase A
+        STAMP(dg_c)
+        __syncthreads(); // the tile just contracted may be overwritten, the one just built may be read
+        STAMP(dg_w)
     }
 
+    if (diag && lane == 0) {
+        long long *d = plan.diag + ((int64_t)(blockIdx.x * gridDim.y + blockIdx.y) * NW + wave) * 8;
+        d[0] = dg_a;
+        d[1] = dg_b;
+        d[2] = dg_c;
+        d[3] = dg_w;
+    }
+#undef STAMP
     // ---- per-q results: sum the 4 row groups of the accumulator layout, then the two
     //      halves of each q-tile (they may live on different waves) through LDS ----
     double *part_ll = Gs;                               // [NW][kMaxUnits][16]
@@ -284,14 +328,14 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
                           double *out_ll, hipStream_t stream)
 {
     // + 8 doubles: the A-fragment prefetch of phase B reads one MFMA step past the last row's end
-    const size_t lds = ((size_t)kTileBins * (NT + 2) + 8) * sizeof(double);
-    static bool configured = false;
-    if (!configured) {
+    const size_t lds = ((size_t)plan.n_buf * kTileBins * plan.ld + 8) * sizeof(double);
+    static size_t configured = 0;
+    if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ll_factored_kernel<NT, TAIL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        configured = true;
+        configured = lds;
     }
     const dim3 grid((unsigned)(plan.ce_end - plan.ce_begin), (unsigned)plan.n_qblocks);
     hipLaunchKernelGGL((ll_factored_kernel<NT, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.dbl_base,

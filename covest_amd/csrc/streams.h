@@ -90,15 +90,21 @@ struct StreamSet {
     }
 
     // Advance every stream by one key and return the sum of the scaled terms.
+    // Two interleaved partial sums: an 8-long dependent fma chain would leave the fp64
+    // pipe idle at the 2 waves per SIMD the factored kernel runs with.
     __device__ __forceinline__ double step()
     {
-        double g = 0.0;
+        double g0 = 0.0, g1 = 0.0;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
+        for (int s = 0; s < S; s += 2) {
             v[s] *= x[s];
-            g += v[s];
+            g0 += v[s];
+            if (s + 1 < S) {
+                v[s + 1] *= x[s + 1];
+                g1 += v[s + 1];
+            }
         }
-        return g;
+        return g0 + g1;
     }
 
     __device__ __forceinline__ void leave_tile(double renorm)

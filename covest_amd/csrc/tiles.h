@@ -61,6 +61,7 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, const double *dbl
 // share one), so that the one tile with T ~ 285 does not serialise the workgroup.
 constexpr int kHalfUnits = 3;             // units a wave carries per half of the key tile
 constexpr int kMaxUnits = 2 * kHalfUnits; // slots 0..2: keys 0..15 of the tile, slots 3..5: keys 16..31
+constexpr int kBuildCost = 36;            // phase A of one wave and key tile, in MFMA-step equivalents (measured)
 
 struct FactoredPlan {
     const double *c_axis, *e_axis; // device copies of axes 0 and 1
@@ -71,6 +72,8 @@ struct FactoredPlan {
     int32_t max_o;                 // max threshold_o - 1: copy numbers to build
     int32_t n_threads;             // workgroup size the unit tables were built for (256 or 512)
     int32_t n_qblocks;             // workgroups per (c, e) (gridDim.y); each rebuilds G
+    int32_t ld;                    // G row stride in doubles: roundup32(max_o) + 2 (= 4 dwords mod 64)
+    int32_t n_buf;                 // 2: G double-buffered in LDS (build tile t+1 while contracting tile t)
     const int32_t *unit_tile;      // [n_qblocks][n_threads/64][kMaxUnits] q-tile of the unit, -1 = none;
                                    //   the slot index gives the half (see kHalfUnits)
     const int32_t *qtile_nsteps;   // [n_qtiles] ceil((max T in tile - 1) / 4): MFMA steps of the tile
@@ -80,6 +83,7 @@ struct FactoredPlan {
     const double *q_first8;        // [8][n_qtiles*16] b_o, o = 1..8   (covest/models.py:193-208)
     const double *q_r4;            // [n_qtiles*16] (1 - q)^4
     int64_t flat_begin, flat_end;  // flat indices whose LL is written (ragged block ends)
+    long long *diag;               // PROFILING ONLY (env COVEST_FACTORED_DIAG): per-wave s_memtime sums [wg][wave][8]
     int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
 };
 

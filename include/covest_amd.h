@@ -152,6 +152,13 @@ int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, con
 int covest_grid_profile(covest_grid *g, int32_t enable);
 int covest_grid_kernel_ms(covest_grid *g, double *total_ms, int64_t *launches);
 
+/* PROFILING AID: with the environment variable COVEST_FACTORED_DIAG set at
+ * covest_grid_create, the factored kernel accumulates s_memtime stamps per wave
+ * ([workgroup][wave][8] int64: build, contract, log, barrier cycles); this copies
+ * up to n of them to the host and returns how many exist.  Not part of the
+ * reference's interface. */
+int64_t covest_grid_diag(covest_grid *g, int64_t *out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-wave phase cycles of K-factored on C3 (in-kernel s_memtime stamps).
+Run on the GPU box:  COVEST_FACTORED_DIAG=1 python tools/factored_diag.py"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("COVEST_FACTORED_DIAG", "1")
+from bench import load_hist, workload  # noqa: E402
+from covest_amd import DenseGrid, RepeatsModel, _capi  # noqa: E402
+
+kind, hname, axes = workload("c3", 1)
+m = RepeatsModel(21, 100, load_hist(hname), 0, max_error=8)
+g = DenseGrid(m, axes)
+g.evaluate(kernel="factored")
+g.argmin()
+L = _capi.lib()
+n = L.covest_grid_diag(g._handle, None, 0)
+buf = np.zeros(n, dtype=np.int64)
+L.covest_grid_diag(g._handle, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n)
+d = buf.reshape(-1, 8, 8)[:, :, :4].astype(np.float64)  # [wg][wave][build, contract, log, barrier]
+print("workgroups", d.shape[0])
+tot = d.sum(axis=2)
+print("mean cycles per wave (s_memtime ticks): total %.0f" % tot.mean())
+for w in range(8):
+    a, b, c, bar = d[:, w, :].mean(axis=0)
+    print("wave %d: build %8.0f  contract %8.0f  log %8.0f  barrier %8.0f   total %8.0f" % (
+        w, a, b, c, bar, a + b + c + bar))

@@ -149,6 +149,14 @@ int main()
     printf("mfma + 8 fma each: %8.3f ms  mfma %7.2f + valu %7.2f TFLOP/s\n", ms, mfma_flop / ms / 1e9, lanes * ITERS * 32 * 2 / ms / 1e9);
     ms = time_kernel([&] { hipLaunchKernelGGL(k_both<16>, dim3(blocks), dim3(threads), 0, 0, out, 1.0, 0.999999); });
     printf("mfma +16 fma each: %8.3f ms  mfma %7.2f + valu %7.2f TFLOP/s\n", ms, mfma_flop / ms / 1e9, lanes * ITERS * 64 * 2 / ms / 1e9);
+    for (int wps = 1; wps <= 8; wps *= 2) { // fp64 VALU rate against waves per SIMD (256-thread workgroups)
+        const int nb = 256 * wps;
+        const double ln = (double)nb * threads;
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_fma, dim3(nb), dim3(threads), 0, 0, out, 1.0, 0.999999); });
+        printf("v_fma_f64, %d wave(s)/SIMD      : %8.3f ms  %7.2f TFLOP/s\n", wps, ms, ln * ITERS * 8 * 2 / ms / 1e9);
+        ms = time_kernel([&] { hipLaunchKernelGGL(k_mulmuladd, dim3(nb), dim3(threads), 0, 0, out, 1.0, 0.999999); });
+        printf("mul+add chain, %d wave(s)/SIMD  : %8.3f ms  %7.2f Tterm/s\n", wps, ms, ln * ITERS * 8 / ms / 1e9);
+    }
     {   // one 512-thread workgroup per CU = 2 waves per SIMD, as K-factored runs
         const double fl = 256.0 * 8 * ITERS * 4 * (16 * 16 * 4 * 2);
         ms = time_kernel([&] { hipLaunchKernelGGL(k_mfma_chain<1>, dim3(256), dim3(512), 0, 0, out, 1.0, 0.999999); });
