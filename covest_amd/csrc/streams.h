@@ -90,21 +90,17 @@ struct StreamSet {
     }
 
     // Advance every stream by one key and return the sum of the scaled terms.
-    // Two interleaved partial sums: an 8-long dependent fma chain would leave the fp64
-    // pipe idle at the 2 waves per SIMD the factored kernel runs with.
+    // Advance every stream by one key and return the sum of the scaled terms.  (Splitting
+    // the sum into two interleaved chains was measured: no gain on gfx950.)
     __device__ __forceinline__ double step()
     {
-        double g0 = 0.0, g1 = 0.0;
+        double g = 0.0;
 #pragma unroll
-        for (int s = 0; s < S; s += 2) {
+        for (int s = 0; s < S; ++s) {
             v[s] *= x[s];
-            g0 += v[s];
-            if (s + 1 < S) {
-                v[s + 1] *= x[s + 1];
-                g1 += v[s + 1];
-            }
+            g += v[s];
         }
-        return g0 + g1;
+        return g;
     }
 
     __device__ __forceinline__ void leave_tile(double renorm)
