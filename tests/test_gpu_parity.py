@@ -224,6 +224,43 @@ def test_factored_small_histograms(hip_lib, oracle, hname, tail):
     print("factored", hname, tail, "worst rel err", worst)
 
 
+def test_factored_plan_shapes(hip_lib, oracle):
+    """The launch shapes of K-factored that the benchmark grid does not reach: several
+    workgroups per (c, e) (more weight vectors than one workgroup carries), threshold_o
+    above 320 (single-buffered G) and the 256-thread variant -- each against K-direct on
+    the whole grid and against the oracle on a sample."""
+    from covest_amd import DenseGrid, RepeatsModel
+    rng = np.random.default_rng(7)
+    hist = {j: int(v) for j, v in zip(range(1, 451), rng.integers(0, 2000, size=450))}
+    hist[700] = 3
+    cases = [
+        # many weight vectors: 7*6*16 = 672 -> 42 q-tiles -> 84 units > 48 per workgroup
+        ("q-blocks", 0, [np.array([20.0, 31.0]), np.array([0.01, 0.04]), np.linspace(0.3, 0.9, 7),
+                         np.linspace(0.0, 1.0, 6), np.linspace(0.08, 0.9, 16)]),
+        # threshold_o up to ~450: LD > 320, one LDS buffer
+        ("single buffer", 5, [np.array([12.0]), np.array([0.02, 0.1]), np.linspace(0.3, 0.9, 4),
+                              np.array([0.2, 0.7]), np.array([0.03, 0.04, 0.2, 0.5, 0.9])]),
+        # few vectors, small T: the 256-thread workgroup
+        ("256 threads", 0, [np.array([5.0, 9.0]), np.array([0.03]), np.linspace(0.4, 0.9, 4),
+                            np.array([0.5]), np.linspace(0.3, 0.9, 8)]),
+    ]
+    for name, tail, axes in cases:
+        m = RepeatsModel(21, 100, hist, tail, max_error=8)
+        om = oracle.OracleModel("repeats", 21, 100, hist, tail, max_error=8)
+        fac = DenseGrid(m, axes)
+        fac.evaluate(kernel="factored")
+        ll = fac.loglikelihoods()
+        ref = DenseGrid(m, axes)
+        ref.evaluate(kernel="direct")
+        worst = _check(ll, ref.loglikelihoods(), name + " vs direct", tol=1e-10)
+        assert fac.argmin()[1] == ref.argmin()[1]
+        sel = rng.choice(fac.total, size=min(24, fac.total), replace=False)
+        pts = np.array([fac.point(i) for i in sel])
+        want = om.compute_loglikelihood_many(pts, n_threads=16)
+        _check(ll[sel], want, name + " vs oracle", slack=_tail_noise(om, pts, want, tail))
+        print("factored plan shape:", name, "points", fac.total, "worst rel err vs direct", worst)
+
+
 def test_threshold_fixture_through_capi(hip_lib):
     from covest_amd import RepeatsModel
     g = load_golden("threshold_o.json")
@@ -297,6 +334,22 @@ def test_block_partition_equals_whole_grid(hip_lib):
         winners.append(g.argmin())
     assert np.array_equal(np.concatenate(parts), ll, equal_nan=True)
     assert min(winners) == best
+
+
+def test_lbfgsb_refinement_reaches_reference_optimum(hip_lib):
+    """The default (non-grid) flow of covest.covest.main: scipy L-BFGS-B with finite-difference
+    gradients over likelihood_f (covest/covest.py:33-39,55), every call a GPU evaluation.  The
+    reference, on its own test histogram, ends at (10.019077633773197, 0.04999234428925103) with
+    LL -3678682.5790824727 (measured by running the reference)."""
+    from covest_amd import BasicModel, CoverageEstimator
+    hist = load_hist("sim_c10_e0.05")
+    m = BasicModel(21, 100, hist, 0, max_error=8)
+    est = CoverageEstimator(m)
+    res, ok = est.compute_coverage([10.0, 0.05], starting_points=1, use_grid_search=False)
+    ll = m.compute_loglikelihood(*res)
+    assert rel_err(ll, -3678682.5790824727) <= 1e-9
+    # the optimum is flat to 1e-9 in LL over ~1e-3 in c: where L-BFGS-B stops depends on rounding noise
+    assert abs(res[0] - 10.019077633773197) <= 2e-3 and abs(res[1] - 0.04999234428925103) <= 1e-5
 
 
 def test_optimize_grid_trace(hip_lib):
