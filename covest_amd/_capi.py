@@ -25,6 +25,8 @@ EXPORTS = (
     "covest_probabilities", "covest_grid_create", "covest_grid_destroy", "covest_grid_size",
     "covest_grid_eval", "covest_grid_argmin", "covest_grid_ll_device", "covest_grid_ll_host",
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
+    "covest_kmer_create", "covest_kmer_destroy", "covest_kmer_reserve", "covest_kmer_add",
+    "covest_kmer_add_device", "covest_kmer_histogram", "covest_kmer_slots",
 )
 
 
@@ -110,6 +112,22 @@ def lib():
     L.covest_grid_profile.argtypes = [vp, i32]
     L.covest_grid_kernel_ms.restype = ctypes.c_int
     L.covest_grid_kernel_ms.argtypes = [vp, dp, ctypes.POINTER(i64)]
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    i64p = ctypes.POINTER(i64)
+    L.covest_kmer_create.restype = ctypes.c_int
+    L.covest_kmer_create.argtypes = [i32, i32, i64, i32, ctypes.POINTER(vp)]
+    L.covest_kmer_destroy.restype = None
+    L.covest_kmer_destroy.argtypes = [vp]
+    L.covest_kmer_reserve.restype = ctypes.c_int
+    L.covest_kmer_reserve.argtypes = [vp, i64]
+    L.covest_kmer_add.restype = ctypes.c_int
+    L.covest_kmer_add.argtypes = [vp, u8p, i64p, i64]
+    L.covest_kmer_add_device.restype = ctypes.c_int
+    L.covest_kmer_add_device.argtypes = [vp, vp, vp, i64, i64, vp]
+    L.covest_kmer_histogram.restype = ctypes.c_int
+    L.covest_kmer_histogram.argtypes = [vp, i64p, i64, i64p, i64p]
+    L.covest_kmer_slots.restype = i64
+    L.covest_kmer_slots.argtypes = [vp]
     L.covest_grid_diag.restype = i64
     L.covest_grid_diag.argtypes = [vp, ctypes.POINTER(i64), i64]
     _lib = L

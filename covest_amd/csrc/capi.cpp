@@ -949,6 +949,203 @@ int covest_grid_ll_host(covest_grid *g, double *out_ll)
     return COVEST_OK;
 }
 
+// ------------------------------------------------------------------ k-mer counter
+} // extern "C" (reopened below: the handle type needs C++ members)
+
+struct covest_kmer {
+    int device = 0;
+    int k = 20;
+    int canonical = 0;
+    KmerTable table{};
+    DevBuf keys, counts, flag, stats, hist, ws_bases, ws_offsets;
+    std::mutex lock;
+};
+
+namespace {
+
+int kmer_alloc_table(covest_kmer *c, int64_t min_slots, KmerTable &t, DevBuf &keys, DevBuf &counts)
+{
+    int lg = 10;
+    while (((int64_t)1 << lg) < min_slots && lg < 40)
+        ++lg;
+    const size_t n = (size_t)1 << lg;
+    HIP_TRY(keys.reserve(n * sizeof(unsigned long long)));
+    HIP_TRY(counts.reserve(n * sizeof(unsigned)));
+    t.keys = keys.as<unsigned long long>();
+    t.counts = counts.as<unsigned>();
+    t.mask = n - 1;
+    t.log2_slots = lg;
+    HIP_TRY(launch_kmer_fill_empty(t, nullptr));
+    (void)c;
+    return COVEST_OK;
+}
+
+int kmer_check_overflow(covest_kmer *c)
+{
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c->flag.ptr, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag)
+        return fail(COVEST_E_NOMEM, "k-mer table overflow: call covest_kmer_reserve with more slots");
+    return COVEST_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int covest_kmer_create(int32_t k, int32_t canonical, int64_t min_slots, int32_t device, covest_kmer **out)
+{
+    if (!out)
+        return fail(COVEST_E_INVALID, "covest_kmer_create: null argument");
+    *out = nullptr;
+    if (k < 1 || k > 31)
+        return fail(COVEST_E_INVALID, "covest_kmer_create: k must be in 1..31 (2k bits + an empty marker in 64)");
+    if (device < 0) {
+        hipError_t e = hipGetDevice(&device);
+        if (e != hipSuccess)
+            return fail_hip(e, "hipGetDevice");
+    }
+    covest_kmer *c = new (std::nothrow) covest_kmer();
+    if (!c)
+        return fail(COVEST_E_NOMEM, "covest_kmer_create: out of host memory");
+    c->device = device;
+    c->k = k;
+    c->canonical = canonical != 0;
+    hipError_t e = hipSetDevice(device);
+    int rc = e == hipSuccess ? COVEST_OK : fail_hip(e, "hipSetDevice");
+    if (rc == COVEST_OK)
+        rc = kmer_alloc_table(c, min_slots, c->table, c->keys, c->counts);
+    if (rc == COVEST_OK) {
+        e = c->flag.reserve(sizeof(int));
+        if (e == hipSuccess)
+            e = hipMemset(c->flag.ptr, 0, sizeof(int));
+        if (e == hipSuccess)
+            e = c->stats.reserve(2 * sizeof(unsigned long long));
+        if (e != hipSuccess)
+            rc = fail_hip(e, "covest_kmer_create: allocation");
+    }
+    if (rc != COVEST_OK) {
+        covest_kmer_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return COVEST_OK;
+}
+
+void covest_kmer_destroy(covest_kmer *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    c->keys.release();
+    c->counts.release();
+    c->flag.release();
+    c->stats.release();
+    c->hist.release();
+    c->ws_bases.release();
+    c->ws_offsets.release();
+    delete c;
+}
+
+int64_t covest_kmer_slots(const covest_kmer *c) { return c ? (int64_t)(c->table.mask + 1) : COVEST_E_INVALID; }
+
+int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
+{
+    if (!c)
+        return fail(COVEST_E_INVALID, "covest_kmer_reserve: null counter");
+    std::lock_guard<std::mutex> guard(c->lock);
+    if ((int64_t)(c->table.mask + 1) >= min_slots)
+        return COVEST_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    KmerTable bigger{};
+    DevBuf keys, counts;
+    int rc = kmer_alloc_table(c, min_slots, bigger, keys, counts);
+    if (rc != COVEST_OK) {
+        keys.release();
+        counts.release();
+        return rc;
+    }
+    HIP_TRY(launch_kmer_rehash(c->table, bigger, c->flag.as<int>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    c->keys.release();
+    c->counts.release();
+    c->keys = keys;
+    c->counts = counts;
+    c->table = bigger;
+    return kmer_check_overflow(c);
+}
+
+int covest_kmer_add_device(covest_kmer *c, const uint8_t *d_bases, const int64_t *d_offsets,
+                           int64_t n_reads, int64_t read_len, void *stream)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && !d_bases) || (!d_offsets && read_len < 0))
+        return fail(COVEST_E_INVALID, "covest_kmer_add_device: bad argument");
+    std::lock_guard<std::mutex> guard(c->lock);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_kmer_count(d_bases, d_offsets, n_reads, read_len, c->k, c->canonical, c->table,
+                              c->flag.as<int>(), static_cast<hipStream_t>(stream)));
+    return COVEST_OK;
+}
+
+int covest_kmer_add(covest_kmer *c, const uint8_t *bases, const int64_t *offsets, int64_t n_reads)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && !offsets))
+        return fail(COVEST_E_INVALID, "covest_kmer_add: bad argument");
+    if (n_reads == 0)
+        return COVEST_OK;
+    const int64_t n_bytes = offsets[n_reads] - offsets[0];
+    if (n_bytes < 0 || (n_bytes > 0 && !bases))
+        return fail(COVEST_E_INVALID, "covest_kmer_add: bad offsets");
+    {
+        std::lock_guard<std::mutex> guard(c->lock);
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(c->ws_bases.reserve((size_t)(n_bytes > 0 ? n_bytes : 1)));
+        HIP_TRY(c->ws_offsets.reserve((size_t)(n_reads + 1) * sizeof(int64_t)));
+        if (n_bytes > 0)
+            HIP_TRY(hipMemcpy(c->ws_bases.ptr, bases + offsets[0], (size_t)n_bytes, hipMemcpyHostToDevice));
+        std::vector<int64_t> rel((size_t)n_reads + 1);
+        for (int64_t i = 0; i <= n_reads; ++i)
+            rel[(size_t)i] = offsets[i] - offsets[0];
+        HIP_TRY(hipMemcpy(c->ws_offsets.ptr, rel.data(), rel.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    int rc = covest_kmer_add_device(c, c->ws_bases.as<uint8_t>(), c->ws_offsets.as<int64_t>(), n_reads, 0, nullptr);
+    if (rc != COVEST_OK)
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return kmer_check_overflow(c);
+}
+
+int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t *needed_len,
+                          int64_t *distinct)
+{
+    if (!c)
+        return fail(COVEST_E_INVALID, "covest_kmer_histogram: null counter");
+    std::lock_guard<std::mutex> guard(c->lock);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = kmer_check_overflow(c);
+    if (rc != COVEST_OK)
+        return rc;
+    unsigned long long stats[2] = {0, 0};
+    HIP_TRY(hipMemset(c->stats.ptr, 0, sizeof(stats)));
+    HIP_TRY(launch_kmer_stats(c->table, c->stats.as<unsigned long long>(), nullptr));
+    HIP_TRY(hipMemcpy(stats, c->stats.ptr, sizeof(stats), hipMemcpyDeviceToHost));
+    const int64_t need = (int64_t)stats[0] + 1; // index 0 .. max count (bin/kmer_hist.py:64)
+    if (needed_len)
+        *needed_len = need;
+    if (distinct)
+        *distinct = (int64_t)stats[1];
+    if (!out)
+        return COVEST_OK;
+    if (out_len < need)
+        return fail(COVEST_E_INVALID, "covest_kmer_histogram: output shorter than max count + 1");
+    HIP_TRY(c->hist.reserve((size_t)need * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->hist.ptr, 0, (size_t)need * sizeof(unsigned long long)));
+    HIP_TRY(launch_kmer_histogram(c->table, c->hist.as<unsigned long long>(), (unsigned long long)need, nullptr));
+    HIP_TRY(hipMemcpy(out, c->hist.ptr, (size_t)need * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return COVEST_OK;
+}
+
 int64_t covest_grid_diag(covest_grid *g, int64_t *out, int64_t n)
 {
     if (!g || !g->has_plan || !g->plan.diag)

@@ -34,4 +34,22 @@ struct ArgminResult {
 hipError_t launch_argmin(const double *ll, int64_t n, double *partial_val, int64_t *partial_idx,
                          ArgminResult *result, hipStream_t stream);
 
+// ---- K-kmer: k-mer abundance histogram (kmer_count.hip), SURVEY 8(f) row F1 ----
+// Open-addressing table in HBM: keys[slot] (all-ones = empty), counts[slot]; slots = 2^log2_slots.
+struct KmerTable {
+    unsigned long long *keys;
+    unsigned *counts;
+    unsigned long long mask;
+    int log2_slots;
+};
+hipError_t launch_kmer_fill_empty(const KmerTable &t, hipStream_t stream);
+// bases: ASCII acgt/ACGT; offsets[n_reads + 1] or nullptr with every read `fixed_len` long.
+hipError_t launch_kmer_count(const unsigned char *bases, const int64_t *offsets, int64_t n_reads,
+                             int64_t fixed_len, int k, int canonical, const KmerTable &t, int *overflow,
+                             hipStream_t stream);
+hipError_t launch_kmer_rehash(const KmerTable &src, const KmerTable &dst, int *overflow, hipStream_t stream);
+hipError_t launch_kmer_stats(const KmerTable &t, unsigned long long *stats, hipStream_t stream);
+hipError_t launch_kmer_histogram(const KmerTable &t, unsigned long long *hist, unsigned long long hist_len,
+                                 hipStream_t stream);
+
 } // namespace covest

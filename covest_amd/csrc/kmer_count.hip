@@ -1,0 +1,226 @@
+// kmer_count.hip -- K-kmer: the k-mer abundance histogram of bin/kmer_hist.py on gfx950
+// (BASELINE.json config 5).
+//
+// Reference restated (paths in the reference checkout):
+//   single_hash / hash_kmer / rehash  bin/kmer_hist.py:14-31   a=0 c=1 g=2 t=3, 2 bits per base
+//   compute_counts                    :34-41   exact counts keyed by the 2k-bit integer
+//   compute_histogram                 :57-64   count-of-counts
+// `canonical` (min of the code and its reverse complement's) is the jellyfish -C convention that
+// config 5 asks for; the reference itself is forward-strand only.
+//
+// Shape: one wave64 per read; lane s owns the window starting at base s (then s+64, ...), builds
+// its 2k-bit code from k byte loads (neighbouring lanes overlap: L1-resident) and inserts it into
+// an open-addressing table in HBM: keys u64 (CAS on first touch), counts u32 (atomic add).
+// Bound: HBM random atomics -- one 8-byte CAS/read and one 4-byte add per k-mer in 64 different
+// cache lines per wave instruction (MI355X_MICROARCH.md, Global atomics: the scattered shape runs
+// ~17x below the 1.3 TB/s contiguous-atomic rate); the arithmetic is noise.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "wave.h"
+
+namespace covest {
+
+namespace {
+
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr int kMaxProbe = 1 << 16;
+
+// ASCII base -> 2-bit code for a/c/g/t in either case: bits 2:1 give a=0 c=1 t=2 g=3; x ^ (x>>1) swaps g,t.
+__device__ __forceinline__ unsigned base_code(unsigned char ch)
+{
+    const unsigned x = (ch >> 1) & 3u;
+    return x ^ (x >> 1);
+}
+
+__device__ __forceinline__ unsigned long long slot_of(unsigned long long key, int log2_slots)
+{
+    return (key * 0x9E3779B97F4A7C15ull) >> (64 - log2_slots); // Fibonacci hashing
+}
+
+__device__ __forceinline__ void table_add(const KmerTable t, unsigned long long key, unsigned add,
+                                          int *overflow)
+{
+    unsigned long long h = slot_of(key, t.log2_slots);
+    for (int probe = 0; probe < kMaxProbe; ++probe) {
+        unsigned long long cur = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmptyKey)
+            cur = atomicCAS(&t.keys[h], kEmptyKey, key); // returns the previous value
+        if (cur == kEmptyKey || cur == key) {
+            atomicAdd(&t.counts[h], add);
+            return;
+        }
+        h = (h + 1) & t.mask;
+    }
+    *overflow = 1;
+}
+
+__global__ __launch_bounds__(256) void kmer_count_kernel(const unsigned char *__restrict__ bases,
+                                                         const int64_t *__restrict__ offsets,
+                                                         int64_t n_reads, int64_t fixed_len, int k,
+                                                         int canonical, const KmerTable t, int *overflow)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (r >= n_reads)
+        return;
+    const int64_t p0 = offsets ? offsets[r] : r * fixed_len;
+    const int64_t len = offsets ? offsets[r + 1] - p0 : fixed_len;
+    const unsigned char *seq = bases + p0;
+    if (len < k) {
+        // hash_kmer(seq[:k]) of a read shorter than k: the hash of what there is, counted once;
+        // an empty read counts k-mer 0 (bin/kmer_hist.py:36-37)
+        if (lane == 0) {
+            unsigned long long h = 0, rc = 0;
+            for (int i = 0; i < (int)len; ++i) {
+                const unsigned long long c = base_code(seq[i]);
+                h = (h << 2) | c;
+            }
+            if (canonical) {
+                unsigned long long x = h;
+                for (int i = 0; i < k; ++i) {
+                    rc = (rc << 2) | (3ull - (x & 3ull));
+                    x >>= 2;
+                }
+                h = h < rc ? h : rc;
+            }
+            table_add(t, h, 1u, overflow);
+        }
+        return;
+    }
+    const int64_t n_windows = len - k + 1;
+    for (int64_t s = lane; s < n_windows; s += kWave) {
+        unsigned long long h = 0, rc = 0;
+        for (int i = 0; i < k; ++i) {
+            const unsigned long long c = base_code(seq[s + i]);
+            h = (h << 2) | c;                  // hash_kmer, :18-23 (rehash :26-31 yields the same window code)
+            rc |= (3ull - c) << (2 * i);       // reverse complement, built back to front
+        }
+        if (canonical)
+            h = h < rc ? h : rc;
+        table_add(t, h, 1u, overflow);
+    }
+}
+
+// Re-insert every entry of `src` into the (larger) `dst` table.
+__global__ __launch_bounds__(256) void kmer_rehash_kernel(const KmerTable src, const KmerTable dst, int *overflow)
+{
+    const unsigned long long n = src.mask + 1;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long key = src.keys[i];
+        if (key != kEmptyKey)
+            table_add(dst, key, src.counts[i], overflow);
+    }
+}
+
+__global__ __launch_bounds__(256) void kmer_fill_empty_kernel(unsigned long long *keys, unsigned *counts,
+                                                              unsigned long long n)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        keys[i] = kEmptyKey;
+        counts[i] = 0u;
+    }
+}
+
+// stats[0] = max count, stats[1] = distinct keys
+__global__ __launch_bounds__(256) void kmer_stats_kernel(const KmerTable t, unsigned long long *stats)
+{
+    const unsigned long long n = t.mask + 1;
+    unsigned long long distinct = 0, mx = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        if (t.keys[i] != kEmptyKey) {
+            ++distinct;
+            const unsigned long long c = t.counts[i];
+            mx = c > mx ? c : mx;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        distinct += __shfl_xor(distinct, off, kWave);
+        const unsigned long long o = __shfl_xor(mx, off, kWave);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicMax(&stats[0], mx);
+        atomicAdd(&stats[1], distinct);
+    }
+}
+
+// compute_histogram: hist[c] = number of keys with count c, c < hist_len.  Low counts go through
+// LDS-private bins (one flush of atomics per workgroup), the rare high ones straight to HBM.
+constexpr int kLdsBins = 4096;
+__global__ __launch_bounds__(256) void kmer_histogram_kernel(const KmerTable t, unsigned long long *hist,
+                                                             unsigned long long hist_len)
+{
+    __shared__ unsigned bins[kLdsBins];
+    for (int i = threadIdx.x; i < kLdsBins; i += blockDim.x)
+        bins[i] = 0u;
+    __syncthreads();
+    const unsigned long long n = t.mask + 1;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        if (t.keys[i] != kEmptyKey) {
+            const unsigned long long c = t.counts[i];
+            if (c < (unsigned long long)kLdsBins)
+                atomicAdd(&bins[c], 1u);
+            else if (c < hist_len)
+                atomicAdd(&hist[c], 1ull);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLdsBins; i += blockDim.x)
+        if (bins[i] != 0u && (unsigned long long)i < hist_len)
+            atomicAdd(&hist[i], (unsigned long long)bins[i]);
+}
+
+unsigned grid_for(unsigned long long n, unsigned cap = 256 * 16)
+{
+    const unsigned long long blocks = (n + 255) / 256;
+    return (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+} // namespace
+
+hipError_t launch_kmer_fill_empty(const KmerTable &t, hipStream_t stream)
+{
+    const unsigned long long n = t.mask + 1;
+    hipLaunchKernelGGL(kmer_fill_empty_kernel, dim3(grid_for(n)), dim3(256), 0, stream, t.keys, t.counts, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_kmer_count(const unsigned char *bases, const int64_t *offsets, int64_t n_reads,
+                             int64_t fixed_len, int k, int canonical, const KmerTable &t, int *overflow,
+                             hipStream_t stream)
+{
+    if (n_reads <= 0)
+        return hipSuccess;
+    const int reads_per_block = 4;
+    const dim3 grid((unsigned)((n_reads + reads_per_block - 1) / reads_per_block));
+    hipLaunchKernelGGL(kmer_count_kernel, grid, dim3(reads_per_block * kWave), 0, stream, bases, offsets,
+                       n_reads, fixed_len, k, canonical, t, overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_kmer_rehash(const KmerTable &src, const KmerTable &dst, int *overflow, hipStream_t stream)
+{
+    hipLaunchKernelGGL(kmer_rehash_kernel, dim3(grid_for(src.mask + 1)), dim3(256), 0, stream, src, dst, overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_kmer_stats(const KmerTable &t, unsigned long long *stats, hipStream_t stream)
+{
+    hipLaunchKernelGGL(kmer_stats_kernel, dim3(grid_for(t.mask + 1)), dim3(256), 0, stream, t, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_kmer_histogram(const KmerTable &t, unsigned long long *hist, unsigned long long hist_len,
+                                 hipStream_t stream)
+{
+    hipLaunchKernelGGL(kmer_histogram_kernel, dim3(grid_for(t.mask + 1)), dim3(256), 0, stream, t, hist, hist_len);
+    return hipGetLastError();
+}
+
+} // namespace covest

@@ -152,6 +152,33 @@ int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, con
 int covest_grid_profile(covest_grid *g, int32_t enable);
 int covest_grid_kernel_ms(covest_grid *g, double *total_ms, int64_t *launches);
 
+/* ---- k-mer abundance histogram: bin/kmer_hist.py (BASELINE config 5) ----
+ * The counter is the `counts` dict of compute_counts (bin/kmer_hist.py:34-41) as an
+ * open-addressing hash table in HBM.  k <= 31.  canonical != 0 counts a k-mer and its reverse
+ * complement as one key (jellyfish -C; NOT reference behaviour, the reference is forward-strand). */
+typedef struct covest_kmer covest_kmer; /* opaque */
+
+int covest_kmer_create(int32_t k, int32_t canonical, int64_t min_slots, int32_t device, covest_kmer **out);
+void covest_kmer_destroy(covest_kmer *c);
+/* Grow the table to at least min_slots (power of two), re-inserting what it holds.  The caller
+ * keeps the table at most half full: slots >= 2 * (k-mers added so far + those about to be). */
+int covest_kmer_reserve(covest_kmer *c, int64_t min_slots);
+/* compute_counts(seq, prev_counts=counts, k) for n_reads preprocessed reads (bin/kmer_hist.py:44-54
+ * already applied: only a/c/g/t in either case).  bases: the reads back to back; offsets[n_reads+1].
+ * A read shorter than k contributes the hash of what there is, an empty read k-mer 0 (:36-37).
+ * HOST buffers; the call copies them to the device and waits. */
+int covest_kmer_add(covest_kmer *c, const uint8_t *bases, const int64_t *offsets, int64_t n_reads);
+/* Same with DEVICE buffers, asynchronous on `stream`: d_offsets may be NULL when every read is
+ * read_len bases long. */
+int covest_kmer_add_device(covest_kmer *c, const uint8_t *d_bases, const int64_t *d_offsets,
+                           int64_t n_reads, int64_t read_len, void *stream);
+/* compute_histogram(counts) (bin/kmer_hist.py:57-64): out[i] = number of distinct k-mers seen i
+ * times, i = 0 .. max count.  Call with out == NULL to learn needed_len (= max count + 1) and the
+ * number of distinct k-mers; fails with COVEST_E_NOMEM-like status if the table overflowed. */
+int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t *needed_len,
+                          int64_t *distinct);
+int64_t covest_kmer_slots(const covest_kmer *c);
+
 /* PROFILING AID: with the environment variable COVEST_FACTORED_DIAG set at
  * covest_grid_create, the factored kernel accumulates s_memtime stamps per wave
  * ([workgroup][wave][8] int64: build, contract, log, barrier cycles); this copies

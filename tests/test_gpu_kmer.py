@@ -1,0 +1,87 @@
+"""Parity of the HIP k-mer histogram (through the C ABI) with the reference's
+bin/kmer_hist.py (golden vectors) and with the numpy oracle.  Exact integer equality."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_histograms(hip_lib):
+    from covest_amd import kmer_hist as kh
+    g = load_golden("kmer_hist.json")
+    for c in g["cases"]:
+        if c["k"] > 31:
+            with pytest.raises(Exception):
+                kh.KmerCounts(c["k"])
+            continue
+        # the reference's call pattern: one compute_counts per read into the same counts
+        counts = None
+        for r in c["reads"]:
+            counts = kh.compute_counts(kh.preprocess(r, c["nstrategy"]), prev_counts=counts, k=c["k"])
+        assert kh.compute_histogram(counts) == c["hist"], c["name"]
+        assert len(counts) == c["distinct"], c["name"]
+        # and batched: all reads in one launch, from a deliberately tiny table that has to grow
+        batched = kh.KmerCounts(c["k"], min_slots=1024)
+        batched.add_reads([kh.preprocess(r, c["nstrategy"]) for r in c["reads"]])
+        assert batched.histogram() == c["hist"], c["name"]
+        counts.close()
+        batched.close()
+    for h in g["helpers"]:
+        assert kh.hash_kmer(h["kmer"]) == h["hash"]
+        assert kh.rehash(h["hash"], "a", len(h["kmer"])) == h["rehash_a"]
+        assert kh.rehash(h["hash"], "t", len(h["kmer"])) == h["rehash_t"]
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_random_reads_against_oracle(hip_lib, canonical):
+    from covest_amd import kmer_hist as kh
+    from oracle import kmer_oracle as ko
+    rng = np.random.default_rng(11)
+    genome = "".join(rng.choice(list("ACGT"), size=200_000))
+    reads = []
+    for _ in range(20_000):
+        s = int(rng.integers(0, len(genome) - 100))
+        r = list(genome[s:s + 100])
+        for i in np.flatnonzero(rng.random(100) < 0.01):  # 1 % substitutions
+            r[i] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(r))
+    for k in (21, 31):
+        counts = kh.KmerCounts(k, canonical=canonical)
+        for i in range(0, len(reads), 3000):  # several launches into one table
+            counts.add_reads(reads[i:i + 3000])
+        want = ko.histogram(reads, k, canonical=canonical)
+        assert counts.histogram() == want
+        assert len(counts) == len(ko.count_kmers(reads, k, canonical=canonical)[0])
+        counts.close()
+
+
+def test_edge_cases(hip_lib, tmp_path):
+    from covest_amd import kmer_hist as kh
+    from oracle import kmer_oracle as ko
+    c = kh.KmerCounts(5)
+    assert c.histogram() == [0] and len(c) == 0          # nothing counted yet
+    c.add_reads([])
+    c.add_reads(["", "ac", "ACGTA", "acgta"])            # empty, short, exactly k (twice, case-insensitive)
+    assert c.histogram() == ko.histogram(["", "ac", "ACGTA", "acgta"], 5)
+    with pytest.raises(KeyError):
+        c.add_reads(["acgtx"])                           # single_hash raises KeyError on other letters
+    c.close()
+    # N strategies and the file front-end
+    fa = tmp_path / "reads.fa"
+    fa.write_text(">r1\nACGTNACGTACG\nTTTGACA\n>r2\nNNACGTACGTAC\n")
+    assert kh.main(str(fa), None, 4, kh.NS_IGNORE) == ko.histogram(["ACGTNACGTACGTTTGACA", "NNACGTACGTAC"], 4, 0)
+    out = tmp_path / "out.hist"
+    hist = kh.main(str(fa), str(out), 4, kh.NS_SINGLE)
+    assert hist == ko.histogram(["ACGTNACGTACGTTTGACA", "NNACGTACGTAC"], 4, 1)
+    assert out.read_text().splitlines()[:2] == ["0 0", "1 %d" % hist[1]]
+    fq = tmp_path / "reads.fq"
+    fq.write_text("@a\nACGTACGT\n+\nIIIIIIII\n@b\nTTTTACGT\n+\nIIIIIIII\n")
+    assert kh.main(str(fq), None, 4, kh.NS_IGNORE) == ko.histogram(["ACGTACGT", "TTTTACGT"], 4)
+    # a k-mer seen more often than the LDS-binned range of the histogram kernel
+    c = kh.KmerCounts(3)
+    c.add_reads(["A" * 6000, "ACG"])
+    h = c.histogram()
+    assert len(h) == 5999 and h[5998] == 1 and h[1] == 1 and sum(h) == 2
+    c.close()
