@@ -17,6 +17,7 @@ quoted on (repeat model, 10k-bin histogram):
   c3  RepeatsModel, H10k_rep.hist (10 000 keys), 32x32x16x1x16 grid (c,e,q1,q2=0.5,q)
   c2  BasicModel,   H10k_basic.hist (10 000 keys), 1000x1000 grid (c,e)
   c1  BasicModel,   H256.hist, 50x50 grid (the reference's CPU-runnable case)
+  c5  (next row F1) canonical 21-mer histogram of synthetic reads, --kmer-gbp gigabases
 Weak scaling: with N ranks the c axis has N times as many values over the same
 range and the flat index range is block-partitioned, one contiguous block of the
 single-GPU size per rank.
@@ -154,15 +155,105 @@ def cpu_baseline(kind, hist, axes, budget_s, seed=20240521):
     }
 
 
+def bench_kmer(args):
+    """Workload c5 (BASELINE.json config 5): canonical 21-mer abundance
+    histogram of synthetic 100-bp reads (random genome, 1 % substitutions) resident in HBM.
+    A step = clear the table, count every k-mer (hash + atomics), count-of-counts histogram."""
+    import torch
+    from covest_amd import kmer_hist as kh
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    k, read_len = 21, 100
+    n_reads = int(args.kmer_gbp * 1e9) // read_len
+    genome_len = max(1_000_000, n_reads * read_len // 40)  # 40x coverage
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20240601)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)  # A C G T
+    genome = lut[torch.randint(0, 4, (genome_len,), device=dev, generator=gen)]
+    reads = torch.empty(n_reads * read_len, dtype=torch.uint8, device=dev)
+    ar = torch.arange(read_len, device=dev)
+    chunk = 2_000_000
+    for a in range(0, n_reads, chunk):
+        b = min(n_reads, a + chunk)
+        starts = torch.randint(0, genome_len - read_len, (b - a,), device=dev, generator=gen)
+        r = genome[starts[:, None] + ar[None, :]]
+        err = torch.rand(r.shape, device=dev, generator=gen) < 0.01
+        r = torch.where(err, lut[torch.randint(0, 4, r.shape, device=dev, generator=gen)], r)
+        reads[a * read_len:b * read_len] = r.reshape(-1)
+    del genome
+    n_kmers = n_reads * (read_len - k + 1)
+    # table sized for the distinct k-mers (genome + ~21 new k-mers per substitution), 3x headroom
+    expected_distinct = genome_len + int(0.01 * n_reads * read_len * k)
+    counts = kh.KmerCounts(k, canonical=True, min_slots=3 * expected_distinct)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(timers=None):
+        counts.clear(stream)
+        if timers:
+            timers[0].record()
+        counts.add_device(reads.data_ptr(), n_reads, read_len, stream=stream, reserve=False)
+        if timers:
+            timers[1].record()
+        return counts.histogram()
+
+    for _ in range(args.warmup):
+        hist = step()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        hist = step(evs[i])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_s = 1e-3 * sum(a.elapsed_time(b) for a, b in evs) / args.steps
+    distinct = len(counts)
+    counted = sum(i * v for i, v in enumerate(hist))  # every window lands in exactly one bin
+    if counted != n_kmers or sum(hist) != distinct:
+        raise SystemExit("k-mer histogram inconsistent: %d windows counted, %d expected" % (counted, n_kmers))
+    alg_bytes = 12.0 * n_kmers + 1.0 * n_reads * read_len  # 8 B key slot + 4 B count per k-mer, each base once
+    out = {
+        "metric": "k-mers/s, canonical k=21 abundance histogram (bin/kmer_hist.py path)",
+        "value": n_kmers * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "C5: canonical 21-mers of %d synthetic 100-bp reads (%.2f Gbp, 40x of a random "
+                               "genome, 1%% substitutions), table of %d slots" % (n_reads, n_reads * read_len / 1e9,
+                                                                                 counts.slots),
+                   "kernel": "kmer_count", "distinct_kmers": distinct, "windows_counted": counted,
+                   "hist_head": hist[:6], "hist_peak": int(np.argmax(hist[5:]) + 5) if len(hist) > 6 else None},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "kmer_count_kernel", "kernel_ms_avg": 1e3 * kernel_s,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "scattered 8-byte CAS + 4-byte atomic add per k-mer: the binding rate is the "
+                             "random-atomic rate of the memory side, far below the streaming HBM roof"},
+    }
+    if args.cpu_budget > 0:
+        from oracle import kmer_oracle as ko
+        n_s = 20000
+        sample = [bytes(reads[i * read_len:(i + 1) * read_len].cpu().numpy()).decode() for i in range(n_s)]
+        t0 = time.perf_counter()
+        ko.histogram(sample, k, canonical=True)
+        wall = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n_s * (read_len - k + 1) / wall, "unit": "k-mers/s", "cores": 1,
+                               "kind": "port", "sample": "first %d reads, numpy restatement of bin/kmer_hist.py "
+                               "(oracle/kmer_oracle.py), %.1f s" % (n_s, wall)}
+    print(json.dumps(out), flush=True)
+    counts.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3"])
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--kmer-gbp", type=float, default=1.0, help="c5: gigabases of synthetic reads")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline (0 = skip)")
     args = ap.parse_args()
+    if args.workload == "c5":
+        return bench_kmer(args)
 
     import torch
     import torch.distributed as dist

@@ -26,7 +26,7 @@ EXPORTS = (
     "covest_grid_eval", "covest_grid_argmin", "covest_grid_ll_device", "covest_grid_ll_host",
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
     "covest_kmer_create", "covest_kmer_destroy", "covest_kmer_reserve", "covest_kmer_add",
-    "covest_kmer_add_device", "covest_kmer_histogram", "covest_kmer_slots",
+    "covest_kmer_add_device", "covest_kmer_histogram", "covest_kmer_slots", "covest_kmer_clear",
 )
 
 
@@ -126,6 +126,8 @@ def lib():
     L.covest_kmer_add_device.argtypes = [vp, vp, vp, i64, i64, vp]
     L.covest_kmer_histogram.restype = ctypes.c_int
     L.covest_kmer_histogram.argtypes = [vp, i64p, i64, i64p, i64p]
+    L.covest_kmer_clear.restype = ctypes.c_int
+    L.covest_kmer_clear.argtypes = [vp, vp]
     L.covest_kmer_slots.restype = i64
     L.covest_kmer_slots.argtypes = [vp]
     L.covest_grid_diag.restype = i64

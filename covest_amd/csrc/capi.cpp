@@ -1049,6 +1049,17 @@ void covest_kmer_destroy(covest_kmer *c)
 
 int64_t covest_kmer_slots(const covest_kmer *c) { return c ? (int64_t)(c->table.mask + 1) : COVEST_E_INVALID; }
 
+int covest_kmer_clear(covest_kmer *c, void *stream)
+{
+    if (!c)
+        return fail(COVEST_E_INVALID, "covest_kmer_clear: null counter");
+    std::lock_guard<std::mutex> guard(c->lock);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_kmer_fill_empty(c->table, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipMemsetAsync(c->flag.ptr, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+    return COVEST_OK;
+}
+
 int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
 {
     if (!c)

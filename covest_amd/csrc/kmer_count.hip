@@ -197,10 +197,16 @@ hipError_t launch_kmer_count(const unsigned char *bases, const int64_t *offsets,
 {
     if (n_reads <= 0)
         return hipSuccess;
+    // HIP wraps a grid of more than 2^32 threads silently: at most 2^23 workgroups per launch
     const int reads_per_block = 4;
-    const dim3 grid((unsigned)((n_reads + reads_per_block - 1) / reads_per_block));
-    hipLaunchKernelGGL(kmer_count_kernel, grid, dim3(reads_per_block * kWave), 0, stream, bases, offsets,
-                       n_reads, fixed_len, k, canonical, t, overflow);
+    const int64_t reads_per_launch = (int64_t)reads_per_block << 23;
+    for (int64_t first = 0; first < n_reads; first += reads_per_launch) {
+        const int64_t n = n_reads - first < reads_per_launch ? n_reads - first : reads_per_launch;
+        const dim3 grid((unsigned)((n + reads_per_block - 1) / reads_per_block));
+        hipLaunchKernelGGL(kmer_count_kernel, grid, dim3(reads_per_block * kWave), 0, stream,
+                           offsets ? bases : bases + first * fixed_len, offsets ? offsets + first : nullptr, n,
+                           fixed_len, k, canonical, t, overflow);
+    }
     return hipGetLastError();
 }
 

@@ -123,14 +123,24 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
         return hipSuccess;
     if (m.n_err != 8 || m.kind != 0)
         return hipErrorInvalidValue;
+    // HIP wraps a grid of more than 2^32 threads silently: at most 2^23 workgroups per launch
     const dim3 block(256);
-    const dim3 grid((unsigned)((n + 255) / 256));
-    if (m.tail != 0.0)
-        hipLaunchKernelGGL((ll_basic_kernel<8, true>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base,
-                           tv.int_base, src, n, out_ll);
-    else
-        hipLaunchKernelGGL((ll_basic_kernel<8, false>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base,
-                           tv.int_base, src, n, out_ll);
+    const int64_t per_launch = (int64_t)256 << 23;
+    for (int64_t first = 0; first < n; first += per_launch) {
+        const int64_t cnt = n - first < per_launch ? n - first : per_launch;
+        const dim3 grid((unsigned)((cnt + 255) / 256));
+        PointSource part = src;
+        if (src.is_grid)
+            part.flat_begin = src.flat_begin + first;
+        else
+            part.params = src.params + first * 2;
+        if (m.tail != 0.0)
+            hipLaunchKernelGGL((ll_basic_kernel<8, true>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base,
+                               tv.int_base, part, cnt, out_ll + first);
+        else
+            hipLaunchKernelGGL((ll_basic_kernel<8, false>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base,
+                               tv.int_base, part, cnt, out_ll + first);
+    }
     return hipGetLastError();
 }
 

@@ -155,19 +155,32 @@ hipError_t launch_ll_direct(const DevModel &m, const PointSource &src, int64_t n
 {
     if (n <= 0)
         return hipSuccess;
+    // HIP wraps a grid of more than 2^32 threads silently: at most 2^23 workgroups per launch
     const int waves_per_block = 4;
     const dim3 block(waves_per_block * kWave);
-    const dim3 grid((unsigned)((n + waves_per_block - 1) / waves_per_block));
-    if (m.kind == 0) {
-        if (out_p)
-            hipLaunchKernelGGL((ll_direct_kernel<2, true>), grid, block, 0, stream, m, src, n, out_ll, out_p);
-        else
-            hipLaunchKernelGGL((ll_direct_kernel<2, false>), grid, block, 0, stream, m, src, n, out_ll, out_p);
-    } else {
-        if (out_p)
-            hipLaunchKernelGGL((ll_direct_kernel<5, true>), grid, block, 0, stream, m, src, n, out_ll, out_p);
-        else
-            hipLaunchKernelGGL((ll_direct_kernel<5, false>), grid, block, 0, stream, m, src, n, out_ll, out_p);
+    const int64_t per_launch = (int64_t)waves_per_block << 23;
+    for (int64_t first = 0; first < n; first += per_launch) {
+        const int64_t cnt = n - first < per_launch ? n - first : per_launch;
+        const dim3 grid((unsigned)((cnt + waves_per_block - 1) / waves_per_block));
+        PointSource part = src;
+        if (src.is_grid) {
+            part.flat_begin = src.flat_begin + first;
+        } else {
+            part.params = src.params + first * (m.kind == 0 ? 2 : 5);
+            part.t_list = src.t_list ? src.t_list + first : nullptr;
+        }
+        double *out = out_ll + first;
+        if (m.kind == 0) {
+            if (out_p)
+                hipLaunchKernelGGL((ll_direct_kernel<2, true>), grid, block, 0, stream, m, part, cnt, out, out_p);
+            else
+                hipLaunchKernelGGL((ll_direct_kernel<2, false>), grid, block, 0, stream, m, part, cnt, out, out_p);
+        } else {
+            if (out_p)
+                hipLaunchKernelGGL((ll_direct_kernel<5, true>), grid, block, 0, stream, m, part, cnt, out, out_p);
+            else
+                hipLaunchKernelGGL((ll_direct_kernel<5, false>), grid, block, 0, stream, m, part, cnt, out, out_p);
+        }
     }
     return hipGetLastError();
 }

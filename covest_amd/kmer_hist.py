@@ -117,13 +117,22 @@ class KmerCounts:
             offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(reads)), "covest_kmer_add")
         return self
 
-    def add_device(self, d_bases_ptr, n_reads, read_len, d_offsets_ptr=None, stream=None):
-        """Reads already resident in HBM (raw device pointers); asynchronous on `stream`."""
-        self._reserve_for(int(n_reads) * max(int(read_len) - self.k + 1, 1))
+    def add_device(self, d_bases_ptr, n_reads, read_len, d_offsets_ptr=None, stream=None, reserve=True):
+        """Reads already resident in HBM (raw device pointers); asynchronous on `stream`.
+        reserve=False: the caller sized the table for the DISTINCT k-mers it expects (an
+        overflow is reported by the next histogram call)."""
+        if reserve:
+            self._reserve_for(int(n_reads) * max(int(read_len) - self.k + 1, 1))
         _capi.check(_capi.lib().covest_kmer_add_device(
             self._handle, ctypes.c_void_p(d_bases_ptr), ctypes.c_void_p(d_offsets_ptr or 0),
             int(n_reads), int(read_len), ctypes.c_void_p(stream or 0)), "covest_kmer_add_device")
         return self
+
+    def clear(self, stream=None):
+        """Drop every count but keep the table (a fresh `defaultdict(int)` of the same size)."""
+        self._added = 0
+        _capi.check(_capi.lib().covest_kmer_clear(self._handle, ctypes.c_void_p(stream or 0)),
+                    "covest_kmer_clear")
 
     def stats(self):
         """(max count + 1, distinct k-mers)."""

@@ -178,6 +178,8 @@ int covest_kmer_add_device(covest_kmer *c, const uint8_t *d_bases, const int64_t
 int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t *needed_len,
                           int64_t *distinct);
 int64_t covest_kmer_slots(const covest_kmer *c);
+/* Forget every count (counts = defaultdict(int) again), keeping the table's size; asynchronous on `stream`. */
+int covest_kmer_clear(covest_kmer *c, void *stream);
 
 /* PROFILING AID: with the environment variable COVEST_FACTORED_DIAG set at
  * covest_grid_create, the factored kernel accumulates s_memtime stamps per wave
