@@ -49,7 +49,7 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <int NT, bool TAIL>
+template <int NT, int HU, bool TAIL>
 __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const int32_t n_tiles,
                                                          const double *__restrict__ tile_dbl,
                                                          const int32_t *__restrict__ tile_int,
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 {
     const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
     constexpr int NW = NT / kWave;
+    constexpr int MU = 2 * HU; // unit slots per wave: 0..HU-1 keys 0..15 of the tile, HU..2HU-1 keys 16..31
     const int LD = plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
     __shared__ __attribute__((aligned(16))) double log_tab[64];
@@ -93,13 +94,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int col = lane & 15; // q column inside a tile / key row of the A fragment
     const int kq = lane >> 4;  // which of the 4 o of an MFMA step
     const int n_slots = plan.n_qtiles * 16;
-    int nsteps[kMaxUnits], nfull[kMaxUnits], tq[kMaxUnits], qslot[kMaxUnits];
-    double r4[kMaxUnits], llacc[kMaxUnits];
-    CompSum spacc[kMaxUnits];
+    int nsteps[MU], nfull[MU], tq[MU], qslot[MU];
+    double r4[MU], llacc[MU];
+    CompSum spacc[MU];
     int max_steps = 0;
 #pragma unroll
-    for (int k = 0; k < kMaxUnits; ++k) {
-        const int at = ((int)blockIdx.y * NW + wave) * kMaxUnits + k;
+    for (int k = 0; k < MU; ++k) {
+        const int at = ((int)blockIdx.y * NW + wave) * MU + k;
         const int qt = __builtin_amdgcn_readfirstlane(plan.unit_tile[at]);
         const bool on = qt >= 0;
         const int slot = (on ? qt : 0) * 16 + col;
@@ -184,21 +185,21 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 hrow[u][r] = tv.cnt[(int64_t)t * kTileBins + bin];
                 inrow[u][r] = TAIL ? tv.in_sp[(int64_t)t * kTileBins + bin] != 0.0 : true;
             }
-        d4 acc[kMaxUnits];
-        double wrun[kMaxUnits]; // b_o for o = 5 + kq, advanced by (1-q)^4 per step
+        d4 acc[MU];
+        double wrun[MU]; // b_o for o = 5 + kq, advanced by (1-q)^4 per step
         const double *arow0 = cur + col * LD + kq;
         const double *arow1 = cur + (16 + col) * LD + kq;
         double a0 = arow0[0], a1 = arow1[0];
         // step 0 (o = 1 + kq): weights b_1..b_4 from the host table (L1-resident)
 #pragma unroll
-        for (int k = 0; k < kMaxUnits; ++k) {
+        for (int k = 0; k < MU; ++k) {
             acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
             const int slot = qslot[k] >= 0 ? qslot[k] : col;
             double w = plan.q_first8[(int64_t)kq * n_slots + slot];
             wrun[k] = plan.q_first8[(int64_t)(4 + kq) * n_slots + slot];
             if (nsteps[k] > 0) { // wave-uniform
                 w = (1 + kq < tq[k]) ? w : 0.0;
-                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < kHalfUnits ? a0 : a1, w, acc[k], 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < HU ? a0 : a1, w, acc[k], 0, 0, 0);
             }
         }
         double a0n = arow0[4], a1n = arow1[4]; // software prefetch of the next A fragments
@@ -210,14 +211,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             a1n = arow1[4 * step + 4];
             const int o_here = 1 + 4 * step + kq;
 #pragma unroll
-            for (int k = 0; k < kMaxUnits; ++k) {
+            for (int k = 0; k < MU; ++k) {
                 if (step < nsteps[k]) { // wave-uniform
                     // b_{o+4} = b_o * (1-q)^4 for o >= 3  (models.py:198-206)
                     double w = wrun[k];
                     wrun[k] *= r4[k];
                     if (step >= nfull[k]) // only the last steps of a tile have columns past their T
                         w = (o_here < tq[k]) ? w : 0.0; // o ranges over 1..T-1 (models.py:239)
-                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < kHalfUnits ? a0 : a1, w, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < HU ? a0 : a1, w, acc[k], 0, 0, 0);
                 }
             }
         }
@@ -226,13 +227,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // ================= phase C: h_j * log p_j from the accumulators =================
         // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
-        for (int k = 0; k < kMaxUnits; ++k) {
+        for (int k = 0; k < MU; ++k) {
             if (qslot[k] >= 0 && !(plan.skip_phases & 4)) { // wave-uniform: the unit exists
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double h = hrow[k < kHalfUnits ? 0 : 1][r];
+                    const double h = hrow[k < HU ? 0 : 1][r];
                     const double p = acc[k][r];
-                    if (TAIL && inrow[k < kHalfUnits ? 0 : 1][r])
+                    if (TAIL && inrow[k < HU ? 0 : 1][r])
                         spacc[k].add(p);
                     if (h != 0.0) // filler and padding keys have h == 0
                         llacc[k] += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
@@ -254,11 +255,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 #undef STAMP
     // ---- per-q results: sum the 4 row groups of the accumulator layout, then the two
     //      halves of each q-tile (they may live on different waves) through LDS ----
-    double *part_ll = Gs;                               // [NW][kMaxUnits][16]
-    double *part_hi = Gs + (size_t)NW * kMaxUnits * 16; // compensated sp_j parts
-    double *part_lo = part_hi + (size_t)NW * kMaxUnits * 16;
+    double *part_ll = Gs;                               // [NW][MU][16]
+    double *part_hi = Gs + (size_t)NW * MU * 16; // compensated sp_j parts
+    double *part_lo = part_hi + (size_t)NW * MU * 16;
 #pragma unroll
-    for (int k = 0; k < kMaxUnits; ++k) {
+    for (int k = 0; k < MU; ++k) {
         double ll = llacc[k];
         ll += __shfl_xor(ll, 16, kWave);
         ll += __shfl_xor(ll, 32, kWave);
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
         }
         if (lane < 16) {
-            const int at = (wave * kMaxUnits + k) * 16 + lane;
+            const int at = (wave * MU + k) * 16 + lane;
             part_ll[at] = ll;
             if (TAIL) {
                 part_hi[at] = sp.hi;
@@ -284,18 +285,18 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
     __syncthreads();
     // one thread per (wave, unit, q) entry of a half-0 unit; it looks up the half-1 partner
-    for (int e = tid; e < NW * kMaxUnits * 16; e += NT) {
-        const int w = e / (kMaxUnits * 16), k = (e / 16) % kMaxUnits, c = e & 15;
-        const int at = ((int)blockIdx.y * NW + w) * kMaxUnits + k;
+    for (int e = tid; e < NW * MU * 16; e += NT) {
+        const int w = e / (MU * 16), k = (e / 16) % MU, c = e & 15;
+        const int at = ((int)blockIdx.y * NW + w) * MU + k;
         const int qt = plan.unit_tile[at];
-        if (qt < 0 || k >= kHalfUnits)
+        if (qt < 0 || k >= HU)
             continue;
         int pe = -1; // the unit with the same tile and half 1 (always in the same workgroup)
         for (int w2 = 0; w2 < NW && pe < 0; ++w2)
-            for (int k2 = 0; k2 < kMaxUnits; ++k2) {
-                const int at2 = ((int)blockIdx.y * NW + w2) * kMaxUnits + k2;
-                if (k2 >= kHalfUnits && plan.unit_tile[at2] == qt) {
-                    pe = (w2 * kMaxUnits + k2) * 16 + c;
+            for (int k2 = 0; k2 < MU; ++k2) {
+                const int at2 = ((int)blockIdx.y * NW + w2) * MU + k2;
+                if (k2 >= HU && plan.unit_tile[at2] == qt) {
+                    pe = (w2 * MU + k2) * 16 + c;
                     break;
                 }
             }
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
 }
 
-template <int NT, bool TAIL>
+template <int NT, int HU, bool TAIL>
 hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                           double *out_ll, hipStream_t stream)
 {
@@ -331,24 +332,24 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
     const size_t lds = ((size_t)plan.n_buf * kTileBins * plan.ld + 8) * sizeof(double);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ll_factored_kernel<NT, TAIL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ll_factored_kernel<NT, HU, TAIL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
         configured = lds;
     }
     const dim3 grid((unsigned)(plan.ce_end - plan.ce_begin), (unsigned)plan.n_qblocks);
-    hipLaunchKernelGGL((ll_factored_kernel<NT, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.dbl_base,
+    hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.dbl_base,
                        tv.int_base, plan, out_ll);
     return hipGetLastError();
 }
 
-template <int NT>
+template <int NT, int HU>
 hipError_t launch_nt(const DevModel &m, const TileView &tv, const FactoredPlan &plan, double *out_ll,
                      hipStream_t stream)
 {
-    return m.tail != 0.0 ? launch_nt_tail<NT, true>(m, tv, plan, out_ll, stream)
-                         : launch_nt_tail<NT, false>(m, tv, plan, out_ll, stream);
+    return m.tail != 0.0 ? launch_nt_tail<NT, HU, true>(m, tv, plan, out_ll, stream)
+                         : launch_nt_tail<NT, HU, false>(m, tv, plan, out_ll, stream);
 }
 
 } // namespace
@@ -360,10 +361,10 @@ hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const Facto
         return hipSuccess;
     if (m.n_err != 8 || m.kind != 1 || plan.max_o > plan.n_threads)
         return hipErrorInvalidValue;
-    if (plan.n_threads == 256)
-        return launch_nt<256>(m, tv, plan, out_ll, stream);
-    if (plan.n_threads == 512)
-        return launch_nt<512>(m, tv, plan, out_ll, stream);
+    if (plan.n_threads == 256 && plan.half_units == 3)
+        return launch_nt<256, 3>(m, tv, plan, out_ll, stream);
+    if (plan.n_threads == 512 && plan.half_units == 3)
+        return launch_nt<512, 3>(m, tv, plan, out_ll, stream);
     return hipErrorInvalidValue;
 }
 

@@ -70,7 +70,8 @@ struct FactoredPlan {
     int64_t n_q;                   // Q
     int32_t n_qtiles;              // ceil(Q / 16)
     int32_t max_o;                 // max threshold_o - 1: copy numbers to build
-    int32_t n_threads;             // workgroup size the unit tables were built for (256 or 512)
+    int32_t n_threads;             // workgroup size the unit tables were built for (256, 512 or 768)
+    int32_t half_units;            // unit slots per wave and half (kHalfUnits, or 2 with 768 threads)
     int32_t n_qblocks;             // workgroups per (c, e) (gridDim.y); each rebuilds G
     int32_t ld;                    // G row stride in doubles: roundup32(max_o) + 2 (= 4 dwords mod 64)
     int32_t n_buf;                 // 2: G double-buffered in LDS (build tile t+1 while contracting tile t)
