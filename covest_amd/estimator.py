@@ -1,9 +1,18 @@
-"""CoverageEstimator: the adapter between optimiser space and model space
-(covest/covest.py:18-96), over a GPU-backed model.
+"""CoverageEstimator over a GPU-backed model.
 
-`likelihood_f` keeps the reference contract (apply `fix`, divide x[1] by
-`err_scale`, return -LL) so scipy's L-BFGS-B and `optimize_grid` see the same
-function; `negll_grid` is its batched form used by covest_amd.grid.optimize_grid.
+The reference's estimator (covest/covest.py:18-96) is an adapter between the optimiser's
+parameter space and the model's: optimiser vectors carry the error rate multiplied by
+`err_scale`, and parameters named in `fix` are pinned.  Its contract, kept here:
+
+  likelihood_f(x)      -> -LL(model-space(x))                       covest/covest.py:26-31
+  bounds               -> model bounds with the error-rate upper bound scaled      :22-24
+  compute_coverage(guess, starting_points, use_grid_search, n_threads)
+                       -> (estimate in model space, success flag)   :41-96
+
+What differs is how the likelihood gets evaluated: every call lands on the HIP kernels, and the
+grid search asks for a whole grid at once (`negll_grid`) instead of mapping pickled calls over a
+process pool.  Multi-start refinements run one after the other in-process (each is a stream of
+single-point GPU evaluations; a pool would only add pickling).
 """
 import numpy as np
 
@@ -12,29 +21,41 @@ from .grid import DenseGrid, initial_grid, optimize_grid
 
 
 class CoverageEstimator:
+    ERROR_RATE = 1  # index of the parameter that err_scale applies to
+
     def __init__(self, model, err_scale=1, fix=None):
-        # covest/covest.py:19-24
         self.model = model
         self.fix = fix
         self.err_scale = err_scale
-        self.bounds = list(self.model.bounds)
-        self.bounds[1] = self.bounds[1][0], self.bounds[1][1] * self.err_scale
+        bounds = [tuple(b) for b in model.bounds]
+        lo, hi = bounds[self.ERROR_RATE]
+        bounds[self.ERROR_RATE] = (lo, hi * err_scale)
+        self.bounds = bounds
 
+    # ------------------------------------------------------------------ space mapping
+    def _pinned(self, values):
+        """Optimiser-space values with the fixed parameters substituted."""
+        if self.fix is None:
+            return list(values)
+        return [v if f is None else f for v, f in zip(values, self.fix)]
+
+    def _model_args(self, x):
+        args = self._pinned(x)
+        args[self.ERROR_RATE] = args[self.ERROR_RATE] / self.err_scale
+        return args
+
+    # ------------------------------------------------------------------ objective
     def likelihood_f(self, x):
-        # covest/covest.py:26-31
-        args = list(x)
-        if self.fix is not None:
-            args = [j if self.fix[i] is None else self.fix[i] for i, j in enumerate(args)]
-        args[1] /= self.err_scale
-        return -self.model.compute_loglikelihood(*args)
+        """The scalar objective handed to scipy and to optimize_grid: -LL."""
+        return -self.model.compute_loglikelihood(*self._model_args(x))
 
     def negll_grid(self, axes, kernel="auto"):
-        """-LL over itertools.product(*axes) (optimiser space) in ONE launch:
-        likelihood_f mapped over the grid of covest/grid.py:59-64."""
+        """likelihood_f over itertools.product(*axes) -- the map of covest/grid.py:59-64 -- as ONE
+        dense-grid evaluation.  Returns an ndarray in product order."""
         axes = [list(a) for a in axes]
         if self.fix is not None:
-            axes = [a if self.fix[i] is None else [self.fix[i]] * len(a) for i, a in enumerate(axes)]
-        axes[1] = [v / self.err_scale for v in axes[1]]
+            axes = [a if f is None else [f] * len(a) for a, f in zip(axes, self.fix)]
+        axes[self.ERROR_RATE] = [v / self.err_scale for v in axes[self.ERROR_RATE]]
         grid = DenseGrid(self.model, axes)
         try:
             grid.evaluate(kernel=kernel)
@@ -42,43 +63,37 @@ class CoverageEstimator:
         finally:
             grid.close()
 
-    def _optimize(self, r):
-        # covest/covest.py:33-39 (scalar refinement)
+    # ------------------------------------------------------------------ refinement
+    def _optimize(self, start):
+        """One bounded quasi-Newton refinement with finite-difference gradients, the reference's
+        choice (method and options of covest/covest.py:33-39)."""
         from scipy.optimize import minimize
-        return minimize(
-            self.likelihood_f, r,
-            method=constants.OPTIMIZATION_METHOD,
-            bounds=self.bounds,
-            options={'disp': False}
-        )
+        return minimize(self.likelihood_f, start, method=constants.OPTIMIZATION_METHOD,
+                        bounds=self.bounds, options={'disp': False})
+
+    def _best_of(self, starts):
+        """Refine every start; keep the first result with the strictly smallest objective."""
+        best = None
+        for res in map(self._optimize, starts):
+            if best is None or best.fun > res.fun:
+                best = res
+        return best
 
     def compute_coverage(self, guess, starting_points=1, use_grid_search=False,
                          n_threads=constants.DEFAULT_THREAD_COUNT):
-        # covest/covest.py:41-96; multi-start runs sequentially in-process (each
-        # likelihood call is a GPU launch; a Pool would only add pickling).
-        r = list(guess)
-        r[1] *= self.err_scale
+        x = list(guess)
+        x[self.ERROR_RATE] *= self.err_scale
         success = True
         try:
-            if starting_points == 1:
-                res = self._optimize(r)
-                success = res.success
-                r = res.x
-            elif starting_points > 1:
-                params = initial_grid(r, count=starting_points, bounds=self.bounds, fix=self.fix)
-                min_r = None
-                for res in [self._optimize(p) for p in params]:
-                    if min_r is None or min_r > res.fun:
-                        min_r = res.fun
-                        success = res.success
-                        r = res.x
-            if use_grid_search is None and not success:
-                use_grid_search = True
-            if use_grid_search:
-                r = list(optimize_grid(self.likelihood_f, r, bounds=self.bounds, fix=self.fix,
-                                       n_threads=n_threads))
+            if starting_points >= 1:
+                starts = [x] if starting_points == 1 else initial_grid(
+                    x, count=starting_points, bounds=self.bounds, fix=self.fix)
+                best = self._best_of(starts)
+                x, success = best.x, best.success
+            if use_grid_search or (use_grid_search is None and not success):
+                x = optimize_grid(self.likelihood_f, x, bounds=self.bounds, fix=self.fix, n_threads=n_threads)
         except KeyboardInterrupt:
-            pass
-        r = list(r)
-        r[1] /= self.err_scale
-        return r, success
+            pass  # return the best so far, as the reference does
+        x = list(x)
+        x[self.ERROR_RATE] /= self.err_scale
+        return x, success

@@ -364,3 +364,45 @@ def test_optimize_grid_trace(hip_lib):
         sizes = [int(line.split("Grid size:")[1]) for line in tr["log"] if "Grid size" in line]
         assert [t["grid_size"] for t in optimize_grid.trace] == sizes
         assert list(res) == tr["result"], (tr["model"], res, tr["result"])
+
+
+@pytest.mark.parametrize("seed", list(range(1, 11)))
+def test_fuzz_random_histograms(hip_lib, oracle, seed):
+    """Random histograms (gapped keys, zero counts, huge counts, tail or not) and random points incl.
+    the bound corners: every kernel that accepts the request against the oracle."""
+    from covest_amd import BasicModel, DenseGrid, RepeatsModel
+    rng = np.random.default_rng(seed)
+    n_keys = int(rng.integers(3, 120))
+    keys = np.sort(rng.choice(np.arange(1, 400), size=n_keys, replace=False))
+    counts = rng.integers(0, 10 ** int(rng.integers(1, 10)), size=n_keys)
+    counts[rng.random(n_keys) < 0.2] = 0
+    hist = {int(k): int(v) for k, v in zip(keys, counts)}
+    tail = int(rng.choice([0, 0, 13, 100000]))
+    k = int(rng.choice([15, 21, 31]))
+    r = int(rng.choice([50, 100, 151]))
+    # --- basic model: point list through direct and recur ---
+    m = BasicModel(k, r, hist, tail, max_error=8)
+    om = oracle.OracleModel("basic", k, r, hist, tail, max_error=8)
+    pts = np.column_stack([np.exp(rng.uniform(np.log(0.005), np.log(500), 60)), rng.uniform(-0.05, 0.6, 60)])
+    pts[:4] = [(0.01, 0.0), (0.01, 0.5), (400.0, 0.0), (400.0, 0.5)]
+    ref = om.compute_loglikelihood_many(pts, n_threads=16)
+    slack = _tail_noise(om, pts, ref, tail)
+    for kernel in ("direct", "recur"):
+        _check(m.loglikelihood_points(pts, kernel=kernel), ref, "fuzz basic %s seed %d" % (kernel, seed), slack=slack)
+    # --- repeats model: dense grid through direct and factored, point list through direct ---
+    rm = RepeatsModel(k, r, hist, tail, max_error=8)
+    orm = oracle.OracleModel("repeats", k, r, hist, tail, max_error=8)
+    axes = [np.exp(rng.uniform(np.log(0.5), np.log(60), 3)), rng.uniform(0.0, 0.5, 3), rng.uniform(0.3, 1.0, 4),
+            rng.uniform(0.0, 1.0, 3), np.concatenate([rng.uniform(0.02, 1.0, 4), [0.0, 1.0]])]
+    grid = DenseGrid(rm, axes)
+    gp = np.array([grid.point(i) for i in range(grid.total)])
+    gref = orm.compute_loglikelihood_many(gp, n_threads=16)
+    gslack = _tail_noise(orm, gp, gref, tail)
+    for kernel in ("direct", "factored"):
+        grid.evaluate(kernel=kernel)
+        ll = grid.loglikelihoods()
+        _check(ll, gref, "fuzz repeats %s seed %d" % (kernel, seed), slack=gslack)
+        k_ref, _ = oracle.first_min(-gref)
+        val, arg = grid.argmin()
+        assert arg == k_ref or rel_err(float(ll[arg]), float(gref[k_ref])) <= TOL
+    _check(rm.loglikelihood_points(gp[::7]), gref[::7], "fuzz repeats list seed %d" % seed, slack=gslack[::7])
