@@ -960,22 +960,20 @@ struct covest_kmer {
     int k = 20;
     int canonical = 0;
     KmerTable table{};
-    DevBuf keys, counts, flag, stats, hist, ws_bases, ws_offsets;
+    DevBuf slots, flag, stats, hist, ws_bases, ws_offsets;
     std::mutex lock;
 };
 
 namespace {
 
-int kmer_alloc_table(covest_kmer *c, int64_t min_slots, KmerTable &t, DevBuf &keys, DevBuf &counts)
+int kmer_alloc_table(covest_kmer *c, int64_t min_slots, KmerTable &t, DevBuf &slots)
 {
     int lg = 10;
     while (((int64_t)1 << lg) < min_slots && lg < 40)
         ++lg;
     const size_t n = (size_t)1 << lg;
-    HIP_TRY(keys.reserve(n * sizeof(unsigned long long)));
-    HIP_TRY(counts.reserve(n * sizeof(unsigned)));
-    t.keys = keys.as<unsigned long long>();
-    t.counts = counts.as<unsigned>();
+    HIP_TRY(slots.reserve(n * sizeof(KmerSlot)));
+    t.slots = slots.as<KmerSlot>();
     t.mask = n - 1;
     t.log2_slots = lg;
     HIP_TRY(launch_kmer_fill_empty(t, nullptr));
@@ -1017,7 +1015,7 @@ int covest_kmer_create(int32_t k, int32_t canonical, int64_t min_slots, int32_t 
     hipError_t e = hipSetDevice(device);
     int rc = e == hipSuccess ? COVEST_OK : fail_hip(e, "hipSetDevice");
     if (rc == COVEST_OK)
-        rc = kmer_alloc_table(c, min_slots, c->table, c->keys, c->counts);
+        rc = kmer_alloc_table(c, min_slots, c->table, c->slots);
     if (rc == COVEST_OK) {
         e = c->flag.reserve(sizeof(int));
         if (e == hipSuccess)
@@ -1040,8 +1038,7 @@ void covest_kmer_destroy(covest_kmer *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    c->keys.release();
-    c->counts.release();
+    c->slots.release();
     c->flag.release();
     c->stats.release();
     c->hist.release();
@@ -1072,19 +1069,16 @@ int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
         return COVEST_OK;
     HIP_TRY(hipSetDevice(c->device));
     KmerTable bigger{};
-    DevBuf keys, counts;
-    int rc = kmer_alloc_table(c, min_slots, bigger, keys, counts);
+    DevBuf slots;
+    int rc = kmer_alloc_table(c, min_slots, bigger, slots);
     if (rc != COVEST_OK) {
-        keys.release();
-        counts.release();
+        slots.release();
         return rc;
     }
     HIP_TRY(launch_kmer_rehash(c->table, bigger, c->flag.as<int>(), nullptr));
     HIP_TRY(hipDeviceSynchronize());
-    c->keys.release();
-    c->counts.release();
-    c->keys = keys;
-    c->counts = counts;
+    c->slots.release();
+    c->slots = slots;
     c->table = bigger;
     return kmer_check_overflow(c);
 }

@@ -35,10 +35,15 @@ hipError_t launch_argmin(const double *ll, int64_t n, double *partial_val, int64
                          ArgminResult *result, hipStream_t stream);
 
 // ---- K-kmer: k-mer abundance histogram (kmer_count.hip), SURVEY 8(f) row F1 ----
-// Open-addressing table in HBM: keys[slot] (all-ones = empty), counts[slot]; slots = 2^log2_slots.
+// Open-addressing table in HBM, slots = 2^log2_slots, one 16-byte entry per slot: {key, count}
+// (key all-ones = empty).  Key and count share a cache line on purpose: a k-mer costs ONE scattered
+// line (relaxed load of the key + atomic add on the neighbouring count), not two.
+struct KmerSlot {
+    unsigned long long key;
+    unsigned long long count;
+};
 struct KmerTable {
-    unsigned long long *keys;
-    unsigned *counts;
+    KmerSlot *slots;
     unsigned long long mask;
     int log2_slots;
 };

@@ -10,9 +10,9 @@
 //
 // Shape: one wave64 per read; lane s owns the window starting at base s (then s+64, ...), builds
 // its 2k-bit code from k byte loads (neighbouring lanes overlap: L1-resident) and inserts it into
-// an open-addressing table in HBM: keys u64 (CAS on first touch), counts u32 (atomic add).
-// Bound: HBM random atomics -- one 8-byte CAS/read and one 4-byte add per k-mer in 64 different
-// cache lines per wave instruction (MI355X_MICROARCH.md, Global atomics: the scattered shape runs
+// an open-addressing table in HBM: 16-byte slots {key u64 (CAS on first touch), count u64 (atomic add)}.
+// Bound: HBM random atomics -- one 8-byte read/CAS and one 8-byte add per k-mer, both in the same line, 64
+// different cache lines per wave instruction (MI355X_MICROARCH.md, Global atomics: the scattered shape runs
 // ~17x below the 1.3 TB/s contiguous-atomic rate); the arithmetic is noise.
 #include <hip/hip_runtime.h>
 
@@ -38,16 +38,17 @@ __device__ __forceinline__ unsigned long long slot_of(unsigned long long key, in
     return (key * 0x9E3779B97F4A7C15ull) >> (64 - log2_slots); // Fibonacci hashing
 }
 
-__device__ __forceinline__ void table_add(const KmerTable t, unsigned long long key, unsigned add,
-                                          int *overflow)
+__device__ __forceinline__ void table_add(const KmerTable t, unsigned long long key,
+                                          unsigned long long add, int *overflow)
 {
     unsigned long long h = slot_of(key, t.log2_slots);
     for (int probe = 0; probe < kMaxProbe; ++probe) {
-        unsigned long long cur = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        KmerSlot *slot = t.slots + h;
+        unsigned long long cur = __hip_atomic_load(&slot->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == kEmptyKey)
-            cur = atomicCAS(&t.keys[h], kEmptyKey, key); // returns the previous value
+            cur = atomicCAS(&slot->key, kEmptyKey, key); // returns the previous value
         if (cur == kEmptyKey || cur == key) {
-            atomicAdd(&t.counts[h], add);
+            atomicAdd(&slot->count, add);
             return;
         }
         h = (h + 1) & t.mask;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(const unsigned char *__
                 }
                 h = h < rc ? h : rc;
             }
-            table_add(t, h, 1u, overflow);
+            table_add(t, h, 1ull, overflow);
         }
         return;
     }
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(const unsigned char *__
         }
         if (canonical)
             h = h < rc ? h : rc;
-        table_add(t, h, 1u, overflow);
+        table_add(t, h, 1ull, overflow);
     }
 }
 
@@ -108,20 +109,17 @@ __global__ __launch_bounds__(256) void kmer_rehash_kernel(const KmerTable src, c
     const unsigned long long n = src.mask + 1;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long key = src.keys[i];
-        if (key != kEmptyKey)
-            table_add(dst, key, src.counts[i], overflow);
+        const KmerSlot e = src.slots[i];
+        if (e.key != kEmptyKey)
+            table_add(dst, e.key, e.count, overflow);
     }
 }
 
-__global__ __launch_bounds__(256) void kmer_fill_empty_kernel(unsigned long long *keys, unsigned *counts,
-                                                              unsigned long long n)
+__global__ __launch_bounds__(256) void kmer_fill_empty_kernel(KmerSlot *slots, unsigned long long n)
 {
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (unsigned long long)gridDim.x * blockDim.x) {
-        keys[i] = kEmptyKey;
-        counts[i] = 0u;
-    }
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        slots[i] = KmerSlot{kEmptyKey, 0ull}; // one 16-byte store per lane: coalesced streaming write
 }
 
 // stats[0] = max count, stats[1] = distinct keys
@@ -131,10 +129,10 @@ __global__ __launch_bounds__(256) void kmer_stats_kernel(const KmerTable t, unsi
     unsigned long long distinct = 0, mx = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
-        if (t.keys[i] != kEmptyKey) {
+        const KmerSlot e = t.slots[i];
+        if (e.key != kEmptyKey) {
             ++distinct;
-            const unsigned long long c = t.counts[i];
-            mx = c > mx ? c : mx;
+            mx = e.count > mx ? e.count : mx;
         }
     }
 #pragma unroll
@@ -162,8 +160,9 @@ __global__ __launch_bounds__(256) void kmer_histogram_kernel(const KmerTable t, 
     const unsigned long long n = t.mask + 1;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (unsigned long long)gridDim.x * blockDim.x) {
-        if (t.keys[i] != kEmptyKey) {
-            const unsigned long long c = t.counts[i];
+        const KmerSlot e = t.slots[i];
+        if (e.key != kEmptyKey) {
+            const unsigned long long c = e.count;
             if (c < (unsigned long long)kLdsBins)
                 atomicAdd(&bins[c], 1u);
             else if (c < hist_len)
@@ -187,7 +186,7 @@ unsigned grid_for(unsigned long long n, unsigned cap = 256 * 16)
 hipError_t launch_kmer_fill_empty(const KmerTable &t, hipStream_t stream)
 {
     const unsigned long long n = t.mask + 1;
-    hipLaunchKernelGGL(kmer_fill_empty_kernel, dim3(grid_for(n)), dim3(256), 0, stream, t.keys, t.counts, n);
+    hipLaunchKernelGGL(kmer_fill_empty_kernel, dim3(grid_for(n)), dim3(256), 0, stream, t.slots, n);
     return hipGetLastError();
 }
 

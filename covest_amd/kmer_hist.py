@@ -11,7 +11,7 @@ Differences from the reference, all deliberate and listed in DESIGN.md:
   * `main` passes its `k` on (the reference's main ignores -k and always counts 20-mers, :81);
   * `canonical=True` (jellyfish -C: a k-mer and its reverse complement are one key) is offered
     because BASELINE.json's config 5 asks for it; the default is the reference's forward strand;
-  * k <= 31 (2k bits and an empty marker in one 64-bit word); counts saturate at 2^32 - 1.
+  * k <= 31 (2k bits and an empty marker in one 64-bit word); counts are 64-bit.
 """
 import ctypes
 import random
