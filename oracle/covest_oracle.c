@@ -367,6 +367,134 @@ void oracle_loglikelihood_many(const oracle_model *m, int64_t n, const double *p
     pthread_mutex_destroy(&job.lock);
 }
 
+/* ---------------------------------------------------------------------------
+ * "Fast" CPU mode (CPU baseline row): the same likelihood with the
+ * O(1) log-domain pmf term the GPU's general kernel uses instead of the reference's
+ * O(j) long-double product, so that the reported GPU/CPU ratio can be split into
+ * "better algorithm" and "faster machine".  It reproduces the reference's normaliser
+ * (200-chunk division, x <= 1e-8 branches) like the kernels do; it is NOT bit-faithful
+ * (lgamma rounding: <= 1e-11 relative per term) and is pinned to the faithful mode by
+ * tests/test_oracle_golden.py::test_fast_mode_agrees.  Only zero-count-free work is
+ * skipped when tail == 0, exactly as the HIP library does. */
+static double log_norm_fast(double x, double log_x)
+{
+    if (x <= 1e-8)
+        return log_x;
+    double base = 0.0, xr = x;
+    if (x > 200.0) {
+        double n = ceil(x / 200.0) - 1.0;
+        xr = x - 200.0 * n;
+        if (xr > 200.0) {
+            n += 1.0;
+            xr -= 200.0;
+        } else if (xr <= 0.0) {
+            n -= 1.0;
+            xr += 200.0;
+        }
+        base = 200.0 * n;
+        if (xr <= 1e-8)
+            return base + log_x;
+    }
+    if (xr < 1.0)
+        return base + log(expm1(xr));
+    return base + (xr + log1p(-exp(-xr)));
+}
+
+double oracle_loglikelihood_fast(const oracle_model *m, const double *params)
+{
+    double par[ORACLE_MAX_PARAMS];
+    const int S = m->n_err;
+    clamp_to_bounds(m, oracle_param_count(m), params, par);
+    double l_s[64];
+    error_class_rates(m, par[0], par[1], l_s);
+    int T = 2;
+    if (m->kind == 1)
+        T = oracle_threshold_o(par[2], par[3], par[4], m->threshold, m->has_threshold, largest_key(m));
+    const int n_o = T > 1 ? T - 1 : 0;
+    double *lx = (double *)malloc(sizeof(double) * (size_t)(n_o > 0 ? n_o : 1) * S * 3);
+    double *cc = lx + (size_t)(n_o > 0 ? n_o : 1) * S, *ww = cc + (size_t)(n_o > 0 ? n_o : 1) * S;
+    for (int o = 1; o < T; o++) {
+        double n_os[64], tot = 0.0;
+        for (int s = 0; s < S; s++) {
+            n_os[s] = m->comb[s] * (1.0 - exp(o * -l_s[s]));
+            tot += n_os[s];
+        }
+        if (tot == 0)
+            tot = 1;
+        const double b = m->kind == 1 ? copy_number_weight(par[2], par[3], par[4], o) : 1.0;
+        for (int s = 0; s < S; s++) {
+            const size_t at = (size_t)(o - 1) * S + s;
+            const double x = o * l_s[s];
+            ww[at] = b * (n_os[s] / tot);
+            if (x > 0) {
+                lx[at] = log(x);
+                cc[at] = -log_norm_fast(x, lx[at]);
+            } else {
+                lx[at] = 0.0;
+                cc[at] = -INFINITY;
+            }
+        }
+    }
+    double acc = 0.0, sp = 0.0;
+    for (int64_t b = 0; b < m->n_keys; b++) {
+        const double h = m->counts[b];
+        if (m->tail == 0 && h == 0)
+            continue; /* the tail term is exactly 0: zero-count keys influence nothing */
+        const int j = m->keys[b] > 0 ? m->keys[b] : 0;
+        const double lg = lgamma((double)j + 1.0);
+        double p = 0.0;
+        for (size_t at = 0; at < (size_t)n_o * S; at++)
+            if (ww[at] != 0)
+                p += ww[at] * exp(j * lx[at] + cc[at] - lg);
+        sp += p;
+        if (h != 0)
+            acc += h * safe_log(p);
+    }
+    free(lx);
+    double tail_term = 0;
+    if (!(sp < 1))
+        sp = 1;
+    if (m->tail != 0 && sp < 1)
+        tail_term = m->tail * safe_log(1 - sp);
+    return acc + tail_term;
+}
+
+static void *batch_worker_fast(void *arg)
+{
+    batch_job *job = (batch_job *)arg;
+    for (;;) {
+        pthread_mutex_lock(&job->lock);
+        int64_t i = job->next++;
+        pthread_mutex_unlock(&job->lock);
+        if (i >= job->n)
+            break;
+        job->out[i] = oracle_loglikelihood_fast(job->m, job->params + i * job->n_par);
+    }
+    return NULL;
+}
+
+void oracle_loglikelihood_many_fast(const oracle_model *m, int64_t n, const double *params, double *out,
+                                    int n_threads)
+{
+    batch_job job;
+    job.m = m;
+    job.params = params;
+    job.out = out;
+    job.n = n;
+    job.n_par = oracle_param_count(m);
+    job.next = 0;
+    pthread_mutex_init(&job.lock, NULL);
+    if (n_threads < 1)
+        n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
+    for (int t = 0; t < n_threads; t++)
+        pthread_create(&th[t], NULL, batch_worker_fast, &job);
+    for (int t = 0; t < n_threads; t++)
+        pthread_join(th[t], NULL);
+    free(th);
+    pthread_mutex_destroy(&job.lock);
+}
+
 /* Sequential strict-< arg-min over a value list, as the scan in
  * covest/grid.py:65-70 with maximize=False: lowest index wins ties, NaN never
  * wins, +inf never beats the start value.  Returns -1 if nothing beats start. */

@@ -72,6 +72,8 @@ def lib():
         L.oracle_loglikelihood.argtypes = [P, DP]
         L.oracle_loglikelihood_many.restype = None
         L.oracle_loglikelihood_many.argtypes = [P, ctypes.c_int64, DP, DP, ctypes.c_int]
+        L.oracle_loglikelihood_many_fast.restype = None
+        L.oracle_loglikelihood_many_fast.argtypes = [P, ctypes.c_int64, DP, DP, ctypes.c_int]
         L.oracle_first_min.restype = ctypes.c_int64
         L.oracle_first_min.argtypes = [DP, ctypes.c_int64, ctypes.c_double, DP]
         _lib = L
@@ -151,6 +153,14 @@ class OracleModel:
     def compute_loglikelihood(self, *args):
         par = np.asarray(args[: self.param_count], dtype=np.float64)
         return lib().oracle_loglikelihood(ctypes.byref(self._st), _dp(par))
+
+    def compute_loglikelihood_many_fast(self, points, n_threads=1):
+        """The log-domain 'fast CPU mode' (see covest_oracle.c); for the baseline report only."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, self.param_count)
+        out = np.empty(len(pts), dtype=np.float64)
+        lib().oracle_loglikelihood_many_fast(ctypes.byref(self._st), len(pts), _dp(pts), _dp(out),
+                                             int(n_threads))
+        return out
 
     def compute_loglikelihood_many(self, points, n_threads=1):
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, self.param_count)

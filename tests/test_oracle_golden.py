@@ -119,3 +119,22 @@ def test_first_min_rules(oracle):
     assert oracle.first_min([1.0, -inf, -inf]) == (1, -inf)           # -inf does
     assert oracle.first_min([]) == (-1, inf)
     assert oracle.first_min([5.0, 6.0], start=4.0) == (-1, 4.0)
+
+
+def test_fast_mode_agrees(oracle):
+    """The log-domain CPU mode (reported as a second baseline) against the faithful one."""
+    for kind, fname in (("basic", "basic_ll.json"), ("repeats", "repeats_ll.json")):
+        g = load_golden(fname)
+        for case in g["cases"]:
+            if case["tail"]:
+                continue  # the tail term amplifies the 1e-12 term error near sp_j = 1
+            m = _model(oracle, kind, case)
+            pts = np.array(case["points"])
+            fast = m.compute_loglikelihood_many_fast(pts, n_threads=4)
+            for a, b in zip(fast, case["ll"]):
+                assert rel_err(float(a), b) <= 1e-10
+    g = load_golden("c3_sample.json")
+    m = _model(oracle, "repeats", g)
+    fast = m.compute_loglikelihood_many_fast(np.array(g["points"]), n_threads=8)
+    for a, b in zip(fast, g["ll"]):
+        assert rel_err(float(a), b) <= 1e-10
