@@ -357,6 +357,10 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     const int nw = nt / 64;
     const int cap_block = nw * mu;
     const int n_qblocks = (n_units + cap_block - 1) / cap_block;
+    // cost model of the assignment, in MFMA steps: a unit costs its steps plus its share of the
+    // logs; a builder wave starts with the cost of phase A (tuned on C3 with the in-kernel stamps)
+    const int unit_overhead = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD") ? std::atoi(std::getenv("COVEST_FACTORED_UNIT_OVERHEAD")) : kUnitOverhead;
+    const int build_cost = std::getenv("COVEST_FACTORED_BUILD_COST") ? std::atoi(std::getenv("COVEST_FACTORED_BUILD_COST")) : kBuildCost;
     std::vector<int32_t> unit_tile((size_t)n_qblocks * cap_block, -1);
     for (int blk = 0; blk < n_qblocks; ++blk) {
         struct Unit {
@@ -365,7 +369,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         std::vector<Unit> units;
         for (int qt = blk; qt < n_qtiles; qt += n_qblocks) // tiles are sorted by T: interleave over blocks
             for (int h = 0; h < 2; ++h)
-                units.push_back({qt, h, std::max(1, (int)nsteps[(size_t)qt])});
+                units.push_back({qt, h, std::max(1, (int)nsteps[(size_t)qt]) + unit_overhead});
         std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.cost > b.cost; });
         // longest first into the lightest SIMD (waves w and w + 4 share one) that still has a
         // free slot for the unit's half, then into the lighter of that SIMD's waves with such a slot
@@ -373,8 +377,8 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         std::vector<long> bin_load((size_t)n_bins, 0), wave_load((size_t)nw, 0);
         if (n_buf == 2) // builders contract less: they fill the next key tile in the same interval
             for (int w = 0; w < nw && w * 64 < t_max - 1; ++w) {
-                bin_load[(size_t)(w % n_bins)] += kBuildCost;
-                wave_load[(size_t)w] += kBuildCost;
+                bin_load[(size_t)(w % n_bins)] += build_cost;
+                wave_load[(size_t)w] += build_cost;
             }
         std::vector<int> used((size_t)nw * 2, 0); // [wave][half] slots taken
         for (const Unit &u : units) {

@@ -61,7 +61,8 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, const double *dbl
 // share one), so that the one tile with T ~ 285 does not serialise the workgroup.
 constexpr int kHalfUnits = 3;             // units a wave carries per half of the key tile
 constexpr int kMaxUnits = 2 * kHalfUnits; // slots 0..2: keys 0..15 of the tile, slots 3..5: keys 16..31
-constexpr int kBuildCost = 36;            // phase A of one wave and key tile, in MFMA-step equivalents (measured)
+constexpr int kBuildCost = 26;            // phase A of one wave and key tile, in MFMA-step equivalents (measured)
+constexpr int kUnitOverhead = 0;          // per-unit cost besides its MFMA steps (logs, setup), same unit
 
 struct FactoredPlan {
     const double *c_axis, *e_axis; // device copies of axes 0 and 1
