@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcovest_amd.so")
+LIB_PATH = os.environ.get("COVEST_AMD_LIB", os.path.join(_HERE, "lib", "libcovest_amd.so"))
 
 MAX_PARAMS = 5
 MODEL_BASIC, MODEL_REPEATS = 0, 1
