@@ -274,6 +274,10 @@ def main():
     ap.add_argument("--kmer-gbp", type=float, default=1.0, help="c5: gigabases of synthetic reads")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend (nccl == RCCL; gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: every rank uses device 0 (needs --backend gloo)")
     args = ap.parse_args()
     if args.workload == "c5":
         return bench_kmer(args)
@@ -289,10 +293,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d processes" % (args.gpus, args.gpus))
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    xdev = device if args.backend == "nccl" else None  # where the 16-byte exchange lives
 
     kind, hist_name, axes = workload(args.workload, world)
     hist = load_hist(hist_name)
@@ -310,13 +320,13 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     grid.evaluate(kernel=args.kernel, stream=stream)
     lmin, lidx = grid.argmin()
-    gmin, gidx = distributed_argmin(lmin, lidx, device=device)
+    gmin, gidx = distributed_argmin(lmin, lidx, device=xdev)
     time_to_argmin_first = time.perf_counter() - t0   # includes HIP module load on first use
 
     def step():
         grid.evaluate(kernel=args.kernel, stream=stream)
         lm, li = grid.argmin()
-        return distributed_argmin(lm, li, device=device)
+        return distributed_argmin(lm, li, device=xdev)
 
     for _ in range(args.warmup):
         step()
@@ -327,7 +337,7 @@ def main():
     grid2 = DenseGrid(model2, axes, block)
     grid2.evaluate(kernel=args.kernel, stream=stream)
     lm, li = grid2.argmin()
-    distributed_argmin(lm, li, device=device)
+    distributed_argmin(lm, li, device=xdev)
     time_to_argmin_warm = time.perf_counter() - t0
     grid2.close()
     model2.close()
@@ -344,7 +354,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = grid.kernel_ms()

@@ -37,6 +37,8 @@
 // covest/grid.py:59-64 (the grid map).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "fastmath.h"
 #include "kernels.h"
 #include "point_fetch.h"
@@ -338,9 +340,16 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
             return e;
         configured = lds;
     }
-    const dim3 grid((unsigned)(plan.ce_end - plan.ce_begin), (unsigned)plan.n_qblocks);
-    hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.dbl_base,
-                       tv.int_base, plan, out_ll);
+    // HIP wraps a grid of more than 2^32 threads silently: at most 2^22 workgroups per launch
+    const int64_t per_launch = std::max<int64_t>(1, ((int64_t)1 << 22) / plan.n_qblocks);
+    for (int64_t first = plan.ce_begin; first < plan.ce_end; first += per_launch) {
+        FactoredPlan part = plan;
+        part.ce_begin = first;
+        part.ce_end = std::min(plan.ce_end, first + per_launch);
+        const dim3 grid((unsigned)(part.ce_end - part.ce_begin), (unsigned)plan.n_qblocks);
+        hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles,
+                           tv.dbl_base, tv.int_base, part, out_ll);
+    }
     return hipGetLastError();
 }
 
