@@ -332,13 +332,17 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
 {
     // + 8 doubles: the A-fragment prefetch of phase B reads one MFMA step past the last row's end
     const size_t lds = ((size_t)plan.n_buf * kTileBins * plan.ld + 8) * sizeof(double);
-    static size_t configured = 0;
-    if (lds > configured) {
+    // the dynamic-LDS ceiling is a per-device attribute of the kernel: raise it once per device
+    static size_t configured[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        dev = 0;
+    if (lds > configured[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ll_factored_kernel<NT, HU, TAIL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
-        configured = lds;
+        configured[dev] = lds;
     }
     // HIP wraps a grid of more than 2^32 threads silently: at most 2^22 workgroups per launch
     const int64_t per_launch = std::max<int64_t>(1, ((int64_t)1 << 22) / plan.n_qblocks);

@@ -115,7 +115,7 @@ int covest_probabilities(covest_model *m, const double *params, int32_t clamp, d
  * fixed parameter is an axis of length 1 (covest/grid.py:27-28).  The handle
  * evaluates flat indices [flat_begin, flat_end) of the product -- one contiguous
  * block per GPU (multi-GPU block partition); pass 0 and -1 for the whole grid.
- * Axes are copied to the device here. */
+ * Axes are copied to the device here.  A grid borrows its model: destroy the grid first. */
 int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axes,
                        const int64_t *axis_len, int64_t flat_begin, int64_t flat_end,
                        covest_grid **out);
