@@ -349,7 +349,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         nfull[(size_t)n_qtiles - 1] = 0; // padding columns (T = 0) are cut off from the first step
     // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
     const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 8) * sizeof(double) + 1024 <= 160 * 1024 ? 2 : 1;
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 1024 <= 160 * 1024 ? 2 : 1;
     const int n_units = 2 * n_qtiles;
     const int nt = (t_max - 1 <= 256 && n_units <= 4 * kMaxUnits) ? 256 : 512;
     const int hu = kHalfUnits; // (768 threads with 2 slots per half, 3 waves/SIMD, was measured: +1 %)
@@ -361,18 +361,20 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     // logs; a builder wave starts with the cost of phase A (tuned on C3 with the in-kernel stamps)
     const int unit_overhead = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD") ? std::atoi(std::getenv("COVEST_FACTORED_UNIT_OVERHEAD")) : kUnitOverhead;
     const int build_cost = std::getenv("COVEST_FACTORED_BUILD_COST") ? std::atoi(std::getenv("COVEST_FACTORED_BUILD_COST")) : kBuildCost;
-    std::vector<int32_t> unit_tile((size_t)n_qblocks * cap_block, -1);
+    const size_t n_unit = (size_t)n_qblocks * cap_block;
+    std::vector<int32_t> unit_tile(n_unit, -1), unit_half(n_unit, 0), unit_s0(n_unit, 0), unit_len(n_unit, 0),
+        unit_cont(n_unit, 0);
     for (int blk = 0; blk < n_qblocks; ++blk) {
         struct Unit {
-            int tile, half, cost;
+            int tile, half, cost, pieces;
         };
         std::vector<Unit> units;
         for (int qt = blk; qt < n_qtiles; qt += n_qblocks) // tiles are sorted by T: interleave over blocks
             for (int h = 0; h < 2; ++h)
-                units.push_back({qt, h, std::max(1, (int)nsteps[(size_t)qt]) + unit_overhead});
+                units.push_back({qt, h, std::max(1, (int)nsteps[(size_t)qt]) + unit_overhead, 1});
         std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.cost > b.cost; });
-        // longest first into the lightest SIMD (waves w and w + 4 share one) that still has a
-        // free slot for the unit's half, then into the lighter of that SIMD's waves with such a slot
+        // longest first into the lightest SIMD (waves w and w + 4 share one) that still has a free
+        // slot, then into the lighter of that SIMD's waves with one
         const int n_bins = std::min(4, nw);
         std::vector<long> bin_load((size_t)n_bins, 0), wave_load((size_t)nw, 0);
         if (n_buf == 2) // builders contract less: they fill the next key tile in the same interval
@@ -380,11 +382,11 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
                 bin_load[(size_t)(w % n_bins)] += build_cost;
                 wave_load[(size_t)w] += build_cost;
             }
-        std::vector<int> used((size_t)nw * 2, 0); // [wave][half] slots taken
+        std::vector<std::vector<Unit>> held((size_t)nw);
         for (const Unit &u : units) {
             int best_wave = -1;
             for (int w = 0; w < nw; ++w) {
-                if (used[(size_t)w * 2 + u.half] >= hu)
+                if ((int)held[(size_t)w].size() >= mu)
                     continue;
                 if (best_wave < 0) {
                     best_wave = w;
@@ -394,18 +396,63 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
                 if (lb < bb || (lb == bb && wave_load[(size_t)w] < wave_load[(size_t)best_wave]))
                     best_wave = w;
             }
-            const size_t at = ((size_t)blk * nw + best_wave) * mu + (size_t)u.half * hu +
-                              (size_t)used[(size_t)best_wave * 2 + u.half];
-            unit_tile[at] = u.tile;
-            used[(size_t)best_wave * 2 + u.half]++;
+            held[(size_t)best_wave].push_back(u);
             bin_load[(size_t)(best_wave % n_bins)] += u.cost;
             wave_load[(size_t)best_wave] += u.cost;
         }
+        for (int w = 0; w < nw; ++w) {
+            std::vector<Unit> &mine = held[(size_t)w];
+            // cut the unit with the longest pieces once more while slots are free (tiles.h)
+            auto piece_len = [&](const Unit &u) { return ((int)nsteps[(size_t)u.tile] + u.pieces - 1) / u.pieces; };
+            int used = (int)mine.size();
+            while (used < mu && !mine.empty()) {
+                size_t longest = 0;
+                for (size_t i = 1; i < mine.size(); ++i)
+                    if (piece_len(mine[i]) > piece_len(mine[longest]))
+                        longest = i;
+                Unit trial = mine[longest];
+                trial.pieces += 1;
+                if (piece_len(trial) < kMinPieceSteps)
+                    break;
+                mine[longest].pieces += 1;
+                ++used;
+            }
+            // slots sorted by piece length (descending), the pieces of a unit adjacent
+            std::stable_sort(mine.begin(), mine.end(),
+                             [&](const Unit &a, const Unit &b) { return piece_len(a) > piece_len(b); });
+            size_t k = 0;
+            for (const Unit &u : mine)
+                for (int p = 0; p < u.pieces; ++p, ++k) {
+                    const size_t at = ((size_t)blk * nw + w) * mu + k;
+                    unit_tile[at] = u.tile;
+                    unit_half[at] = u.half;
+                    unit_s0[at] = p * piece_len(u);
+                    unit_len[at] = piece_len(u); // equal lengths: steps past the unit's end are cut off by T
+                    unit_cont[at] = p > 0;
+                }
+        }
+    }
+    // weights of every slot's first two MFMA steps, per lane (lane = 16 * (o mod 4) + column)
+    std::vector<double> piece_w(n_unit * 2 * 64, 0.0);
+    for (size_t at = 0; at < n_unit; ++at) {
+        const int qt = unit_tile[at];
+        if (qt < 0)
+            continue;
+        for (int which = 0; which < 2; ++which)
+            for (int lane = 0; lane < 64; ++lane) {
+                const size_t slot = (size_t)qt * 16 + (size_t)(lane & 15);
+                if (slot >= (size_t)nq)
+                    continue; // padding column
+                const int64_t qi = order[slot];
+                const int64_t a = qi / (n2 * n3), b = (qi / n3) % n2, c = qi % n3;
+                const int o = 1 + 4 * (unit_s0[at] + which) + (lane >> 4);
+                piece_w[(at * 2 + (size_t)which) * 64 + (size_t)lane] = copy_number_weight_host(
+                    clamp_one(m->dm, 2, axes[2][a]), clamp_one(m->dm, 3, axes[3][b]), clamp_one(m->dm, 4, axes[4][c]), o);
+            }
     }
     // one buffer: doubles first (first8 | r4), then int32 (nsteps | q_T | q_orig | unit_tile | nfull)
-    const size_t n_dbl = 9 * n_slots;
-    const size_t n_unit = unit_tile.size();
-    const size_t n_int = 2 * (size_t)n_qtiles + 2 * n_slots + n_unit;
+    const size_t n_dbl = 9 * n_slots + piece_w.size();
+    const size_t n_int = 2 * (size_t)n_qtiles + 2 * n_slots + 5 * n_unit;
     HIP_TRY(g->plan_buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
     double *dbase = g->plan_buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
@@ -416,6 +463,12 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     HIP_TRY(hipMemcpy(ibase + n_qtiles + n_slots, q_orig.data(), n_slots * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ibase + n_qtiles + 2 * n_slots, unit_tile.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ibase + n_qtiles + 2 * n_slots + n_unit, nfull.data(), (size_t)n_qtiles * sizeof(int32_t), hipMemcpyHostToDevice));
+    int32_t *piece_base = ibase + 2 * n_qtiles + 2 * n_slots + n_unit;
+    HIP_TRY(hipMemcpy(piece_base, unit_half.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(piece_base + n_unit, unit_s0.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(piece_base + 2 * n_unit, unit_len.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(piece_base + 3 * n_unit, unit_cont.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dbase + 9 * n_slots, piece_w.data(), piece_w.size() * sizeof(double), hipMemcpyHostToDevice));
     FactoredPlan &pl = g->plan;
     pl.c_axis = g->src.axis[0];
     pl.e_axis = g->src.axis[1];
@@ -432,6 +485,11 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     pl.n_buf = std::getenv("COVEST_FACTORED_NBUF") ? std::atoi(std::getenv("COVEST_FACTORED_NBUF")) : n_buf;
     pl.unit_tile = ibase + n_qtiles + 2 * n_slots;
     pl.qtile_nfull = ibase + n_qtiles + 2 * n_slots + n_unit;
+    pl.unit_half = piece_base;
+    pl.unit_s0 = piece_base + n_unit;
+    pl.unit_len = piece_base + 2 * n_unit;
+    pl.unit_cont = piece_base + 3 * n_unit;
+    pl.piece_w = dbase + 9 * n_slots;
     pl.q_first8 = dbase;
     pl.q_r4 = dbase + 8 * n_slots;
     pl.qtile_nsteps = ibase;

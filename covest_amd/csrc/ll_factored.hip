@@ -51,6 +51,26 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// One MFMA step of the first N accumulator slots of a wave (they are sorted by length, so the active
+// slots are always a prefix): all A fragments first -- N independent LDS reads in flight -- then per
+// slot the weight b_o (advanced by (1-q)^4, cut off at o >= T: models.py:198-206,239) and the MFMA.
+// Straight-line code: no per-slot branch separates the reads from their MFMAs.
+template <int N, int MU>
+__device__ __forceinline__ void contract_step(int i, const double *cur, const int (&a_off)[MU], const int (&cut)[MU],
+                                              const double (&r4)[MU], double (&wrun)[MU], d4 (&acc)[MU])
+{
+    double a[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        a[k] = cur[a_off[k] + 4 * i];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double w = (i < cut[k]) ? wrun[k] : 0.0; // this lane's o has reached T: models.py:239
+        wrun[k] *= r4[k];
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], w, acc[k], 0, 0, 0);
+    }
+}
+
 template <int NT, int HU, bool TAIL>
 __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const int32_t n_tiles,
                                                          const double *__restrict__ tile_dbl,
@@ -60,7 +80,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 {
     const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
     constexpr int NW = NT / kWave;
-    constexpr int MU = 2 * HU; // unit slots per wave: 0..HU-1 keys 0..15 of the tile, HU..2HU-1 keys 16..31
+    constexpr int MU = 2 * HU; // accumulator slots per wave (6: the specialised step loops below assume it)
+    static_assert(MU == 6, "contract loops are written for 6 slots");
     const int LD = plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
     __shared__ __attribute__((aligned(16))) double log_tab[64];
@@ -91,30 +112,40 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     StreamSet<8> st;
     st.init(m, lam, tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o);
     const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
+    if (tid < 64)
+        Gs[(size_t)plan.n_buf * kTileBins * LD + tid] = 0.0; // the slack behind the buffers (see launch)
+    // the two pad columns of every row are read by masked steps too: keep them finite
+    if (tid < plan.n_buf * kTileBins) {
+        Gs[(size_t)tid * LD + LD - 2] = 0.0;
+        Gs[(size_t)tid * LD + LD - 1] = 0.0;
+    }
 
     // ---- phase-B/C state: this wave's (q-tile, half) units ----
     const int col = lane & 15; // q column inside a tile / key row of the A fragment
     const int kq = lane >> 4;  // which of the 4 o of an MFMA step
-    const int n_slots = plan.n_qtiles * 16;
-    int nsteps[MU], nfull[MU], tq[MU], qslot[MU];
+    int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU];
     double r4[MU], llacc[MU];
     CompSum spacc[MU];
-    int max_steps = 0;
+    const int slot_base = ((int)blockIdx.y * NW + wave) * MU;
 #pragma unroll
     for (int k = 0; k < MU; ++k) {
-        const int at = ((int)blockIdx.y * NW + wave) * MU + k;
+        const int at = slot_base + k;
         const int qt = __builtin_amdgcn_readfirstlane(plan.unit_tile[at]);
         const bool on = qt >= 0;
         const int slot = (on ? qt : 0) * 16 + col;
+        const int first_step = __builtin_amdgcn_readfirstlane(on ? plan.unit_s0[at] : 0);
         qslot[k] = on ? slot : -1;
-        nsteps[k] = __builtin_amdgcn_readfirstlane(on ? plan.qtile_nsteps[qt] : 0);
-        nfull[k] = __builtin_amdgcn_readfirstlane(on ? plan.qtile_nfull[qt] : 0);
-        tq[k] = on ? plan.q_T[slot] : 0;
+        len[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_len[at] : 0);
+        cont[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_cont[at] : 0);
+        uhalf[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_half[at] : 0);
+        a_off[k] = (16 * uhalf[k] + col) * LD + kq + 4 * first_step; // this lane's A fragment inside a G buffer
+        // iterations of the piece during which this lane's o = 1 + 4 (first_step + i) + kq is below T
+        const int t_lane = on ? plan.q_T[slot] : 0;
+        cut[k] = (t_lane - (1 + 4 * first_step + kq) + 3) >> 2;
         r4[k] = plan.q_r4[slot];
         llacc[k] = 0.0;
         spacc[k].hi = 0.0;
         spacc[k].lo = 0.0;
-        max_steps = max(max_steps, nsteps[k]);
     }
 
     // ================= phase A: G[key][o] of key tile t into `dst` =================
@@ -145,7 +176,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     };
 
     // in-kernel stamps (diagnostic runs only): cycles per wave in build / contract / log / barrier
-    long long dg_a = 0, dg_b = 0, dg_c = 0, dg_w = 0, dg_t0 = 0;
+    long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0;
     const bool diag = plan.diag != nullptr;
 #define STAMP(acc)                                    \
     if (diag) {                                       \
@@ -188,54 +219,54 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 inrow[u][r] = TAIL ? tv.in_sp[(int64_t)t * kTileBins + bin] != 0.0 : true;
             }
         d4 acc[MU];
-        double wrun[MU]; // b_o for o = 5 + kq, advanced by (1-q)^4 per step
-        const double *arow0 = cur + col * LD + kq;
-        const double *arow1 = cur + (16 + col) * LD + kq;
-        double a0 = arow0[0], a1 = arow1[0];
-        // step 0 (o = 1 + kq): weights b_1..b_4 from the host table (L1-resident)
+        double wrun[MU]; // b_o of the piece's second step, then advanced by (1-q)^4 per step
+        // the piece's first step: weight from the host table (L2-resident)
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
             acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
-            const int slot = qslot[k] >= 0 ? qslot[k] : col;
-            double w = plan.q_first8[(int64_t)kq * n_slots + slot];
-            wrun[k] = plan.q_first8[(int64_t)(4 + kq) * n_slots + slot];
-            if (nsteps[k] > 0) { // wave-uniform
-                w = (1 + kq < tq[k]) ? w : 0.0;
-                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < HU ? a0 : a1, w, acc[k], 0, 0, 0);
+            const double *pw = plan.piece_w + ((int64_t)(slot_base + k) * 2) * kWave + lane;
+            double w = pw[0];
+            wrun[k] = pw[kWave];
+            if (len[k] > 0) { // wave-uniform
+                w = (0 < cut[k]) ? w : 0.0;
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[a_off[k]], w, acc[k], 0, 0, 0);
             }
         }
-        double a0n = arow0[4], a1n = arow1[4]; // software prefetch of the next A fragments
-        const int steps_run = (plan.skip_phases & 2) ? 0 : max_steps;
-        for (int step = 1; step < steps_run; ++step) {
-            a0 = a0n;
-            a1 = a1n;
-            a0n = arow0[4 * step + 4]; // one step past the end stays inside the row (LD = NT + 2)
-            a1n = arow1[4 * step + 4];
-            const int o_here = 1 + 4 * step + kq;
+        STAMP(dg_b0)
+        // the remaining steps, specialised on the number of slots still running (len is sorted)
+        if (!(plan.skip_phases & 2)) {
+            int i = 1;
+            for (; i < len[5]; ++i)
+                contract_step<6, MU>(i, cur, a_off, cut, r4, wrun, acc);
+            for (; i < len[4]; ++i)
+                contract_step<5, MU>(i, cur, a_off, cut, r4, wrun, acc);
+            for (; i < len[3]; ++i)
+                contract_step<4, MU>(i, cur, a_off, cut, r4, wrun, acc);
+            for (; i < len[2]; ++i)
+                contract_step<3, MU>(i, cur, a_off, cut, r4, wrun, acc);
+            for (; i < len[1]; ++i)
+                contract_step<2, MU>(i, cur, a_off, cut, r4, wrun, acc);
+            for (; i < len[0]; ++i)
+                contract_step<1, MU>(i, cur, a_off, cut, r4, wrun, acc);
+        }
+        // pieces of one unit: add the accumulators into the unit's first slot
 #pragma unroll
-            for (int k = 0; k < MU; ++k) {
-                if (step < nsteps[k]) { // wave-uniform
-                    // b_{o+4} = b_o * (1-q)^4 for o >= 3  (models.py:198-206)
-                    double w = wrun[k];
-                    wrun[k] *= r4[k];
-                    if (step >= nfull[k]) // only the last steps of a tile have columns past their T
-                        w = (o_here < tq[k]) ? w : 0.0; // o ranges over 1..T-1 (models.py:239)
-                    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(k < HU ? a0 : a1, w, acc[k], 0, 0, 0);
-                }
-            }
-        }
+        for (int k = MU - 1; k >= 1; --k)
+            if (cont[k]) // wave-uniform
+                acc[k - 1] += acc[k];
 
         STAMP(dg_b)
         // ================= phase C: h_j * log p_j from the accumulators =================
         // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
-            if (qslot[k] >= 0 && !(plan.skip_phases & 4)) { // wave-uniform: the unit exists
+            if (qslot[k] >= 0 && !cont[k] && !(plan.skip_phases & 4)) { // wave-uniform: first slot of a unit
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double h = hrow[k < HU ? 0 : 1][r];
+                    const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
+                    const bool in_sp = uhalf[k] ? inrow[1][r] : inrow[0][r];
                     const double p = acc[k][r];
-                    if (TAIL && inrow[k < HU ? 0 : 1][r])
+                    if (TAIL && in_sp)
                         spacc[k].add(p);
                     if (h != 0.0) // filler and padding keys have h == 0
                         llacc[k] += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
@@ -253,6 +284,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         d[1] = dg_b;
         d[2] = dg_c;
         d[3] = dg_w;
+        d[4] = dg_b0;
     }
 #undef STAMP
     // ---- per-q results: sum the 4 row groups of the accumulator layout, then the two
@@ -291,13 +323,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const int w = e / (MU * 16), k = (e / 16) % MU, c = e & 15;
         const int at = ((int)blockIdx.y * NW + w) * MU + k;
         const int qt = plan.unit_tile[at];
-        if (qt < 0 || k >= HU)
+        if (qt < 0 || plan.unit_half[at] != 0 || plan.unit_cont[at])
             continue;
         int pe = -1; // the unit with the same tile and half 1 (always in the same workgroup)
         for (int w2 = 0; w2 < NW && pe < 0; ++w2)
             for (int k2 = 0; k2 < MU; ++k2) {
                 const int at2 = ((int)blockIdx.y * NW + w2) * MU + k2;
-                if (k2 >= HU && plan.unit_tile[at2] == qt) {
+                if (plan.unit_tile[at2] == qt && plan.unit_half[at2] == 1 && !plan.unit_cont[at2]) {
                     pe = (w2 * MU + k2) * 16 + c;
                     break;
                 }
@@ -330,8 +362,9 @@ template <int NT, int HU, bool TAIL>
 hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                           double *out_ll, hipStream_t stream)
 {
-    // + 8 doubles: the A-fragment prefetch of phase B reads one MFMA step past the last row's end
-    const size_t lds = ((size_t)plan.n_buf * kTileBins * plan.ld + 8) * sizeof(double);
+    // + 64 zeroed doubles: the last piece of a unit may run a few (masked, weight 0) steps past the end
+    // of a G row; what it reads there must be finite
+    const size_t lds = ((size_t)plan.n_buf * kTileBins * plan.ld + 64) * sizeof(double);
     // the dynamic-LDS ceiling is a per-device attribute of the kernel: raise it once per device
     static size_t configured[64] = {0};
     int dev = 0;

@@ -56,13 +56,19 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, const double *dbl
 // for a dense repeats-model grid.  The Q = |q1| x |q2| x |q| weight vectors are
 // sorted by threshold_o (descending) into "slots", 16 per q-tile.  The unit of
 // matrix work is (q-tile, half) -- 16 weight vectors x 16 of a tile's 32 keys --
-// costing ceil((T-1)/4) MFMAs per key tile; units are dealt to the waves of a
-// workgroup by longest-processing-time first, balanced per SIMD (waves w and w+4
-// share one), so that the one tile with T ~ 285 does not serialise the workgroup.
-constexpr int kHalfUnits = 3;             // units a wave carries per half of the key tile
-constexpr int kMaxUnits = 2 * kHalfUnits; // slots 0..2: keys 0..15 of the tile, slots 3..5: keys 16..31
-constexpr int kBuildCost = 26;            // phase A of one wave and key tile, in MFMA-step equivalents (measured)
-constexpr int kUnitOverhead = 0;          // per-unit cost besides its MFMA steps (logs, setup), same unit
+// costing ceil((T-1)/4) MFMAs per key tile.  Units are dealt to the waves of a
+// workgroup longest-first, balanced per SIMD (waves w and w+4 share one); a wave
+// with free accumulator slots cuts its longest units into equal PIECES (disjoint
+// ranges of MFMA steps) that run concurrently in adjacent slots and are added before
+// the logs: a single dependent chain of MFMAs with its LDS read and weight update
+// keeps the fp64 pipe busy only a third of the time.  A wave's slots are sorted by
+// length, so the active ones are always a prefix and the step loop is specialised
+// on their number (no per-slot branches inside it).
+constexpr int kMaxUnits = 6;       // accumulator slots per wave
+constexpr int kHalfUnits = 3;      // (kept for the 256-thread capacity rule: 4 waves x 6 slots)
+constexpr int kBuildCost = 26;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3)
+constexpr int kMinPieceSteps = 6;  // pieces are not made shorter than this
+constexpr int kUnitOverhead = 0;   // per-unit cost besides its MFMA steps (logs, setup), same unit
 
 struct FactoredPlan {
     const double *c_axis, *e_axis; // device copies of axes 0 and 1
@@ -76,8 +82,15 @@ struct FactoredPlan {
     int32_t n_qblocks;             // workgroups per (c, e) (gridDim.y); each rebuilds G
     int32_t ld;                    // G row stride in doubles: roundup32(max_o) + 2 (= 4 dwords mod 64)
     int32_t n_buf;                 // 2: G double-buffered in LDS (build tile t+1 while contracting tile t)
-    const int32_t *unit_tile;      // [n_qblocks][n_threads/64][kMaxUnits] q-tile of the unit, -1 = none;
-                                   //   the slot index gives the half (see kHalfUnits)
+    // per accumulator slot, [n_qblocks][n_threads/64][kMaxUnits], sorted by length within a wave:
+    const int32_t *unit_tile;      // q-tile of the slot, -1 = none
+    const int32_t *unit_half;      // 0 = keys 0..15 of the key tile, 1 = keys 16..31
+    const int32_t *unit_s0;        // first MFMA step of the slot's piece
+    const int32_t *unit_len;       // steps of the piece (equal for all pieces of a unit; steps past the
+                                   //   unit's end are masked by the T cut-off)
+    const int32_t *unit_cont;      // 1 = this slot continues the unit of the slot before it
+    const double *piece_w;         // [slots][2][64 lanes] b_o at the piece's first and second step
+                                   //   (o = 1 + 4 step + lane/16, column lane%16), libm pow on the host
     const int32_t *qtile_nsteps;   // [n_qtiles] ceil((max T in tile - 1) / 4): MFMA steps of the tile
     const int32_t *qtile_nfull;    // [n_qtiles] floor((min T in tile - 1) / 4): steps with no column cut off
     const int32_t *q_T;            // [n_qtiles*16] threshold_o per slot (0 = padding)
