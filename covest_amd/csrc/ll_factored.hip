@@ -148,6 +148,20 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         spacc[k].lo = 0.0;
     }
 
+    // b_o of every slot's first (wfirst) and second (wrun, then advanced by (1-q)^4 per step) MFMA step:
+    // an L2-resident host table.  The loads for tile t+1 are issued between tile t's MFMAs and its
+    // logs, so their latency (2-3 us per tile when exposed) hides behind the logs and the barrier.
+    double wfirst[MU], wrun[MU];
+    auto load_weights = [&]() {
+#pragma unroll
+        for (int k = 0; k < MU; ++k) {
+            const double *pw = plan.piece_w + ((int64_t)(slot_base + k) * 2) * kWave + lane;
+            wfirst[k] = pw[0];
+            wrun[k] = pw[kWave];
+        }
+    };
+    load_weights();
+
     // ================= phase A: G[key][o] of key tile t into `dst` =================
     auto build_tile = [&](int t, double *dst) {
         if (plan.skip_phases & 1)
@@ -219,16 +233,12 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 inrow[u][r] = TAIL ? tv.in_sp[(int64_t)t * kTileBins + bin] != 0.0 : true;
             }
         d4 acc[MU];
-        double wrun[MU]; // b_o of the piece's second step, then advanced by (1-q)^4 per step
-        // the piece's first step: weight from the host table (L2-resident)
+        // the piece's first step (weights wfirst/wrun were fetched during the previous tile's logs)
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
             acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
-            const double *pw = plan.piece_w + ((int64_t)(slot_base + k) * 2) * kWave + lane;
-            double w = pw[0];
-            wrun[k] = pw[kWave];
             if (len[k] > 0) { // wave-uniform
-                w = (0 < cut[k]) ? w : 0.0;
+                const double w = (0 < cut[k]) ? wfirst[k] : 0.0;
                 acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[a_off[k]], w, acc[k], 0, 0, 0);
             }
         }
@@ -254,6 +264,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         for (int k = MU - 1; k >= 1; --k)
             if (cont[k]) // wave-uniform
                 acc[k - 1] += acc[k];
+        load_weights(); // for the next key tile
 
         STAMP(dg_b)
         // ================= phase C: h_j * log p_j from the accumulators =================
