@@ -4,9 +4,9 @@
 // microbench_f64.hip) -- it became the dominant cost once a pmf term is down to 2
 // instructions.  The log-likelihood needs log(p_j) to an ABSOLUTE accuracy of a few
 // 1e-16 (it is summed with weights h_j into a total whose terms all have the same
-// sign), so: exponent/mantissa split (v_frexp_*), a 32-entry table {1/c, log c'}
-// in LDS indexed by the top 5 mantissa bits, r = fma(m, 1/c, -1) with |r| <= 2^-6,
-// and log1p(r) to r^8.  ~18 instructions, absolute error < 2e-16 (relative
+// sign), so: exponent/mantissa split (v_frexp_*), a 64-entry table {1/c, log c'}
+// in LDS indexed by the top 6 mantissa bits, r = fma(m, 1/c, -1) with |r| <= 2^-7,
+// and log1p(r) to r^7.  ~18 instructions, absolute error < 2e-16 (relative
 // < 2e-16 for |log x| > 1) for x in (0, 1].
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,28 +15,42 @@
 
 namespace covest {
 
+constexpr int kLogTableDoubles = 2 << kLogTableBits;
+
 // Copy the table into this workgroup's LDS (call from all threads, then barrier).
 __device__ __forceinline__ void load_log_table(double *tab_lds)
 {
-    if (threadIdx.x < 64)
-        tab_lds[threadIdx.x] = kLogTable[threadIdx.x];
+    for (int i = threadIdx.x; i < kLogTableDoubles; i += blockDim.x)
+        tab_lds[i] = kLogTable[i];
 }
 
-// log(x) for finite x > 0 (subnormals included).  NaN propagates.
+// d = a * b + c with the coefficient c in an SGPR pair, as the three-address VOP3 instruction.
+// Left to itself the compiler keeps the Horner coefficients in VGPRs, picks the two-address
+// v_fmac_f64 and copies the coefficient into the destination first -- 7 extra full-rate slots
+// per log (16% of K-basic).  A scalar operand costs nothing and frees the VGPRs.
+__device__ __forceinline__ double fma_vvs(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+
+// log(x) for finite x > 0 (subnormals included).  NaN propagates.  x == 0 gives a finite
+// value (callers handle p_j <= 0 themselves).
 __device__ __forceinline__ double fast_log(double x, const double *tab_lds)
 {
     const double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
     const int e = __builtin_amdgcn_frexp_exp(x);
-    const int idx = (__double2hiint(m) >> 15) & 31;
-    const double2 ent = *reinterpret_cast<const double2 *>(tab_lds + 2 * idx);
-    const double r = fma(m, ent.x, -1.0);
-    double q = fma(r, -0.125, 1.0 / 7.0);
-    q = fma(r, q, -1.0 / 6.0);
-    q = fma(r, q, 0.2);
-    q = fma(r, q, -0.25);
-    q = fma(r, q, 1.0 / 3.0);
+    // byte offset of the 16-byte entry: the top kLogTableBits mantissa bits
+    const unsigned off = __builtin_amdgcn_ubfe((unsigned)__double2hiint(m), 20 - kLogTableBits, kLogTableBits) << 4;
+    const double2 ent = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab_lds) + off);
+    const double r = fma(m, ent.x, -1.0); // |r| <= 2^-7
+    double q = fma_vvs(r, 1.0 / 7.0, -1.0 / 6.0);
+    q = fma_vvs(r, q, 0.2);
+    q = fma_vvs(r, q, -0.25);
+    q = fma_vvs(r, q, 1.0 / 3.0);
     q = fma(r, q, -0.5);
-    const double lp = fma(r * r, q, r); // log1p(r)
+    const double lp = fma(r * r, q, r); // log1p(r), truncation r^8/8 < 2^-59
     return fma((double)e, 0.693147180559945309417232121458, ent.y) + lp;
 }
 

@@ -3,9 +3,10 @@
 // One LANE per grid point: a wave64 evaluates 64 consecutive points of the flat
 // grid order (or of a point list).  Every lane walks the histogram keys in
 // ascending order with the pmf recurrence of streams.h (S error-class streams in
-// registers, 2 fp64 instructions per pmf term), so the key, its count h_j and
+// registers, 1.5 fp64 instructions per pmf term on full tiles), so the key, its count h_j and
 // the per-key scale are WAVE-UNIFORM: they come from the tile table through the
-// scalar cache into SGPRs, there is no LDS traffic beyond the 512-byte log table, no cross-lane operation and
+// scalar cache into SGPRs, LDS holds only the 1 KB log table and the per-lane anchor constants
+// (read once per tile), there is no cross-lane operation and
 // no divergence (neighbouring lanes differ only in (c, e)).  One log per
 // (point, non-zero bin) -- the dominant cost of this kernel once the terms are
 // down to 2 instructions.
@@ -13,7 +14,8 @@
 // Reference restated: BasicModel.compute_probabilities / compute_loglikelihood,
 // covest/models.py:81-107, over the grid of covest/grid.py:59-64.
 //
-// Roofline: fp64 VALU.  Per point: S*B pmf terms (2 instr each) + B logs.
+// Roofline: fp64 VALU.  Per point and key: 12.5 instructions for the 8 streams + 18 for the
+// log and its accumulation (30.75 measured in the ISA; tools/microbench_ops.hip prices each).
 // Algorithmic HBM bytes: 16 in (or the two axes) + 8 out per point.
 #include <hip/hip_runtime.h>
 
@@ -28,14 +30,14 @@ namespace covest {
 namespace {
 
 template <int S, bool TAIL>
-__global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const int32_t n_tiles,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ll_basic_kernel(const DevModel m, const int32_t n_tiles,
                                                        const double *__restrict__ tile_dbl,
                                                        const int32_t *__restrict__ tile_int,
                                                        const PointSource src, const int64_t n,
                                                        double *__restrict__ out_ll)
 {
     const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
-    __shared__ __attribute__((aligned(16))) double log_tab[64];
+    __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
     load_log_table(log_tab);
     __syncthreads();
     const int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,20 +54,30 @@ __global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const i
 #pragma unroll
     for (int s = 0; s < S; ++s)
         lam[s] = error_class_rate(m, par[0], par[1], s);
-    StreamSet<S> st;
+    __shared__ double anchors[2 * S * 256]; // [2S][lane of the workgroup]: conflict-free columns
+    StreamSet<S, LdsAnchors<S>> st;
+    st.an.mine = anchors + threadIdx.x;
+    st.an.stride = 256;
     st.init(m, lam, 1, finite);
 
     double acc_ll = 0.0;
+    uint64_t dead = 0; // lanes that met a p_j <= 0 with h_j != 0
     CompSum acc_sp = {0.0, 0.0};
 
-    // one key: advance the streams, scale, sum into sp_j, log (all branches wave-uniform)
-    auto visit = [&](double scal, double h, bool in_sp) {
-        const double p = st.step() * scal; // p_j, flushed like the reference's double
+    // one key's p_j (flushed like the reference's double): into sp_j, and its log (all branches
+    // wave-uniform)
+    auto account = [&](double p, double h, bool in_sp) {
         if (TAIL && in_sp)
             acc_sp.add(p);
-        if (h != 0.0) // filler keys and zero counts: no log (`if h`, covest/models.py:106)
-            acc_ll += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
+        if (h != 0.0) { // filler keys and zero counts: no log (`if h`, covest/models.py:106)
+            // utils.safe_log: p_j <= 0 makes the whole sum -inf.  Remembered as a lane mask in
+            // SGPRs (one compare) instead of a select per key; fast_log(0) is finite.
+            dead |= __ballot(p <= 0.0);
+            acc_ll = fma(h, fast_log(p, log_tab), acc_ll);
+        }
     };
+    double xx[S];
+    st.squares(xx);
 
     for (int t = 0; t < tv.n_tiles; ++t) {
         const double k0 = tv.first_key[t];
@@ -77,7 +89,8 @@ __global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const i
         const double *insp = tv.in_sp + (int64_t)t * kTileBins;
         if (nb == kTileBins) {
             // full tile: two straight-line halves of 16 keys, their scales and counts fetched
-            // into SGPRs up front (s_load_dwordx16) so no key waits on the scalar cache
+            // into SGPRs up front (s_load_dwordx16) so no key waits on the scalar cache; the
+            // streams advance two keys per step (streams.h step2)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 double sc[16], hc[16];
@@ -89,12 +102,16 @@ __global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const i
                     in[b] = TAIL ? insp[16 * half + b] != 0.0 : true;
                 }
 #pragma unroll
-                for (int b = 0; b < 16; ++b)
-                    visit(sc[b], hc[b], in[b]);
+                for (int b = 0; b < 16; b += 2) {
+                    double g1, g2;
+                    st.step2(xx, g1, g2);
+                    account(g1 * sc[b], hc[b], in[b]);
+                    account(g2 * sc[b + 1], hc[b + 1], in[b + 1]);
+                }
             }
         } else {
             for (int b = 0; b < nb; ++b)
-                visit(scal[b], cnt[b], TAIL ? insp[b] != 0.0 : true);
+                account(st.step() * scal[b], cnt[b], TAIL ? insp[b] != 0.0 : true);
         }
         st.leave_tile(tv.renorm[t]);
     }
@@ -107,6 +124,8 @@ __global__ __launch_bounds__(256) void ll_basic_kernel(const DevModel m, const i
         if (sp < 1.0)
             tail_term = m.tail * log(1.0 - sp);
     }
+    if ((dead >> (threadIdx.x & (kWave - 1))) & 1)
+        acc_ll = isnan(acc_ll) ? acc_ll : -INFINITY; // h * -inf summed with finite terms
     double ll = acc_ll + tail_term;
     if (!finite)
         ll = NAN; // a NaN parameter poisons every p_j in the reference

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     static_assert(MU == 6, "contract loops are written for 6 slots");
     const int LD = plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
-    __shared__ __attribute__((aligned(16))) double log_tab[64];
+    __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
     load_log_table(log_tab);
 
     const int tid = threadIdx.x;
@@ -111,6 +111,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const bool wave_builds = wave * kWave < plan.max_o; // wave-uniform
     StreamSet<8> st;
     st.init(m, lam, tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o);
+    double xx[8]; // squared rates: the streams advance two keys per step (streams.h step2)
+    st.squares(xx);
     const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
     if (tid < 64)
         Gs[(size_t)plan.n_buf * kTileBins * LD + tid] = 0.0; // the slack behind the buffers (see launch)
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int kq = lane >> 4;  // which of the 4 o of an MFMA step
     int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU];
     double r4[MU], llacc[MU];
+    uint64_t dead[MU]; // lanes that met a p_j <= 0 with h_j != 0
     CompSum spacc[MU];
     const int slot_base = ((int)blockIdx.y * NW + wave) * MU;
 #pragma unroll
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         cut[k] = (t_lane - (1 + 4 * first_step + kq) + 3) >> 2;
         r4[k] = plan.q_r4[slot];
         llacc[k] = 0.0;
+        dead[k] = 0;
         spacc[k].hi = 0.0;
         spacc[k].lo = 0.0;
     }
@@ -174,10 +178,15 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         double *colp = dst + (lane_in_row ? tid : 0);
         if (nb == kTileBins) { // the common case: straight-line code, scales in SGPRs
 #pragma unroll
-            for (int b = 0; b < kTileBins; ++b) {
-                const double g = st.step() * scal[b];
-                if (lane_in_row)
-                    colp[b * LD] = g;
+            for (int b = 0; b < kTileBins; b += 2) {
+                double g1, g2;
+                st.step2(xx, g1, g2);
+                g1 *= scal[b];
+                g2 *= scal[b + 1];
+                if (lane_in_row) {
+                    colp[b * LD] = g1;
+                    colp[(b + 1) * LD] = g2;
+                }
             }
         } else {
             for (int b = 0; b < kTileBins; ++b) {
@@ -279,8 +288,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     const double p = acc[k][r];
                     if (TAIL && in_sp)
                         spacc[k].add(p);
-                    if (h != 0.0) // filler and padding keys have h == 0
-                        llacc[k] += h * ((p <= 0.0) ? -INFINITY : fast_log(p, log_tab)); // utils.safe_log
+                    if (h != 0.0) { // filler and padding keys have h == 0
+                        // utils.safe_log: p_j <= 0 makes the sum -inf; kept as a lane mask in SGPRs
+                        dead[k] |= __ballot(p <= 0.0);
+                        llacc[k] = fma(h, fast_log(p, log_tab), llacc[k]);
+                    }
                 }
             }
         }
@@ -306,6 +318,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 #pragma unroll
     for (int k = 0; k < MU; ++k) {
         double ll = llacc[k];
+        if ((dead[k] >> lane) & 1)
+            ll = isnan(ll) ? ll : -INFINITY; // h * -inf summed with finite terms
         ll += __shfl_xor(ll, 16, kWave);
         ll += __shfl_xor(ll, 32, kWave);
         CompSum sp = spacc[k];

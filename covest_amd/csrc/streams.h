@@ -30,12 +30,36 @@
 
 namespace covest {
 
+// Where a lane keeps the two per-stream constants that only enter_tile needs:
+//   lx = ln x,   c = ln a_os - D(x)  (log of the weight over the normaliser).
+// Registers (K-factored, whose LDS holds G), or a [2S][workgroup] array in LDS (K-basic: 32
+// VGPRs less per lane is the difference between 3 and 4 waves per SIMD there).
 template <int S>
+struct RegAnchors {
+    double lx_[S], c_[S];
+    __device__ __forceinline__ void set(int s, double lx, double c) { lx_[s] = lx; c_[s] = c; }
+    __device__ __forceinline__ double lx(int s) const { return lx_[s]; }
+    __device__ __forceinline__ double c(int s) const { return c_[s]; }
+};
+
+template <int S>
+struct LdsAnchors {
+    double *mine; // this lane's column
+    int stride;   // lanes per workgroup
+    __device__ __forceinline__ void set(int s, double lx, double c)
+    {
+        mine[(2 * s) * stride] = lx;
+        mine[(2 * s + 1) * stride] = c;
+    }
+    __device__ __forceinline__ double lx(int s) const { return mine[(2 * s) * stride]; }
+    __device__ __forceinline__ double c(int s) const { return mine[(2 * s + 1) * stride]; }
+};
+
+template <int S, class Anchors = RegAnchors<S>>
 struct StreamSet {
     double v[S];   // scaled running term (see header)
     double x[S];   // o * lambda_s
-    double lx[S];  // ln x
-    double c[S];   // ln a_os - D(x): log of the weight over the normaliser
+    Anchors an;
 
     // Mixture weights and constants of one (copy number o) over the S error
     // classes: covest/models.py:85-90 (o = 1) and :217-233.
@@ -56,12 +80,11 @@ struct StreamSet {
             const double a = n_os[s] / tot;
             v[s] = 0.0;
             if (live && x[s] > 0.0 && a > 0.0) {
-                lx[s] = log(x[s]);
-                c[s] = log(a) - log_trunc_norm(x[s], lx[s]);
+                const double lx = log(x[s]);
+                an.set(s, lx, log(a) - log_trunc_norm(x[s], lx));
             } else { // contributes exactly 0 (x == 0: TP returns 0, c_src/covest_poissonmodule.c:15)
                 x[s] = 0.0;
-                lx[s] = 0.0;
-                c[s] = -INFINITY;
+                an.set(s, 0.0, -INFINITY);
             }
         }
     }
@@ -74,8 +97,9 @@ struct StreamSet {
     {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const double a0 = fma(km1, lx[s], c[s] - lgam_prev);
-            const double a1 = fma(klast, lx[s], c[s] - lgam_last);
+            const double lx = an.lx(s), c = an.c(s);
+            const double a0 = fma(km1, lx, c - lgam_prev);
+            const double a1 = fma(klast, lx, c - lgam_last);
             const bool need = run_start ? true : (v[s] == 0.0 && fmax(a0, a1) > kWindowLn);
             if (__any(need)) {
                 // 2^SC is applied exactly (v_ldexp_f64) wherever exp(a0) itself is a normal
@@ -89,18 +113,43 @@ struct StreamSet {
         }
     }
 
-    // Advance every stream by one key and return the sum of the scaled terms.
     // Advance every stream by one key and return the sum of the scaled terms.  (Splitting
     // the sum into two interleaved chains was measured: no gain on gfx950.)
     __device__ __forceinline__ double step()
     {
-        double g = 0.0;
+        v[0] *= x[0];
+        double g = v[0];
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
+        for (int s = 1; s < S; ++s) {
             v[s] *= x[s];
             g += v[s];
         }
         return g;
+    }
+
+    // Two keys at once: the sum at key+1 is a dot product of the CURRENT terms with x (one FMA
+    // per term), the terms themselves jump two keys with x^2 (one multiply) and are summed for
+    // key+2 (one add): 3 instructions per stream for two keys instead of 4.
+    __device__ __forceinline__ void step2(const double (&xx)[S], double &g1, double &g2)
+    {
+        g1 = v[0] * x[0];
+#pragma unroll
+        for (int s = 1; s < S; ++s)
+            g1 = fma(v[s], x[s], g1);
+        v[0] *= xx[0];
+        g2 = v[0];
+#pragma unroll
+        for (int s = 1; s < S; ++s) {
+            v[s] *= xx[s];
+            g2 += v[s];
+        }
+    }
+
+    __device__ __forceinline__ void squares(double (&xx)[S]) const
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            xx[s] = x[s] * x[s];
     }
 
     __device__ __forceinline__ void leave_tile(double renorm)
