@@ -664,6 +664,9 @@ int build_scan_plan(covest_grid *g, const double *const *axes, const int64_t *ax
     pl.var_orig = ibase + unit_m.size() + unit_cut.size();
     pl.flat_begin = g->flat_begin;
     pl.flat_end = g->flat_end;
+    pl.skip_phases = std::getenv("COVEST_SCAN_SKIP") ? std::atoi(std::getenv("COVEST_SCAN_SKIP")) : 0;
+    // the stamps share K-factored's diagnostic buffer when the two launch shapes agree (diagnostic runs only)
+    pl.diag = (g->has_plan && g->plan.diag && g->plan.n_threads == 512 && g->plan.n_qblocks == n_qblocks) ? g->plan.diag : nullptr;
     g->scan_steps = steps_total;
     g->has_scan = true;
     return COVEST_OK;

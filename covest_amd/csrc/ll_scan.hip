@@ -48,13 +48,22 @@ namespace covest {
 namespace {
 
 typedef double d16 __attribute__((ext_vector_type(16)));
+typedef double d8 __attribute__((ext_vector_type(8)));
 
 constexpr int kNT = kScanWaves * kWave;
 constexpr int kBlock = 8; // scan steps per prefetched block
+constexpr bool kFastBlocks = false; // two-accumulator blocks where nothing is read off: measured, costs registers (spills)
+constexpr int kLogGroup = 4; // logs in flight per lane (registers: two waves per SIMD leave 256 VGPRs)
 constexpr double kTinyP = 0x1p-960; // below this, p_j is re-summed with the reference's per-term rounding
 
-// value of the same key's lane in the other half of the wave
-__device__ __forceinline__ double from_partner(double x) { return __shfl_xor(x, 32, kWave); }
+// v_permlane32_swap: lanes 32..63 of `x` trade places with lanes 0..31 of `y` (pure VALU, no LDS)
+__device__ __forceinline__ void swap_halves(double &x, double &y)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
 
 // sum over the 32 lanes of this lane's half (every lane gets it)
 __device__ __forceinline__ double half_sum(double x)
@@ -125,6 +134,8 @@ __global__ __launch_bounds__(kNT) void ll_scan_kernel(const DevModel m, const in
     const bool lane_in_row = tid < LD - 2;
 
     auto build_tile = [&](int t, double *dst) {
+        if (plan.skip_phases & 1)
+            return;
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
         st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
@@ -177,6 +188,18 @@ __global__ __launch_bounds__(kNT) void ll_scan_kernel(const DevModel m, const in
         }
     }
 
+    // in-kernel stamps (diagnostic runs only): cycles per wave in build / scan / log / barrier
+    long long dg_a = 0, dg_b = 0, dg_c = 0, dg_w = 0, dg_t0 = 0;
+    const bool diag = plan.diag != nullptr;
+#define STAMP(acc)                                    \
+    if (diag) {                                       \
+        const long long now__ = (long long)clock64(); \
+        acc += now__ - dg_t0;                         \
+        dg_t0 = now__;                                \
+    }
+    if (diag)
+        dg_t0 = (long long)clock64();
+
     const bool dbuf = plan.n_buf == 2;
     if (dbuf) {
         if (wave_builds)
@@ -192,6 +215,7 @@ __global__ __launch_bounds__(kNT) void ll_scan_kernel(const DevModel m, const in
         } else if (wave_builds && t + 1 < tv.n_tiles) {
             build_tile(t + 1, Gs + ((t + 1) & 1) * kTileBins * LD);
         }
+        STAMP(dg_a)
         const double hj = tv.cnt[(int64_t)t * kTileBins + key];
         const double *row = cur + key * LD;
         const double g1 = row[0], g2 = row[1]; // G[1][key], G[2][key]
@@ -201,8 +225,12 @@ __global__ __launch_bounds__(kNT) void ll_scan_kernel(const DevModel m, const in
             if (um[u] < 0) // wave-uniform
                 continue;
             // ============ phase B: the running sum over o ============
+            // Blocks of 8 steps, branch-free inside: the partial sum after every step of the block stays
+            // in registers (pre[0..7], s), and the cut-offs that fall into the block pick theirs with a
+            // scalar register index afterwards.  A taken scalar branch costs this pipeline about as much
+            // as a dozen fp64 instructions, so there is one loop branch per block and one per cut-off.
             const double *p0 = row + col0[u];
-            const double r = rho[u];
+            const double r = rho[u], r2 = r * r;
             double s = 0.0, w = 1.0;
             d16 snap;
 #pragma unroll
@@ -210,99 +238,136 @@ __global__ __launch_bounds__(kNT) void ll_scan_kernel(const DevModel m, const in
                 snap[v] = 0.0;
             int nv = 0;
             int next_cut = __builtin_amdgcn_readlane(cutv[u], 0);
-            const int len = __builtin_amdgcn_readlane(cutv[u], NV - 1);
+            const int len = (plan.skip_phases & 2) ? 0 : __builtin_amdgcn_readlane(cutv[u], NV - 1);
             double s0 = 0.0;
-            bool s0_open = true;
+            int s0_at = len0[u]; // step at which the lower half's sum is complete (then INT_MAX)
 
-            auto capture = [&](int i) { // partial sums complete at step i (wave-uniform control flow)
-                if (s0_open && i == len0[u]) {
-                    s0 = s;
-                    s0_open = false;
-                }
-                while (nv < NV && i == next_cut) {
-                    snap[nv] = s;
-                    ++nv;
-                    next_cut = __builtin_amdgcn_readlane(cutv[u], nv < NV ? nv : NV - 1);
-                }
-            };
-            // `n` steps of block `g` starting at step `base`
-            auto run_block = [&](const double (&g)[kBlock], int base, int n) {
-                const int first_stop = s0_open ? min(len0[u], next_cut) : next_cut;
-                if (first_stop >= base + n) { // no capture inside: straight multiply-adds
-#pragma unroll
-                    for (int k = 0; k < kBlock; ++k)
-                        if (k < n) {
-                            s = fma(g[k], w, s);
-                            w *= r;
-                        }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < kBlock; ++k)
-                        if (k < n) {
-                            capture(base + k);
-                            s = fma(g[k], w, s);
-                            w *= r;
-                        }
-                }
-            };
-            double ga[kBlock], gb[kBlock];
+            // one block: consumes g[0..7] (steps base .. base + 7) and refills each register with the
+            // same step of the next block as soon as it is free (the loads fly during the rest of the
+            // block and the read-offs)
+            double g[kBlock];
 #pragma unroll
             for (int k = 0; k < kBlock; ++k)
-                ga[k] = p0[k];
-            for (int base = 0; base < len; base += 2 * kBlock) {
+                g[k] = p0[k];
+            for (int base = 0; base < len; base += kBlock) {
+                const int stop = base + kBlock;
+                const double *pn = p0 + stop;
+                if (kFastBlocks && min(s0_at, next_cut) > stop) {
+                    // nothing to read off inside this block: two independent partial sums
+                    double sb = g[1] * (w * r);
+                    s = fma(g[0], w, s);
+                    g[0] = pn[0];
+                    g[1] = pn[1];
+                    w *= r2;
 #pragma unroll
-                for (int k = 0; k < kBlock; ++k)
-                    gb[k] = p0[base + kBlock + k];
-                run_block(ga, base, min(kBlock, len - base));
+                    for (int k = 2; k < kBlock; k += 2) {
+                        s = fma(g[k], w, s);
+                        sb = fma(g[k + 1], w * r, sb);
+                        g[k] = pn[k];
+                        g[k + 1] = pn[k + 1];
+                        w *= r2;
+                    }
+                    s += sb;
+                    continue;
+                }
+                d8 pre;
 #pragma unroll
-                for (int k = 0; k < kBlock; ++k)
-                    ga[k] = p0[base + 2 * kBlock + k];
-                if (base + kBlock < len)
-                    run_block(gb, base + kBlock, min(kBlock, len - base - kBlock));
+                for (int k = 0; k < kBlock; ++k) {
+                    pre[k] = s; // sum over the steps before base + k
+                    s = fma(g[k], w, s);
+                    g[k] = pn[k];
+                    w *= r;
+                }
+                if (s0_at <= stop) {
+                    const int at = s0_at - base;
+                    const double inside = pre[at & (kBlock - 1)];
+                    s0 = at == kBlock ? s : inside;
+                    s0_at = 0x7fffffff;
+                }
+                while (next_cut <= stop) { // ends: the cut-off after the last one is INT_MAX
+                    const int at = next_cut - base;
+                    const double inside = pre[at & (kBlock - 1)];
+                    snap[nv] = at == kBlock ? s : inside;
+                    ++nv;
+                    next_cut = nv < NV ? __builtin_amdgcn_readlane(cutv[u], nv) : 0x7fffffff;
+                }
             }
-            capture(len);
+            // (len == 0: every sum is the empty one, snap and s0 are already 0)
 
+            STAMP(dg_b)
             // ============ phase C: exchange, p_j, log ============
             // half 0 holds s0 = S over [3, m); half 1 holds snap[v] = sum over [m, T_v) with weights
             // relative to m.  Lane (key, half) takes variants 8 half .. 8 half + 7.
-            const double s0_partner = from_partner(s0);
-            const double base_sum = half ? s0_partner : s0;
+            double base_sum = s0, junk = s0;
+            swap_halves(base_sum, junk); // base_sum: lanes 32..63 now hold the lower half's s0 too
             const double *cf = coef + ((wave * NU + u) * NV + half * (NV / 2)) * 4;
             const double rm = rho_m[u];
+            // Four variants at a time: p_j, then their (independent, interleaved) logs.  Near the bottom
+            // of the double range the REFERENCE's p_j is a sum of products b_o * G that were each rounded
+            // to a subnormal (covest/models.py:236-240); the factored sum rounds once and would differ
+            // from it by whole subnormal ulps.  Those keys (a handful per grid, h_j of 1..3) are summed
+            // again term by term.  The same test catches p_j <= 0 (utils.safe_log: the whole sum is -inf;
+            // kept as a lane mask).  `if h` of covest/models.py:106: filler keys (h_j == 0) are skipped.
 #pragma unroll
-            for (int k = 0; k < NV / 2; ++k) {
-                const double lo_v = from_partner(snap[k]); // half 0 receives the upper half's snapshot k
-                const double up = half ? snap[k + NV / 2] : lo_v;
-                const double S = fma(rm, up, base_sum);
-                const double2 b12 = *reinterpret_cast<const double2 *>(cf + 4 * k);
-                const double on = cf[4 * k + 2];
-                double p = fma(on, S, fma(b12.y, g2, b12.x * g1));
-                // Near the bottom of the double range the REFERENCE's p_j is a sum of products
-                // b_o * G that were each rounded to a subnormal (covest/models.py:236-240); the
-                // factored sum above rounds once and would differ from it by whole subnormal ulps.
-                // Those keys (a handful per grid, h_j of 1..3) are summed again term by term.  The
-                // test also catches p_j <= 0 (utils.safe_log: the whole sum is -inf; kept as a lane
-                // mask).  `if h` of covest/models.py:106: filler keys have h_j == 0 and are skipped.
-                const bool low = p < kTinyP && hj != 0.0;
-                if (__ballot(low)) { // wave-uniform, rare
-                    // (all lanes take part in the shuffle: the cut-offs live in lanes 0..15)
-                    const int t_end = __shfl(cutv[u], half * (NV / 2) + k, kWave) + um[u]; // max(T, 3)
-                    if (low) {
-                        double acc = __dadd_rn(__dmul_rn(b12.x, g1), __dmul_rn(b12.y, g2));
-                        double pw = 1.0;
-                        for (int o = 3; o < t_end; ++o) {
-                            acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(on, pw), row[o - 1]));
-                            pw = __dmul_rn(pw, r);
-                        }
-                        p = acc;
-                    }
-                    dead[u][k] |= __ballot(low && p <= 0.0);
+            for (int k0 = 0; k0 < NV / 2; k0 += kLogGroup) {
+                double pk[kLogGroup];
+                bool any_low = false;
+#pragma unroll
+                for (int i = 0; i < kLogGroup; ++i) {
+                    const int k = k0 + i;
+                    // after the swap `up` holds the upper half's snapshot of THIS lane's variant in both
+                    // halves: lanes 0..31 receive snap[k] of lanes 32..63, lanes 32..63 keep their snap[k + 8]
+                    double lo_part = snap[k], up = snap[k + NV / 2];
+                    swap_halves(lo_part, up);
+                    const double S = fma(rm, up, base_sum);
+                    const double2 b12 = *reinterpret_cast<const double2 *>(cf + 4 * k);
+                    const double on = cf[4 * k + 2];
+                    pk[i] = fma(on, S, fma(b12.y, g2, b12.x * g1));
+                    any_low |= pk[i] < kTinyP;
                 }
-                ll[u][k] = fma(hj, fast_log(p, log_tab), ll[u][k]);
+                if (__ballot(any_low && hj != 0.0)) { // wave-uniform, rare
+#pragma unroll
+                    for (int i = 0; i < kLogGroup; ++i) {
+                        const int k = k0 + i;
+                        const bool low = pk[i] < kTinyP && hj != 0.0;
+                        if (!__ballot(low))
+                            continue;
+                        // (all lanes take part in the shuffle: the cut-offs live in lanes 0..15)
+                        const int t_end = __shfl(cutv[u], half * (NV / 2) + k, kWave) + um[u]; // max(T, 3)
+                        if (low) {
+                            const double2 b12 = *reinterpret_cast<const double2 *>(cf + 4 * k);
+                            const double on = cf[4 * k + 2];
+                            double acc = __dadd_rn(__dmul_rn(b12.x, g1), __dmul_rn(b12.y, g2));
+                            double pw = 1.0;
+                            for (int o = 3; o < t_end; ++o) {
+                                acc = __dadd_rn(acc, __dmul_rn(__dmul_rn(on, pw), row[o - 1]));
+                                pw = __dmul_rn(pw, r);
+                            }
+                            pk[i] = acc;
+                        }
+                        dead[u][k] |= __ballot(low && pk[i] <= 0.0);
+                    }
+                }
+                if (!(plan.skip_phases & 4)) {
+#pragma unroll
+                    for (int i = 0; i < kLogGroup; ++i)
+                        ll[u][k0 + i] = fma(hj, fast_log(pk[i], log_tab), ll[u][k0 + i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            STAMP(dg_c)
         }
         __syncthreads(); // the tile just read may be overwritten, the one just built may be read
+        STAMP(dg_w)
     }
+    if (diag && lane == 0) {
+        long long *d = plan.diag + ((int64_t)(blockIdx.x * gridDim.y + blockIdx.y) * kScanWaves + wave) * 8;
+        d[0] = dg_a;
+        d[1] = dg_b;
+        d[2] = dg_c;
+        d[3] = dg_w;
+    }
+#undef STAMP
 
     // ---- per-(unit, variant) results: sum over the 32 keys of the half ----
 #pragma unroll

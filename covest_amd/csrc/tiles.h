@@ -133,6 +133,8 @@ struct ScanPlan {
     const double *var_coef;        // [slots][16][4] q1 (0 if T <= 1), (1-q1) q2 (0 if T <= 2), o_n (0 if T <= 3), 0
     const int32_t *var_orig;       // [slots][16] index into the (q1,q2,q) product (-1 = padding)
     int64_t flat_begin, flat_end;  // flat indices whose LL is written (ragged block ends)
+    int32_t skip_phases;           // PROFILING ONLY (env COVEST_SCAN_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
+    long long *diag;               // PROFILING ONLY (env COVEST_FACTORED_DIAG): per-wave cycle sums [wg][wave][8]
 };
 
 } // namespace covest
