@@ -103,10 +103,6 @@ struct covest_grid {
     DevBuf axes, t_table, ll, partial_val, partial_idx, result, plan_buf;
     FactoredPlan plan{};        // K-factored work description (repeats model, dense grid)
     bool has_plan = false;
-    DevBuf scan_buf;
-    ScanPlan scan{};            // K-scan work description (repeats model, dense grid, tail == 0)
-    bool has_scan = false;
-    double scan_steps = 0.0;    // sum over the units of a (c, e) of their scan steps (both halves), for covest_grid_work
     double q_sum_t_minus_1 = 0.0; // sum over the Q weight vectors of (threshold_o - 1)
     double sum_t_minus_1 = 0.0; // sum over the block's points of (threshold_o - 1)
     const char *last_kernel = "none";
@@ -518,160 +514,6 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     return COVEST_OK;
 }
 
-// ScanPlan of tiles.h for the (q1, q2, q) product of a dense repeats grid (tail == 0).
-int build_scan_plan(covest_grid *g, const double *const *axes, const int64_t *axis_len,
-                    const std::vector<int32_t> &t_table)
-{
-    covest_model *m = g->model;
-    g->has_scan = false;
-    if (!m->has_tiles || m->n_par != 5 || m->dm.tail != 0.0)
-        return COVEST_OK;
-    const int64_t n1 = axis_len[2], n2 = axis_len[3], n3 = axis_len[4];
-    const int64_t nq = n1 * n2 * n3;
-    if (nq > (int64_t)1 << 24)
-        return COVEST_OK;
-    int t_max = 1;
-    for (int64_t i = 0; i < nq; ++i)
-        t_max = std::max(t_max, (int)t_table[(size_t)i]);
-    if (t_max - 1 > kScanWaves * 64 || t_max - 1 < 1)
-        return COVEST_OK; // more copy-number classes than a workgroup has lanes: other kernels
-    constexpr int NV = kScanVariants;
-    struct Unit {
-        int m, len;
-        long cost;
-        int32_t cut[NV], orig[NV];
-        double rho, rho_m, coef[NV][4];
-    };
-    const int log_cost = std::getenv("COVEST_SCAN_LOG_COST") ? std::atoi(std::getenv("COVEST_SCAN_LOG_COST")) : kScanLogCost;
-    const int build_cost = std::getenv("COVEST_SCAN_BUILD_COST") ? std::atoi(std::getenv("COVEST_SCAN_BUILD_COST")) : kScanBuildCost;
-    std::vector<Unit> units;
-    double steps_total = 0.0;
-    for (int64_t c = 0; c < n3; ++c) {
-        const double q = clamp_one(m->dm, 4, axes[4][c]);
-        std::vector<int32_t> vars((size_t)(n1 * n2));
-        for (size_t i = 0; i < vars.size(); ++i)
-            vars[i] = (int32_t)i;
-        auto t_of = [&](int32_t v) { return (int)t_table[(size_t)((int64_t)v * n3 + c)]; };
-        std::stable_sort(vars.begin(), vars.end(), [&](int32_t a, int32_t b) { return t_of(a) < t_of(b); });
-        for (size_t first = 0; first < vars.size(); first += NV) {
-            Unit u{};
-            const size_t n = std::min<size_t>(NV, vars.size() - first);
-            const int cmin = std::max(3, t_of(vars[first]));
-            u.m = (cmin + 3) / 2; // lower half [3, m) is done before the first cut-off of the upper half
-            u.rho = 1 - q;
-            u.rho_m = std::pow(1 - q, (double)(u.m - 3));
-            for (size_t i = 0; i < (size_t)NV; ++i) {
-                if (i >= n) { // padding: nothing more to sum, contributes nothing, written nowhere
-                    u.cut[i] = u.cut[n - 1];
-                    u.orig[i] = -1;
-                    continue;
-                }
-                const int32_t v = vars[first + i];
-                const int t = t_of(v);
-                const double q1 = clamp_one(m->dm, 2, axes[2][v / n2]);
-                const double q2 = clamp_one(m->dm, 3, axes[3][v % n2]);
-                u.cut[i] = std::max(3, t) - u.m;
-                u.orig[i] = (int32_t)((int64_t)v * n3 + c);
-                // RepeatsModel.get_b_o, covest/models.py:193-208, each weight only while o < T
-                u.coef[i][0] = t > 1 ? q1 : 0.0;
-                u.coef[i][1] = t > 2 ? (1 - q1) * q2 : 0.0;
-                u.coef[i][2] = t > 3 ? (1 - q1) * (1 - q2) * q : 0.0;
-            }
-            u.len = u.cut[NV - 1];
-            u.cost = 2L * u.len + (long)(NV / 2) * log_cost;
-            steps_total += (double)(u.m - 3) + (double)u.len;
-            units.push_back(u);
-        }
-    }
-    const int per_block = kScanWaves * kScanUnitsPerWave;
-    const int n_qblocks = (int)((units.size() + per_block - 1) / per_block);
-    std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.cost > b.cost; });
-    // G row stride: odd, so that the 32 rows of a key tile start in 32 different 8-byte banks
-    const int ld = (t_max - 1 + 2) | 1;
-    const size_t lds_fixed = (64 + (size_t)per_block * NV * 4) * sizeof(double) + 1024 + 256;
-    const int n_buf = 2 * (size_t)kTileBins * ld * sizeof(double) + lds_fixed <= 160 * 1024 ? 2 : 1;
-    if ((size_t)n_buf * kTileBins * ld * sizeof(double) + lds_fixed > 160 * 1024)
-        return COVEST_OK;
-    const size_t n_slot = (size_t)n_qblocks * per_block;
-    std::vector<int32_t> unit_m(n_slot, -1), unit_cut(n_slot * NV, 0), var_orig(n_slot * NV, -1);
-    std::vector<double> unit_rho(n_slot * 2, 0.0), var_coef(n_slot * NV * 4, 0.0);
-    for (int blk = 0; blk < n_qblocks; ++blk) {
-        // units are sorted by cost: deal them over the q-blocks in turn, then longest first into the lightest
-        // SIMD (waves w and w + 4 share one) with a free slot, then into the lighter of its waves
-        std::vector<long> simd_load(4, 0), wave_load(kScanWaves, 0);
-        std::vector<int> used(kScanWaves, 0);
-        if (n_buf == 2)
-            for (int w = 0; w < kScanWaves && w * 64 < t_max - 1; ++w) {
-                simd_load[(size_t)(w % 4)] += build_cost;
-                wave_load[(size_t)w] += build_cost;
-            }
-        for (size_t i = (size_t)blk; i < units.size(); i += (size_t)n_qblocks) {
-            const Unit &u = units[i];
-            int best = -1;
-            for (int w = 0; w < kScanWaves; ++w) {
-                if (used[(size_t)w] >= kScanUnitsPerWave)
-                    continue;
-                if (best < 0) {
-                    best = w;
-                    continue;
-                }
-                const long lw = simd_load[(size_t)(w % 4)], lb = simd_load[(size_t)(best % 4)];
-                if (lw < lb || (lw == lb && wave_load[(size_t)w] < wave_load[(size_t)best]))
-                    best = w;
-            }
-            const size_t at = ((size_t)blk * kScanWaves + (size_t)best) * kScanUnitsPerWave + (size_t)used[(size_t)best];
-            used[(size_t)best]++;
-            simd_load[(size_t)(best % 4)] += u.cost;
-            wave_load[(size_t)best] += u.cost;
-            unit_m[at] = u.m;
-            unit_rho[2 * at] = u.rho;
-            unit_rho[2 * at + 1] = u.rho_m;
-            for (int v = 0; v < NV; ++v) {
-                unit_cut[at * NV + (size_t)v] = u.cut[v];
-                var_orig[at * NV + (size_t)v] = u.orig[v];
-                for (int k = 0; k < 4; ++k)
-                    var_coef[(at * NV + (size_t)v) * 4 + (size_t)k] = u.coef[v][k];
-            }
-        }
-    }
-    // one buffer: doubles first (unit_rho | var_coef), then int32 (unit_m | unit_cut | var_orig)
-    const size_t n_dbl = unit_rho.size() + var_coef.size();
-    const size_t n_int = unit_m.size() + unit_cut.size() + var_orig.size();
-    HIP_TRY(g->scan_buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
-    double *dbase = g->scan_buf.as<double>();
-    int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
-    HIP_TRY(hipMemcpy(dbase, unit_rho.data(), unit_rho.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dbase + unit_rho.size(), var_coef.data(), var_coef.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ibase, unit_m.data(), unit_m.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ibase + unit_m.size(), unit_cut.data(), unit_cut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ibase + unit_m.size() + unit_cut.size(), var_orig.data(), var_orig.size() * sizeof(int32_t),
-                      hipMemcpyHostToDevice));
-    ScanPlan &pl = g->scan;
-    pl.c_axis = g->src.axis[0];
-    pl.e_axis = g->src.axis[1];
-    pl.n_e = axis_len[1];
-    pl.n_q = nq;
-    pl.ce_begin = g->flat_begin / nq;
-    pl.ce_end = (g->flat_end + nq - 1) / nq;
-    pl.max_o = t_max - 1;
-    pl.n_qblocks = n_qblocks;
-    pl.ld = ld;
-    pl.n_buf = std::getenv("COVEST_SCAN_NBUF") ? std::atoi(std::getenv("COVEST_SCAN_NBUF")) : n_buf;
-    pl.unit_rho = dbase;
-    pl.var_coef = dbase + unit_rho.size();
-    pl.unit_m = ibase;
-    pl.unit_cut = ibase + unit_m.size();
-    pl.var_orig = ibase + unit_m.size() + unit_cut.size();
-    pl.flat_begin = g->flat_begin;
-    pl.flat_end = g->flat_end;
-    pl.skip_phases = std::getenv("COVEST_SCAN_SKIP") ? std::atoi(std::getenv("COVEST_SCAN_SKIP")) : 0;
-    // the stamps share K-factored's diagnostic buffer when the two launch shapes agree (diagnostic runs only)
-    pl.diag = (g->has_plan && g->plan.diag && g->plan.n_threads == 512 && g->plan.n_qblocks == n_qblocks) ? g->plan.diag : nullptr;
-    g->scan_steps = steps_total;
-    g->has_scan = true;
-    return COVEST_OK;
-}
-
 } // namespace
 
 extern "C" {
@@ -823,14 +665,10 @@ static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_gr
 {
     const bool basic_fast = m->has_tiles && m->dm.kind == COVEST_MODEL_BASIC;
     const bool factored_ok = g && g->has_plan;
-    const bool scan_ok = g && g->has_scan;
     switch (kernel) {
     case COVEST_KERNEL_AUTO:
         if (basic_fast)
             return COVEST_KERNEL_RECUR;
-        // one running sum per q value instead of one contraction per (q1, q2, q): cheaper whenever it applies
-        if (scan_ok && g->scan.n_q >= 32)
-            return COVEST_KERNEL_SCAN;
         // the factored kernel pays when many weight vectors share each (c, e)
         if (factored_ok && g->plan.n_q >= 32)
             return COVEST_KERNEL_FACTORED;
@@ -846,11 +684,6 @@ static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_gr
             return COVEST_KERNEL_FACTORED;
         return fail(COVEST_E_INVALID, "factored kernel needs a dense repeats-model grid, max_error 8, keys in "
                                       "1..16384 and threshold_o <= 513");
-    case COVEST_KERNEL_SCAN:
-        if (scan_ok)
-            return COVEST_KERNEL_SCAN;
-        return fail(COVEST_E_INVALID, "scan kernel needs a dense repeats-model grid, tail 0, max_error 8, keys in "
-                                      "1..16384 and threshold_o <= 513");
     default:
         return fail(COVEST_E_INVALID, "unknown kernel");
     }
@@ -864,11 +697,6 @@ static hipError_t launch_ll(const covest_model *m, int kernel, const PointSource
         if (name)
             *name = "ll_factored";
         return launch_ll_factored(m->dm, m->tv, g->plan, out, st);
-    }
-    if (kernel == COVEST_KERNEL_SCAN) {
-        if (name)
-            *name = "ll_scan";
-        return launch_ll_scan(m->dm, m->tv, g->scan, out, st);
     }
     if (kernel == COVEST_KERNEL_RECUR) {
         if (name)
@@ -990,7 +818,6 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
         g->partial_idx.release();
         g->result.release();
         g->plan_buf.release();
-        g->scan_buf.release();
         delete g;
         return code;
     };
@@ -1050,9 +877,7 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
         };
         g->sum_t_minus_1 = upto(flat_end) - upto(flat_begin);
         g->q_sum_t_minus_1 = prefix[(size_t)nq];
-        int prc = build_factored_plan(g, axes, axis_len, table);
-        if (prc == COVEST_OK)
-            prc = build_scan_plan(g, axes, axis_len, table);
+        const int prc = build_factored_plan(g, axes, axis_len, table);
         if (prc != COVEST_OK)
             return bail(prc);
     }
@@ -1078,7 +903,6 @@ void covest_grid_destroy(covest_grid *g)
     g->partial_idx.release();
     g->result.release();
     g->plan_buf.release();
-    g->scan_buf.release();
     for (hipEvent_t e : g->ev_begin)
         (void)hipEventDestroy(e);
     for (hipEvent_t e : g->ev_end)
@@ -1426,14 +1250,6 @@ int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, con
             const double max_o = (double)g->plan.max_o;
             *flops = n_ce * (bins * S * max_o * 2.0 + bins * g->q_sum_t_minus_1 * 2.0 +
                              bins * (double)g->plan.n_q * 25.0 + 25.0 * S * max_o);
-        } else if (g->last_kernel_id == COVEST_KERNEL_SCAN) {
-            // algorithmic minimum of the scan formulation (ll_scan.hip header): per (c,e): G build 2 flop per
-            // (key, o, s), running sums 2 flop per (key, q value, o), 25 per log (key, point) + 6 for p_j,
-            // prologue exps 25 per (o, s)
-            const double n_ce = (double)(g->scan.ce_end - g->scan.ce_begin);
-            const double max_o = (double)g->scan.max_o;
-            *flops = n_ce * (bins * S * max_o * 2.0 + bins * g->scan_steps * 2.0 +
-                             bins * (double)g->scan.n_q * 31.0 + 25.0 * S * max_o);
         } else {
             // 4 flop per pmf term + 25 per log + 25 per exp of the prologue
             *flops = 4.0 * terms + 25.0 * bins * n + 25.0 * S * g->sum_t_minus_1;

@@ -24,11 +24,6 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
 hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                               double *out_ll, hipStream_t stream);
 
-// K-scan: repeats model on a dense grid with tail == 0, one workgroup per (c, e); the copy-number
-// sum is a running sum per q value read off at each variant's cut-off (ll_scan.hip).
-hipError_t launch_ll_scan(const DevModel &m, const TileView &tv, const ScanPlan &plan, double *out_ll,
-                          hipStream_t stream);
-
 // (min -LL, lowest index) over ll[n]: two-stage reduction (argmin.hip).
 // partial_val/partial_idx need kArgminBlocks entries; result[0] = {min, bits of idx}.
 constexpr int kArgminBlocks = 256;

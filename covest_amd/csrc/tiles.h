@@ -102,39 +102,4 @@ struct FactoredPlan {
     int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
 };
 
-// Work description of K-scan (ll_scan.hip), built at covest_grid_create for a dense repeats-model
-// grid with tail == 0.  For o >= 3 the copy-number weight is b_o = o_n rho^(o-3) with rho = 1 - q and
-// o_n = (1-q1)(1-q2)q (covest/models.py:193-208), so for one value of q every (q1, q2) VARIANT needs the
-// same running sum  S(T) = sum_{3 <= o < T} G[key][o] rho^(o-3),  read off at its own cut-off T:
-//     p_j = q1 G[j][1] + (1-q1) q2 G[j][2] + o_n S(T).
-// A UNIT is one q value with up to 16 variants, sorted by T; a wave holds two units and a workgroup
-// 16 (a further q-block of workgroups takes the rest and rebuilds G).  Lanes are (key, half): the two
-// halves of a wave split a unit's o range at m <= (T_min + 3) / 2, so that the lower half [3, m) is done
-// before the upper half [m, T_max) reaches the first cut-off, and they split the 16 logs of a key.
-constexpr int kScanVariants = 16;   // cut-offs per unit
-constexpr int kScanUnitsPerWave = 2;
-constexpr int kScanWaves = 8;       // 512 threads
-constexpr int kScanBuildCost = 500; // phase A of one wave and key tile, in fp64 issue slots (LPT charge)
-constexpr int kScanLogCost = 26;    // one p_j assembly + log + accumulation, same unit
-
-struct ScanPlan {
-    const double *c_axis, *e_axis; // device copies of axes 0 and 1
-    int64_t n_e;                   // len(e axis): ce = ic * n_e + ie
-    int64_t ce_begin, ce_end;      // (c, e) pairs this block covers
-    int64_t n_q;                   // |q1| x |q2| x |q|
-    int32_t max_o;                 // max threshold_o - 1: copy numbers to build
-    int32_t n_qblocks;             // workgroups per (c, e) (gridDim.y); each rebuilds G
-    int32_t ld;                    // G row stride in doubles, odd: the 32 rows of a tile fall into distinct banks
-    int32_t n_buf;                 // 2: G double-buffered in LDS
-    // per unit slot, [n_qblocks][kScanWaves][kScanUnitsPerWave]:
-    const int32_t *unit_m;         // first o of the upper half's range (>= 3); -1 = empty slot
-    const int32_t *unit_cut;       // [slots][16] loop step at which variant v's sum is complete: max(T_v, 3) - m, ascending
-    const double *unit_rho;        // [slots][2] rho and rho^(m-3) (libm pow)
-    const double *var_coef;        // [slots][16][4] q1 (0 if T <= 1), (1-q1) q2 (0 if T <= 2), o_n (0 if T <= 3), 0
-    const int32_t *var_orig;       // [slots][16] index into the (q1,q2,q) product (-1 = padding)
-    int64_t flat_begin, flat_end;  // flat indices whose LL is written (ragged block ends)
-    int32_t skip_phases;           // PROFILING ONLY (env COVEST_SCAN_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
-    long long *diag;               // PROFILING ONLY (env COVEST_FACTORED_DIAG): per-wave cycle sums [wg][wave][8]
-};
-
 } // namespace covest

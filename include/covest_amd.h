@@ -50,7 +50,6 @@ extern "C" {
 #define COVEST_KERNEL_DIRECT 1   /* one wavefront per grid point, one exp per pmf term        */
 #define COVEST_KERNEL_RECUR 2    /* one wavefront per grid point, pmf recurrence along j      */
 #define COVEST_KERNEL_FACTORED 3 /* repeats, dense grids: (c,e)-outer / (q1,q2,q)-inner reuse */
-#define COVEST_KERNEL_SCAN 4     /* repeats, dense grids, tail 0: one running sum per q value  */
 
 typedef struct covest_model covest_model; /* opaque */
 typedef struct covest_grid covest_grid;   /* opaque */

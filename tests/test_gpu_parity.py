@@ -165,7 +165,7 @@ def _verify_argmin_with_oracle(oracle, om, grid, ll, arg, top):
     assert cand[k] == arg
 
 
-@pytest.mark.parametrize("kernel", ["direct", "factored", "scan"])
+@pytest.mark.parametrize("kernel", ["direct", "factored"])
 def test_config3_sample_and_argmin(hip_lib, oracle, kernel):
     from covest_amd import DenseGrid
     g = load_golden("c3_sample.json")
@@ -185,21 +185,18 @@ def test_config3_sample_and_argmin(hip_lib, oracle, kernel):
         assert rel_err(float(ll[i]), want) <= TOL
     val, arg = grid.argmin()
     assert val == -ll[arg] and arg == int(np.argmin(np.where(np.isnan(ll), np.inf, -ll)))
-    if kernel != "direct":  # whole grid against the direct kernel (itself pinned to the fixture above)
+    if kernel == "factored":  # whole grid against the direct kernel (itself pinned to the fixture above)
         ref = DenseGrid(m, axes)
         ref.evaluate(kernel="direct")
-        worst = _check(ll, ref.loglikelihoods(), "C3 %s vs direct" % kernel, tol=1e-11)
+        worst = _check(ll, ref.loglikelihoods(), "C3 factored vs direct", tol=1e-11)
         assert ref.argmin() == (val, arg) or ref.argmin()[1] == arg
-        print("C3 %s vs direct worst rel err" % kernel, worst)
-        auto = DenseGrid(m, axes)  # AUTO picks the scan kernel for a dense repeats grid without a tail
-        auto.evaluate()
-        assert auto.work()[2] == "ll_scan"
+        print("C3 factored vs direct worst rel err", worst)
 
 
-@pytest.mark.parametrize("kernel,tail", [("factored", 0), ("factored", 1000), ("scan", 0)])
+@pytest.mark.parametrize("tail", [0, 1000])
 @pytest.mark.parametrize("hname", ["sim_c10_e0.05", "sim_c10_e0.05_sparse", "sim_c10_e0"])
-def test_factored_small_histograms(hip_lib, oracle, hname, kernel, tail):
-    """K-factored and K-scan on the reference's own test histograms: every point of a dense
+def test_factored_small_histograms(hip_lib, oracle, hname, tail):
+    """K-factored on the reference's own test histograms: every point of a dense
     5-D grid against the oracle, whole and in ragged flat-index blocks."""
     from covest_amd import DenseGrid, RepeatsModel
     hist = load_hist(hname)
@@ -208,12 +205,11 @@ def test_factored_small_histograms(hip_lib, oracle, hname, kernel, tail):
     axes = [np.array([6.0, 10.0, 14.5]), np.array([0.0, 0.02, 0.05, 0.3]), np.array([0.2, 0.5, 0.8, 1.0]),
             np.array([0.0, 0.4, 1.0]), np.array([0.0, 0.05, 0.3, 0.7, 1.0])]
     grid = DenseGrid(m, axes)
-    grid.evaluate(kernel=kernel)
-    assert grid.work()[2] == "ll_" + kernel
+    grid.evaluate(kernel="factored")
     ll = grid.loglikelihoods()
     pts = np.array([grid.point(i) for i in range(grid.total)])
     ref = om.compute_loglikelihood_many(pts, n_threads=16)
-    worst = _check(ll, ref, "%s %s tail=%d" % (kernel, hname, tail), slack=_tail_noise(om, pts, ref, tail))
+    worst = _check(ll, ref, "factored %s tail=%d" % (hname, tail), slack=_tail_noise(om, pts, ref, tail))
     k, best = oracle.first_min(-ref)
     val, arg = grid.argmin()
     assert arg == k or ll[arg] == ll[k]
@@ -222,10 +218,10 @@ def test_factored_small_histograms(hip_lib, oracle, hname, kernel, tail):
     parts = []
     for a, b in zip(cuts[:-1], cuts[1:]):
         blk = DenseGrid(m, axes, (a, b))
-        blk.evaluate(kernel=kernel)
+        blk.evaluate(kernel="factored")
         parts.append(blk.loglikelihoods())
     assert np.array_equal(np.concatenate(parts), ll, equal_nan=True)
-    print(kernel, hname, tail, "worst rel err", worst)
+    print("factored", hname, tail, "worst rel err", worst)
 
 
 def test_factored_plan_shapes(hip_lib, oracle):
@@ -244,8 +240,6 @@ def test_factored_plan_shapes(hip_lib, oracle):
         # threshold_o up to ~450: LD > 320, one LDS buffer
         ("single buffer", 5, [np.array([12.0]), np.array([0.02, 0.1]), np.linspace(0.3, 0.9, 4),
                               np.array([0.2, 0.7]), np.array([0.03, 0.04, 0.2, 0.5, 0.9])]),
-        ("single buffer, no tail", 0, [np.array([12.0]), np.array([0.02, 0.1]), np.linspace(0.3, 0.9, 4),
-                                       np.array([0.2, 0.7]), np.array([0.03, 0.04, 0.2, 0.5, 0.9])]),
         # few vectors, small T: the 256-thread workgroup
         ("256 threads", 0, [np.array([5.0, 9.0]), np.array([0.03]), np.linspace(0.4, 0.9, 4),
                             np.array([0.5]), np.linspace(0.3, 0.9, 8)]),
@@ -265,12 +259,6 @@ def test_factored_plan_shapes(hip_lib, oracle):
         want = om.compute_loglikelihood_many(pts, n_threads=16)
         _check(ll[sel], want, name + " vs oracle", slack=_tail_noise(om, pts, want, tail))
         print("factored plan shape:", name, "points", fac.total, "worst rel err vs direct", worst)
-        if tail == 0:  # K-scan on the same shapes (several q-blocks; padded units)
-            sc = DenseGrid(m, axes)
-            sc.evaluate(kernel="scan")
-            worst = _check(sc.loglikelihoods(), ref.loglikelihoods(), name + " scan vs direct", tol=1e-10)
-            assert sc.argmin()[1] == ref.argmin()[1]
-            print("scan plan shape:", name, "worst rel err vs direct", worst)
 
 
 def test_threshold_fixture_through_capi(hip_lib):
@@ -410,7 +398,7 @@ def test_fuzz_random_histograms(hip_lib, oracle, seed):
     gp = np.array([grid.point(i) for i in range(grid.total)])
     gref = orm.compute_loglikelihood_many(gp, n_threads=16)
     gslack = _tail_noise(orm, gp, gref, tail)
-    for kernel in ("direct", "factored") + (("scan",) if tail == 0 else ()):
+    for kernel in ("direct", "factored"):
         grid.evaluate(kernel=kernel)
         ll = grid.loglikelihoods()
         _check(ll, gref, "fuzz repeats %s seed %d" % (kernel, seed), slack=gslack)

@@ -1,6 +1,13 @@
-# A/B of likelihood kernels on C3 (one process per run)
+# A/B of two builds of libcovest_amd.so in ONE GPU run (same box, same clocks):
+#   tools/ab.sh <lib_a.so> <lib_b.so> [workloads...]     (default workloads: c2 c3)
+a=$1; b=$2; shift 2
+wl=${*:-c2 c3}
 for i in 1 2; do
-for k in factored scan; do
-  echo -n "$k: "; python bench.py --workload c3 --kernel $k --steps 20 --warmup 3 --cpu-budget 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['value'], d['roofline']['frac'])"
-done
+  for lib in "$a" "$b"; do
+    for w in $wl; do
+      echo -n "$(basename $lib) $w: "
+      COVEST_AMD_LIB=$PWD/$lib python bench.py --workload $w --steps 20 --warmup 3 --cpu-budget 0 2>/dev/null |
+        python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'])"
+    done
+  done
 done

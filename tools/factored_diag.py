@@ -15,7 +15,7 @@ from covest_amd import DenseGrid, RepeatsModel, _capi  # noqa: E402
 kind, hname, axes = workload("c3", 1)
 m = RepeatsModel(21, 100, load_hist(hname), 0, max_error=8)
 g = DenseGrid(m, axes)
-g.evaluate(kernel=os.environ.get("COVEST_DIAG_KERNEL", "factored"))
+g.evaluate(kernel="factored")
 g.argmin()
 L = _capi.lib()
 n = L.covest_grid_diag(g._handle, None, 0)
