@@ -76,8 +76,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             acc_ll = fma(h, fast_log(p, log_tab), acc_ll);
         }
     };
-    double xx[S];
-    st.squares(xx);
 
     for (int t = 0; t < tv.n_tiles; ++t) {
         const double k0 = tv.first_key[t];
@@ -88,6 +86,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const double *cnt = tv.cnt + (int64_t)t * kTileBins;
         const double *insp = tv.in_sp + (int64_t)t * kTileBins;
         if (nb == kTileBins) {
+            double xx[S]; // squared rates, recomputed per tile (S multiplies) rather than held in 2 S registers
+            st.squares(xx);
             // full tile: two straight-line halves of 16 keys, their scales and counts fetched
             // into SGPRs up front (s_load_dwordx16) so no key waits on the scalar cache; the
             // streams advance two keys per step (streams.h step2)
