@@ -111,8 +111,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const bool wave_builds = wave * kWave < plan.max_o; // wave-uniform
     StreamSet<8> st;
     st.init(m, lam, tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o);
-    double xx[8]; // squared rates: the streams advance two keys per step (streams.h step2)
-    st.squares(xx);
     const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
     if (tid < 64)
         Gs[(size_t)plan.n_buf * kTileBins * LD + tid] = 0.0; // the slack behind the buffers (see launch)
@@ -177,6 +175,16 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         double *colp = dst + (lane_in_row ? tid : 0);
         if (nb == kTileBins) { // the common case: straight-line code, scales in SGPRs
+            // squared rates (the streams advance two keys per step, streams.h step2): 8 multiplies per tile
+            // rather than 16 registers held through phases B and C -- the empty asm keeps the compiler from
+            // hoisting them back out of the tile loop (it would spill them)
+            double xx[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                double xs = st.x[s];
+                asm volatile("" : "+v"(xs));
+                xx[s] = xs * xs;
+            }
 #pragma unroll
             for (int b = 0; b < kTileBins; b += 2) {
                 double g1, g2;
