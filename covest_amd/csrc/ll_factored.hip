@@ -296,12 +296,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     const double p = acc[k][r];
                     if (TAIL && in_sp)
                         spacc[k].add(p);
-                    if (h != 0.0) { // filler and padding keys have h == 0
-                        // utils.safe_log: p_j <= 0 makes the sum -inf; kept as a lane mask in SGPRs
-                        dead[k] |= __ballot(p <= 0.0);
-                        llacc[k] = fma(h, fast_log(p, log_tab), llacc[k]);
-                    }
+                    // No branch on h (it differs between the lanes' rows): the four logs of a unit are
+                    // straight-line code and interleave.  Filler and padding keys have h == 0 (`if h`,
+                    // covest/models.py:106) and add 0 * log p -- fast_log(0) is finite.  utils.safe_log:
+                    // p_j <= 0 with h_j != 0 makes the sum -inf; kept as a lane mask in SGPRs.
+                    dead[k] |= __ballot(p <= 0.0 && h != 0.0);
+                    llacc[k] = fma(h, fast_log(p, log_tab), llacc[k]);
                 }
+                __builtin_amdgcn_sched_barrier(0); // ... one unit at a time: registers
             }
         }
         STAMP(dg_c)
