@@ -66,9 +66,9 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, const double *dbl
 // on their number (no per-slot branches inside it).
 constexpr int kMaxUnits = 6;       // accumulator slots per wave
 constexpr int kHalfUnits = 3;      // (kept for the 256-thread capacity rule: 4 waves x 6 slots)
-constexpr int kBuildCost = 50;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3)
+constexpr int kBuildCost = 36;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3)
 constexpr int kMinPieceSteps = 6;  // pieces are not made shorter than this
-constexpr int kUnitOverhead = 0;   // per-unit cost besides its MFMA steps (logs, setup), same unit
+constexpr int kUnitOverhead = 3;   // per-unit cost besides its MFMA steps (logs, setup), same unit
 
 struct FactoredPlan {
     const double *c_axis, *e_axis; // device copies of axes 0 and 1
