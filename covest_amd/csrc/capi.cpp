@@ -1216,6 +1216,60 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
     return COVEST_OK;
 }
 
+int covest_thin_histogram(int32_t device, int64_t n, const int32_t *keys, const double *counts, double factor,
+                          int64_t out_len, double *out)
+{
+    if (n < 0 || out_len < 0 || (n > 0 && (!keys || !counts)) || (out_len > 0 && !out))
+        return fail(COVEST_E_INVALID, "covest_thin_histogram: null argument");
+    if (!(factor > 1.0))
+        return fail(COVEST_E_INVALID, "covest_thin_histogram: factor must be > 1");
+    int32_t max_key = 0;
+    for (int64_t s = 0; s < n; ++s) {
+        if (keys[s] < 1)
+            return fail(COVEST_E_INVALID, "covest_thin_histogram: keys must be >= 1");
+        max_key = std::max(max_key, keys[s]);
+    }
+    if (out_len == 0)
+        return COVEST_OK;
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (n_dev < 1)
+        return fail(COVEST_E_NO_DEVICE, "covest_thin_histogram: no HIP device");
+    HIP_TRY(hipSetDevice(device < 0 ? 0 : device));
+    const int64_t top = std::max<int64_t>(max_key, out_len);
+    std::vector<double> lgam((size_t)top + 1);
+    for (int64_t v = 0; v <= top; ++v)
+        lgam[(size_t)v] = std::lgamma((double)v + 1.0);
+    DevBuf d_keys, d_counts, d_lgam, d_out;
+    auto done = [&](int code) {
+        d_keys.release();
+        d_counts.release();
+        d_lgam.release();
+        d_out.release();
+        return code;
+    };
+#define THIN_TRY(expr)                          \
+    do {                                        \
+        hipError_t e__ = (expr);                \
+        if (e__ != hipSuccess)                  \
+            return done(fail_hip(e__, #expr));  \
+    } while (0)
+    THIN_TRY(d_keys.reserve((size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));
+    THIN_TRY(d_counts.reserve((size_t)std::max<int64_t>(n, 1) * sizeof(double)));
+    THIN_TRY(d_lgam.reserve(lgam.size() * sizeof(double)));
+    THIN_TRY(d_out.reserve((size_t)out_len * sizeof(double)));
+    if (n > 0) {
+        THIN_TRY(hipMemcpy(d_keys.ptr, keys, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+        THIN_TRY(hipMemcpy(d_counts.ptr, counts, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    THIN_TRY(hipMemcpy(d_lgam.ptr, lgam.data(), lgam.size() * sizeof(double), hipMemcpyHostToDevice));
+    THIN_TRY(launch_thin_hist(d_keys.as<int32_t>(), d_counts.as<double>(), n, d_lgam.as<double>(), factor, out_len,
+                              d_out.as<double>(), nullptr));
+    THIN_TRY(hipMemcpy(out, d_out.ptr, (size_t)out_len * sizeof(double), hipMemcpyDeviceToHost));
+#undef THIN_TRY
+    return done(COVEST_OK);
+}
+
 int64_t covest_grid_diag(covest_grid *g, int64_t *out, int64_t n)
 {
     if (!g || !g->has_plan || !g->plan.diag)

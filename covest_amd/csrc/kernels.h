@@ -57,4 +57,9 @@ hipError_t launch_kmer_stats(const KmerTable &t, unsigned long long *stats, hipS
 hipError_t launch_kmer_histogram(const KmerTable &t, unsigned long long *hist, unsigned long long hist_len,
                                  hipStream_t stream);
 
+// ---- K-thin: expected histogram after down-sampling by `factor` (thin_hist.hip), SURVEY 8(f) row F3 ----
+// keys/counts: the n source bins (device); lgam[m] = ln m! for m = 0 .. max key (device); out[j-1], j = 1..out_len.
+hipError_t launch_thin_hist(const int32_t *keys, const double *counts, int64_t n, const double *lgam,
+                            double factor, int64_t out_len, double *out, hipStream_t stream);
+
 } // namespace covest

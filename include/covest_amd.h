@@ -181,6 +181,16 @@ int64_t covest_kmer_slots(const covest_kmer *c);
 /* Forget every count (counts = defaultdict(int) again), keeping the table's size; asynchronous on `stream`. */
 int covest_kmer_clear(covest_kmer *c, void *stream);
 
+/* ---- histogram down-sampling: covest/histogram.py:47-70 sample_histogram ----
+ * Expected counts of the histogram after keeping every read with probability 1/factor, BEFORE the
+ * reference's randomised rounding (:71-74, host side): out[j-1] = sum_i counts_i * pmf_i(j) for
+ * j = 1 .. out_len, with pmf_i = binomial(i, 1/factor) for i < 100 and Poisson(i/factor) for i >= 100.
+ * keys[n] >= 1 are the (already trimmed) source counts i, counts[n] their multiplicities.  HOST buffers.
+ * factor must be > 1.  (Where i/factor > 200 the reference's poisson_dist is itself wrong -- see
+ * DESIGN.md -- and this returns the correct Poisson pmf.) */
+int covest_thin_histogram(int32_t device, int64_t n, const int32_t *keys, const double *counts, double factor,
+                          int64_t out_len, double *out);
+
 /* PROFILING AID: with the environment variable COVEST_FACTORED_DIAG set at
  * covest_grid_create, the factored kernel accumulates s_memtime stamps per wave
  * ([workgroup][wave][8] int64: build, contract, log, barrier cycles); this copies

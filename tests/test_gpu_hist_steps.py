@@ -1,0 +1,113 @@
+"""K-thin (histogram down-sampling) and the result record on the GPU, through the C ABI: against the
+oracle (tests at sizes it finishes in seconds), against the reference's own vectors where the reference is
+right (every i / factor <= 200), and through size-independent properties at full size."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, load_hist, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+G = load_golden("hist_steps.json")
+
+
+def _hist(name):
+    if name == "H10k_rep_le640":
+        return {k: v for k, v in load_hist("H10k_rep").items() if k <= 640}
+    return load_hist(name)
+
+
+def _trimmed(hist, factor, trim, ho):
+    if trim is None:
+        t = ho.get_trim(hist) if len(hist) > 300 else max(hist)
+    else:
+        t = min(max(hist), trim * factor)
+    return {k: v for k, v in hist.items() if k < t}
+
+
+@pytest.mark.parametrize("name", sorted(G["cases"]))
+def test_expected_counts_against_oracle_and_reference(hip_lib, name):
+    from covest_amd import hist_steps as hs
+    from oracle import hist_oracle as ho
+    hist = _hist(name)
+    for s in G["cases"][name]["sample"]:
+        kept = _trimmed(hist, s["factor"], s["trim"], ho)
+        got = hs.expected_sampled(kept, s["factor"])
+        want = ho.sample_expected(hist, factor=s["factor"], trim=s["trim"], faithful=False)
+        assert list(got) == list(range(1, max(kept) + 1))
+        worst = 0.0
+        for j, v in want.items():
+            assert rel_err(got[j], v) <= TOL or abs(got[j] - v) < 1e-290, (name, s["factor"], j, got[j], v)
+            worst = max(worst, rel_err(got[j], v) if v > 1e-290 else 0.0)
+        print(name, "factor", s["factor"], "trim", s["trim"], "worst rel err vs oracle", worst)
+        if max(kept) / s["factor"] <= 200:  # the reference itself is right here: its own numbers
+            for j, v in s["expected"]:
+                assert rel_err(got[j], v) <= TOL, (name, s["factor"], j, got[j], v)
+            rounded = hs.sample_histogram(hist, factor=s["factor"], trim=s["trim"], rng=iter(s["uniforms"]).__next__)
+            assert [[k, v] for k, v in rounded.items()] == s["rounded"]
+
+
+def test_mass_is_conserved_at_full_size(hip_lib):
+    """Thinning keeps a k-mer occurrence with probability 1/factor: sum_j j h'[j] = sum_i i h[i] / factor for
+    both pmf branches (binomial exactly; Poisson truncated at j <= i loses < 1e-9 of it for i >= 100)."""
+    from covest_amd import hist_steps as hs
+    hist = load_hist("H10k_rep")  # 10 000 keys: 5e7 (i, j) pairs in one launch
+    for factor in (2, 7):
+        exp = hs.expected_sampled(hist, factor)
+        assert len(exp) == max(hist)
+        js = np.array(list(exp.keys()), dtype=np.float64)
+        vs = np.array(list(exp.values()))
+        occurrences = sum(i * n for i, n in hist.items())
+        assert abs((js * vs).sum() / (occurrences / factor) - 1.0) < 1e-8
+        assert (vs >= 0).all() and np.isfinite(vs).all()
+        # every source k-mer lands somewhere or vanishes: distinct k-mers can only go down
+        assert vs.sum() <= sum(hist.values()) * (1 + 1e-12)
+
+
+def test_edge_cases(hip_lib):
+    from covest_amd import hist_steps as hs
+    from covest_amd._capi import CovestHipError
+    assert hs.expected_sampled({}, 2) == {}
+    with pytest.raises(ValueError):
+        hs.expected_sampled({1: 3}, 1)
+    one = hs.expected_sampled({1: 1000}, 4)
+    assert list(one) == [1] and rel_err(one[1], 250.0) <= 1e-14
+    # a lone large count: Poisson branch, j <= i
+    big = hs.expected_sampled({300: 10}, 3)
+    assert len(big) == 300 and abs(sum(big.values()) - 10.0) < 1e-8
+    assert hs.sample_histogram({5: 1}, factor=50, rng=lambda: 0.999999) == {}  # everything rounds down to 0
+
+
+def test_auto_sampling_and_process_histogram(hip_lib):
+    """process_histogram end to end (auto sample factor, trimming): deterministic under a seeded rng, the
+    sampled coverage at or below the target, and identical to the oracle-driven flow."""
+    import random
+    from covest_amd import hist_steps as hs
+    hist = _hist("H10k_rep_le640")
+    a = hs.process_histogram(hist, 21, 100, rng=random.Random(5).random)
+    b = hs.process_histogram(hist, 21, 100, rng=random.Random(5).random)
+    assert a == b
+    ph, tail, sf, c, e = a
+    assert sf > 1 and c <= hs.AUTO_SAMPLE_TARGET_COVERAGE and 0 <= e < 1
+    assert tail >= 0 and max(ph) < max(hist)
+    # one factor lower must overshoot the target (that is what the bisection guarantees)
+    lower = hs.sample_histogram(hist, factor=sf - 1, rng=random.Random(5).random) if sf > 2 else hist
+    assert hs.compute_coverage_apx(lower, 21, 100)[0] > hs.AUTO_SAMPLE_TARGET_COVERAGE
+
+
+@pytest.mark.parametrize("kind", ["basic", "repeats"])
+def test_result_record(hip_lib, kind):
+    from covest_amd import BasicModel, RepeatsModel, print_output
+    want = G["print_output"][kind]
+    hist = load_hist("sim_c10_e0.05")
+    m = (BasicModel if kind == "basic" else RepeatsModel)(21, 100, hist, 0, max_error=8)
+    rec = print_output(hist, m, True, 2, estimated=list(want["estimated"]), guess=list(want["guess"]),
+                       orig=[None] * len(want["estimated"]), reads_size=123456789, silent=True,
+                       orig_sample_factor=3, starting_points=4, use_grid_search=True)
+    rec.pop("version")
+    assert set(rec) == set(want["fields"])
+    for key, v in want["fields"].items():
+        if isinstance(v, float):
+            assert rel_err(rec[key], v) <= TOL, (key, rec[key], v)
+        else:
+            assert rec[key] == v, (key, rec[key], v)
