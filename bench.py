@@ -265,12 +265,64 @@ def bench_kmer(args):
     counts.close()
 
 
+def bench_thin(args):
+    """Workload f3: expected histogram after down-sampling H10k_rep (10 000 bins, every
+    count 1..10000 present) by a factor of 2 -- covest/histogram.py:47-69 sample_histogram without its
+    rounding.  A step = one K-thin launch pair (partial sums + ordered reduction), inputs resident in HBM."""
+    import ctypes
+    from covest_amd import _capi
+    hist = load_hist("H10k_rep")
+    factor = 2.0
+    keys = np.array(list(hist.keys()), dtype=np.int32)
+    counts = np.array([float(v) for v in hist.values()])
+    top = int(keys.max())
+    out = np.empty(top)
+    ms = ctypes.c_double()
+    ip, dp_ = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)
+
+    def run(repeats):
+        _capi.check(_capi.lib().covest_thin_histogram_timed(
+            0, len(keys), keys.ctypes.data_as(ip), counts.ctypes.data_as(dp_), factor, top, out.ctypes.data_as(dp_),
+            repeats, ctypes.byref(ms)), "covest_thin_histogram_timed")
+        return ms.value
+
+    run(max(args.warmup, 1))
+    kernel_ms = run(args.steps)
+    pairs = float(sum(int(i) for i in keys))  # (source i, target j <= i) pairs: one pmf value each
+    flops = pairs * 29.0  # one exp at 25 flop (SURVEY 8(d) convention) + 4 for its argument and the accumulation
+    occurrences = float((keys * counts).sum())
+    if abs((np.arange(1, top + 1) * out).sum() / (occurrences / factor) - 1.0) > 1e-8:
+        raise SystemExit("K-thin: occurrences not conserved")
+    res = {
+        "metric": "thinning pmf terms/s, histogram down-sampling (covest/histogram.py sample_histogram)",
+        "value": pairs / (1e-3 * kernel_ms), "unit": "terms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": kernel_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "F3: H10k_rep.hist, %d bins (counts 1..%d), factor 2" % (len(keys), top),
+                   "kernel": "thin_partial_kernel + thin_sum_kernel", "terms": pairs},
+        "roofline": {"bound": "mfma", "pipe": "fp64 VALU (one exp per term)", "achieved": flops / (1e-3 * kernel_ms) / 1e12,
+                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (1e-3 * kernel_ms) / 1e12 / FP64_PEAK_TFLOPS,
+                     "traffic": None, "kernel": "thin_partial_kernel", "kernel_ms_avg": kernel_ms,
+                     "algorithmic_flops_per_launch": flops},
+    }
+    if args.cpu_budget > 0:
+        from oracle import hist_oracle as ho
+        n_s = 3000  # counts 1..3000: 4.5e6 terms, the reference's O(i) long-double recurrence per bin
+        t0 = time.perf_counter()
+        ho.thin_expected_c(keys[:n_s], counts[:n_s], factor, int(keys[:n_s].max()), faithful=True)
+        wall = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": float(sum(int(i) for i in keys[:n_s])) / wall, "unit": "terms/s", "cores": 1,
+                               "kind": "port", "sample": "bins 1..%d of the same histogram, C restatement of the reference's "
+                               "loops (oracle_thin_expected, long double), %.2f s" % (n_s, wall)}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5", "f3"])
     ap.add_argument("--kmer-gbp", type=float, default=1.0, help="c5: gigabases of synthetic reads")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline (0 = skip)")
@@ -281,6 +333,8 @@ def main():
     args = ap.parse_args()
     if args.workload == "c5":
         return bench_kmer(args)
+    if args.workload == "f3":
+        return bench_thin(args)
 
     import torch
     import torch.distributed as dist

@@ -27,7 +27,7 @@ EXPORTS = (
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
     "covest_kmer_create", "covest_kmer_destroy", "covest_kmer_reserve", "covest_kmer_add",
     "covest_kmer_add_device", "covest_kmer_histogram", "covest_kmer_slots", "covest_kmer_clear",
-    "covest_thin_histogram",
+    "covest_thin_histogram", "covest_thin_histogram_timed",
 )
 
 
@@ -133,6 +133,9 @@ def lib():
     L.covest_kmer_slots.argtypes = [vp]
     L.covest_thin_histogram.restype = ctypes.c_int
     L.covest_thin_histogram.argtypes = [ctypes.c_int32, i64, ctypes.POINTER(ctypes.c_int32), dp, ctypes.c_double, i64, dp]
+    L.covest_thin_histogram_timed.restype = ctypes.c_int
+    L.covest_thin_histogram_timed.argtypes = [ctypes.c_int32, i64, ctypes.POINTER(ctypes.c_int32), dp, ctypes.c_double,
+                                              i64, dp, ctypes.c_int32, dp]
     L.covest_grid_diag.restype = i64
     L.covest_grid_diag.argtypes = [vp, ctypes.POINTER(i64), i64]
     _lib = L

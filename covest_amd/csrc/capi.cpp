@@ -1216,8 +1216,8 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
     return COVEST_OK;
 }
 
-int covest_thin_histogram(int32_t device, int64_t n, const int32_t *keys, const double *counts, double factor,
-                          int64_t out_len, double *out)
+static int thin_histogram_impl(int32_t device, int64_t n, const int32_t *keys, const double *counts, double factor,
+                               int64_t out_len, double *out, int32_t repeats, double *kernel_ms)
 {
     if (n < 0 || out_len < 0 || (n > 0 && (!keys || !counts)) || (out_len > 0 && !out))
         return fail(COVEST_E_INVALID, "covest_thin_histogram: null argument");
@@ -1229,6 +1229,8 @@ int covest_thin_histogram(int32_t device, int64_t n, const int32_t *keys, const 
             return fail(COVEST_E_INVALID, "covest_thin_histogram: keys must be >= 1");
         max_key = std::max(max_key, keys[s]);
     }
+    if (kernel_ms)
+        *kernel_ms = 0.0;
     if (out_len == 0)
         return COVEST_OK;
     int n_dev = 0;
@@ -1240,12 +1242,27 @@ int covest_thin_histogram(int32_t device, int64_t n, const int32_t *keys, const 
     std::vector<double> lgam((size_t)top + 1);
     for (int64_t v = 0; v <= top; ++v)
         lgam[(size_t)v] = std::lgamma((double)v + 1.0);
-    DevBuf d_keys, d_counts, d_lgam, d_out;
+    std::vector<ThinSource> src((size_t)std::max<int64_t>(n, 1));
+    for (int64_t s = 0; s < n; ++s) {
+        ThinSource &e = src[(size_t)s];
+        e.i = keys[s];
+        e.pad = 0;
+        e.count = counts[s];
+        const double l = (double)keys[s] * (1.0 / factor); // `i * prob`, covest/histogram.py:64
+        e.a = keys[s] < 100 ? lgam[(size_t)keys[s]] : std::log(l);
+        e.b = l;
+    }
+    DevBuf d_src, d_lgam, d_partial, d_out;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     auto done = [&](int code) {
-        d_keys.release();
-        d_counts.release();
+        d_src.release();
         d_lgam.release();
+        d_partial.release();
         d_out.release();
+        if (e0)
+            (void)hipEventDestroy(e0);
+        if (e1)
+            (void)hipEventDestroy(e1);
         return code;
     };
 #define THIN_TRY(expr)                          \
@@ -1254,20 +1271,42 @@ int covest_thin_histogram(int32_t device, int64_t n, const int32_t *keys, const 
         if (e__ != hipSuccess)                  \
             return done(fail_hip(e__, #expr));  \
     } while (0)
-    THIN_TRY(d_keys.reserve((size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));
-    THIN_TRY(d_counts.reserve((size_t)std::max<int64_t>(n, 1) * sizeof(double)));
+    THIN_TRY(d_src.reserve(src.size() * sizeof(ThinSource)));
     THIN_TRY(d_lgam.reserve(lgam.size() * sizeof(double)));
+    THIN_TRY(d_partial.reserve((size_t)thin_hist_chunks() * (size_t)out_len * sizeof(double)));
     THIN_TRY(d_out.reserve((size_t)out_len * sizeof(double)));
-    if (n > 0) {
-        THIN_TRY(hipMemcpy(d_keys.ptr, keys, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
-        THIN_TRY(hipMemcpy(d_counts.ptr, counts, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    }
+    THIN_TRY(hipMemcpy(d_src.ptr, src.data(), src.size() * sizeof(ThinSource), hipMemcpyHostToDevice));
     THIN_TRY(hipMemcpy(d_lgam.ptr, lgam.data(), lgam.size() * sizeof(double), hipMemcpyHostToDevice));
-    THIN_TRY(launch_thin_hist(d_keys.as<int32_t>(), d_counts.as<double>(), n, d_lgam.as<double>(), factor, out_len,
-                              d_out.as<double>(), nullptr));
+    if (kernel_ms) {
+        THIN_TRY(hipEventCreate(&e0));
+        THIN_TRY(hipEventCreate(&e1));
+        THIN_TRY(hipEventRecord(e0, nullptr));
+    }
+    for (int32_t rep = 0; rep < std::max(repeats, 1); ++rep)
+        THIN_TRY(launch_thin_hist(d_src.as<ThinSource>(), n, d_lgam.as<double>(), factor, out_len,
+                                  d_partial.as<double>(), d_out.as<double>(), nullptr));
+    if (kernel_ms) {
+        THIN_TRY(hipEventRecord(e1, nullptr));
+        THIN_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        THIN_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *kernel_ms = (double)ms / std::max(repeats, 1);
+    }
     THIN_TRY(hipMemcpy(out, d_out.ptr, (size_t)out_len * sizeof(double), hipMemcpyDeviceToHost));
 #undef THIN_TRY
     return done(COVEST_OK);
+}
+
+int covest_thin_histogram(int32_t device, int64_t n, const int32_t *keys, const double *counts, double factor,
+                          int64_t out_len, double *out)
+{
+    return thin_histogram_impl(device, n, keys, counts, factor, out_len, out, 1, nullptr);
+}
+
+int covest_thin_histogram_timed(int32_t device, int64_t n, const int32_t *keys, const double *counts, double factor,
+                                int64_t out_len, double *out, int32_t repeats, double *kernel_ms)
+{
+    return thin_histogram_impl(device, n, keys, counts, factor, out_len, out, repeats, kernel_ms);
 }
 
 int64_t covest_grid_diag(covest_grid *g, int64_t *out, int64_t n)

@@ -58,8 +58,17 @@ hipError_t launch_kmer_histogram(const KmerTable &t, unsigned long long *hist, u
                                  hipStream_t stream);
 
 // ---- K-thin: expected histogram after down-sampling by `factor` (thin_hist.hip), SURVEY 8(f) row F3 ----
-// keys/counts: the n source bins (device); lgam[m] = ln m! for m = 0 .. max key (device); out[j-1], j = 1..out_len.
-hipError_t launch_thin_hist(const int32_t *keys, const double *counts, int64_t n, const double *lgam,
-                            double factor, int64_t out_len, double *out, hipStream_t stream);
+struct ThinSource {
+    int32_t i;     // source count
+    int32_t pad;
+    double count;  // its multiplicity h_i
+    double a;      // i < 100: ln i!            i >= 100: ln(i / factor)
+    double b;      // i < 100: unused           i >= 100: i / factor
+};
+// src[n] and lgam[m] = ln m! (m = 0 .. max(max key, out_len)) on the device; partial needs
+// thin_hist_chunks() * out_len doubles; out[j-1], j = 1..out_len.
+int thin_hist_chunks();
+hipError_t launch_thin_hist(const ThinSource *src, int64_t n, const double *lgam, double factor, int64_t out_len,
+                            double *partial, double *out, hipStream_t stream);
 
 } // namespace covest

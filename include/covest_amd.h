@@ -190,6 +190,10 @@ int covest_kmer_clear(covest_kmer *c, void *stream);
  * DESIGN.md -- and this returns the correct Poisson pmf.) */
 int covest_thin_histogram(int32_t device, int64_t n, const int32_t *keys, const double *counts, double factor,
                           int64_t out_len, double *out);
+/* The same, launched `repeats` times with inputs resident in HBM; *kernel_ms = mean device time of one
+ * launch pair (hipEvents on the launch stream).  For benchmarks. */
+int covest_thin_histogram_timed(int32_t device, int64_t n, const int32_t *keys, const double *counts, double factor,
+                                int64_t out_len, double *out, int32_t repeats, double *kernel_ms);
 
 /* PROFILING AID: with the environment variable COVEST_FACTORED_DIAG set at
  * covest_grid_create, the factored kernel accumulates s_memtime stamps per wave

@@ -512,3 +512,48 @@ int64_t oracle_first_min(const double *vals, int64_t n, double start, double *be
         *best_out = best;
     return arg;
 }
+
+/* ---- histogram down-sampling: expected counts of covest/histogram.py:47-69 ----
+ * out[j-1] += counts_s * probs_s[j-1] for every source bin s, probs as the reference builds them:
+ * keys < 100: scipy's binomial pmf (here exp of long-double lgammal terms); keys >= 100: the C
+ * extension's poisson_dist(i * prob, i), c_src/covest_poissonmodule.c:64-108, restated statement by
+ * statement in long double when faithful != 0 -- INCLUDING its defect for i * prob > 200 (the rescaling
+ * loop subtracts MAX_EXP from `l` itself) -- or the Poisson pmf (what the GPU path computes) when
+ * faithful == 0.  Same O(i) work per source bin as the reference. */
+void oracle_thin_expected(int64_t n, const int32_t *keys, const double *counts, double factor, int64_t out_len,
+                          double *out, int faithful)
+{
+    const double prob = 1.0 / factor;
+    for (int64_t j = 0; j < out_len; j++)
+        out[j] = 0.0;
+    for (int64_t s = 0; s < n; s++) {
+        const int i = keys[s];
+        const double v = counts[s];
+        if (i < 100) {
+            const long double lp = logl((long double)prob), lq = log1pl(-(long double)prob);
+            for (int j = 1; j <= i && j <= out_len; j++) {
+                const long double t = lgammal(i + 1.0L) - lgammal(j + 1.0L) - lgammal(i - j + 1.0L) + j * lp + (i - j) * lq;
+                out[j - 1] += v * (double)expl(t);
+            }
+        } else if (faithful) {
+            double l = i * prob;
+            if (l == 0 || l != l)
+                continue;
+            long double p1 = 1;
+            const long double d1 = expl(200), d2 = expl(l);
+            for (int j = 1; j <= i && j <= out_len; j++) {
+                p1 *= l / j;
+                long double p1c = p1;
+                while (l > 200 && p1c > 0) {
+                    p1c /= d1;
+                    l -= 200;
+                }
+                out[j - 1] += v * (double)(p1c / d2);
+            }
+        } else {
+            const long double l = (long double)(i * prob), ll = logl(l);
+            for (int j = 1; j <= i && j <= out_len; j++)
+                out[j - 1] += v * (double)expl(j * ll - lgammal(j + 1.0L) - l);
+        }
+    }
+}

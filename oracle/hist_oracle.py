@@ -86,6 +86,24 @@ def sample_expected(hist, factor=2, trim=None, faithful=True):
     return h
 
 
+def thin_expected_c(keys, counts, factor, out_len, faithful=False):
+    """The C twin (oracle/covest_oracle.c: oracle_thin_expected) of the double loop of sample_expected over
+    already trimmed bins: ndarray[out_len].  Used where Python loops are too slow (bench, full sizes)."""
+    import ctypes
+    from . import covest_oracle
+    L = covest_oracle.lib()
+    L.oracle_thin_expected.restype = None
+    L.oracle_thin_expected.argtypes = [ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double),
+                                       ctypes.c_double, ctypes.c_int64, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    k = np.ascontiguousarray(keys, dtype=np.int32)
+    c = np.ascontiguousarray(counts, dtype=np.float64)
+    out = np.zeros(int(out_len), dtype=np.float64)
+    L.oracle_thin_expected(len(k), k.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                           c.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), float(factor), int(out_len),
+                           out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1 if faithful else 0)
+    return out
+
+
 def round_sampled(expected, uniforms):
     """covest/histogram.py:71-75 with the uniforms `random.random()` would have returned, in order."""
     it = iter(uniforms)

@@ -66,3 +66,15 @@ def test_histogram_steps(name):
             assert _close(got[k], want[k], 1e-12), (name, s["factor"], k, got[k], want[k])
         rounded = ho.round_sampled(exp, s["uniforms"])
         assert [[k, v] for k, v in rounded.items()] == s["rounded"]
+
+
+def test_c_twin_of_the_thinning_loop():
+    """oracle_thin_expected (C, used for timing and full sizes) == the pinned Python restatement."""
+    import numpy as np
+    hist = {k: v for k, v in load_hist("H10k_rep").items() if k <= 640}
+    for faithful in (True, False):
+        want = ho.sample_expected(hist, factor=2, trim=700, faithful=faithful)
+        kept = {k: v for k, v in hist.items() if k < 640}  # what sample_expected keeps with this trim
+        got = ho.thin_expected_c(list(kept), [float(v) for v in kept.values()], 2, max(kept), faithful=faithful)
+        for j, v in want.items():
+            assert _close(float(got[j - 1]), v, 1e-13 if faithful else 1e-11), (faithful, j, got[j - 1], v)
