@@ -307,7 +307,7 @@ def bench_thin(args):
     }
     if args.cpu_budget > 0:
         from oracle import hist_oracle as ho
-        n_s = 3000  # counts 1..3000: 4.5e6 terms, the reference's O(i) long-double recurrence per bin
+        n_s = len(keys)  # every bin: 5e7 terms, the reference's O(i) long-double recurrence per bin
         t0 = time.perf_counter()
         ho.thin_expected_c(keys[:n_s], counts[:n_s], factor, int(keys[:n_s].max()), faithful=True)
         wall = time.perf_counter() - t0
