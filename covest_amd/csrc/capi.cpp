@@ -91,7 +91,7 @@ struct covest_model {
     TileView tv{};
     bool has_tiles = false;
     // scratch for covest_eval_points / covest_probabilities
-    DevBuf ws_params, ws_t, ws_out, ws_p;
+    DevBuf ws_params, ws_t, ws_out, ws_p, ws_plan;
     std::mutex lock;
 };
 
@@ -497,6 +497,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     pl.q_orig = ibase + n_qtiles + n_slots;
     pl.flat_begin = g->flat_begin;
     pl.flat_end = g->flat_end;
+    pl.list_mode = 0;
     {
         const char *skip = std::getenv("COVEST_FACTORED_SKIP"); // profiling aid, see tiles.h
         pl.skip_phases = skip ? std::atoi(skip) : 0;
@@ -511,6 +512,116 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         }
     }
     g->has_plan = pl.max_o >= 1;
+    return COVEST_OK;
+}
+
+// K-factored on a POINT LIST (tiles.h FactoredPlan::list_mode): every point is its own (c, e) workgroup with
+// a q-tile of one real column.  What a refinement step needs -- a handful of points, each a full likelihood --
+// then costs one workgroup's pass over the keys (the recurrence over o in 5 waves, a few MFMAs) instead of
+// K-direct's single wave looping over every (key, o, s).  Built per call: ~13 KB of tables per point.
+int build_list_plan(covest_model *m, int64_t n, const double *params, const std::vector<int32_t> &t_list,
+                    FactoredPlan &pl)
+{
+    constexpr int NW = 8, MU = kMaxUnits;
+    int t_max = 1;
+    for (int64_t i = 0; i < n; ++i)
+        t_max = std::max(t_max, (int)t_list[(size_t)i]);
+    const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 1024 <= 160 * 1024 ? 2 : 1;
+    const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
+    std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 2 * 64, 0.0);
+    std::vector<int32_t> q_t(n_slots, 0), q_orig(n_slots, -1), unit_tile(n_unit, -1), unit_half(n_unit, 0),
+        unit_s0(n_unit, 0), unit_len(n_unit, 0), unit_cont(n_unit, 0);
+    for (int64_t p = 0; p < n; ++p) {
+        const double *par = params + p * 5;
+        axes[(size_t)p] = par[0];
+        axes[(size_t)n + (size_t)p] = par[1];
+        const double q1 = clamp_one(m->dm, 2, par[2]), q2 = clamp_one(m->dm, 3, par[3]), q = clamp_one(m->dm, 4, par[4]);
+        const int t = t_list[(size_t)p];
+        const size_t slot = (size_t)p * 16;
+        q_t[slot] = t;
+        q_orig[slot] = 0;
+        r4[slot] = std::pow(1 - q, 4.0);
+        const int steps = t > 1 ? (t - 1 + 3) / 4 : 0;
+        // the two halves of the key tile go to the workgroup's last two waves, each cut into equal pieces
+        const int pieces = std::max(1, std::min(MU, steps / kMinPieceSteps));
+        const int piece_len = std::max(1, (steps + pieces - 1) / pieces);
+        for (int h = 0; h < 2; ++h)
+            for (int k = 0; k < pieces; ++k) {
+                const size_t at = (1 + 2 * (size_t)p + (size_t)h) * MU + (size_t)k;
+                unit_tile[at] = (int32_t)p;
+                unit_half[at] = h;
+                unit_s0[at] = k * piece_len;
+                unit_len[at] = piece_len;
+                unit_cont[at] = k > 0;
+                for (int which = 0; which < 2; ++which)
+                    for (int kq = 0; kq < 4; ++kq) // column 0 only: lanes 16 kq
+                        piece_w[(at * 2 + (size_t)which) * 64 + (size_t)(16 * kq)] =
+                            copy_number_weight_host(q1, q2, q, 1 + 4 * (unit_s0[at] + which) + kq);
+            }
+    }
+    std::vector<std::pair<const void *, size_t>> dparts = {{axes.data(), axes.size()}, {r4.data(), r4.size()},
+                                                           {piece_w.data(), piece_w.size()}};
+    std::vector<std::pair<const void *, size_t>> iparts = {
+        {q_t.data(), q_t.size()},             {q_orig.data(), q_orig.size()},       {unit_tile.data(), unit_tile.size()},
+        {unit_half.data(), unit_half.size()}, {unit_s0.data(), unit_s0.size()},     {unit_len.data(), unit_len.size()},
+        {unit_cont.data(), unit_cont.size()}};
+    size_t n_dbl = 0, n_int = 0;
+    for (auto &pr : dparts)
+        n_dbl += pr.second;
+    for (auto &pr : iparts)
+        n_int += pr.second;
+    HIP_TRY(m->ws_plan.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
+    // one staging buffer, one copy
+    std::vector<char> stage(n_dbl * sizeof(double) + n_int * sizeof(int32_t));
+    double *dbase = m->ws_plan.as<double>();
+    int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
+    std::vector<const double *> dptr;
+    std::vector<const int32_t *> iptr;
+    size_t off = 0;
+    for (auto &pr : dparts) {
+        std::memcpy(stage.data() + off * sizeof(double), pr.first, pr.second * sizeof(double));
+        dptr.push_back(dbase + off);
+        off += pr.second;
+    }
+    off = 0;
+    for (auto &pr : iparts) {
+        std::memcpy(stage.data() + n_dbl * sizeof(double) + off * sizeof(int32_t), pr.first, pr.second * sizeof(int32_t));
+        iptr.push_back(ibase + off);
+        off += pr.second;
+    }
+    HIP_TRY(hipMemcpy(m->ws_plan.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice));
+    pl = FactoredPlan{};
+    pl.c_axis = dptr[0];
+    pl.e_axis = dptr[0] + n;
+    pl.n_e = 1;
+    pl.ce_begin = 0;
+    pl.ce_end = n;
+    pl.n_q = 1;
+    pl.n_qtiles = (int32_t)n;
+    pl.max_o = t_max - 1;
+    pl.n_threads = NW * 64;
+    pl.half_units = kHalfUnits;
+    pl.n_qblocks = 1;
+    pl.ld = ld;
+    pl.n_buf = n_buf;
+    pl.q_r4 = dptr[1];
+    pl.piece_w = dptr[2];
+    pl.q_T = iptr[0];
+    pl.q_orig = iptr[1];
+    pl.unit_tile = iptr[2];
+    pl.unit_half = iptr[3];
+    pl.unit_s0 = iptr[4];
+    pl.unit_len = iptr[5];
+    pl.unit_cont = iptr[6];
+    pl.qtile_nsteps = nullptr;
+    pl.qtile_nfull = nullptr;
+    pl.q_first8 = nullptr;
+    pl.flat_begin = 0;
+    pl.flat_end = n;
+    pl.list_mode = 1;
+    pl.diag = nullptr;
+    pl.skip_phases = 0;
     return COVEST_OK;
 }
 
@@ -672,6 +783,9 @@ static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_gr
         // the factored kernel pays when many weight vectors share each (c, e)
         if (factored_ok && g->plan.n_q >= 32)
             return COVEST_KERNEL_FACTORED;
+        // a repeats-model point list: one workgroup per point (list mode) instead of one wave
+        if (!g && m->has_tiles && m->dm.kind == COVEST_MODEL_REPEATS)
+            return COVEST_KERNEL_FACTORED;
         return COVEST_KERNEL_DIRECT;
     case COVEST_KERNEL_DIRECT:
         return COVEST_KERNEL_DIRECT;
@@ -680,7 +794,7 @@ static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_gr
             return COVEST_KERNEL_RECUR;
         return fail(COVEST_E_INVALID, "recurrence kernel needs the basic model, max_error 8 and keys in 1..16384");
     case COVEST_KERNEL_FACTORED:
-        if (factored_ok)
+        if (factored_ok || (!g && m->has_tiles && m->dm.kind == COVEST_MODEL_REPEATS))
             return COVEST_KERNEL_FACTORED;
         return fail(COVEST_E_INVALID, "factored kernel needs a dense repeats-model grid, max_error 8, keys in "
                                       "1..16384 and threshold_o <= 513");
@@ -736,6 +850,52 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         HIP_TRY(m->ws_t.reserve((size_t)n * sizeof(int32_t)));
         HIP_TRY(hipMemcpy(m->ws_t.ptr, t.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
         src.t_list = m->ws_t.as<int32_t>();
+    }
+    if (kern == COVEST_KERNEL_FACTORED) {
+        // repeats model point list: one workgroup per point (build_list_plan).  A point's kernel must not
+        // depend on what else is in the call (refinements compare values across calls), so the points whose
+        // threshold_o does not fit a workgroup (or is 1: nothing to sum) go to K-direct on their own.
+        std::vector<int32_t> t((size_t)n);
+        std::vector<int64_t> fits, rest;
+        for (int64_t i = 0; i < n; ++i) {
+            t[(size_t)i] = threshold_for_point(m, params + i * P);
+            (t[(size_t)i] - 1 >= 1 && t[(size_t)i] - 1 <= 512 ? fits : rest).push_back(i);
+        }
+        if (!rest.empty() && kernel == COVEST_KERNEL_FACTORED)
+            return fail(COVEST_E_INVALID, "factored kernel: threshold_o must be in 2..513 for every point");
+        if (!fits.empty()) {
+            std::vector<double> sub_par(fits.size() * 5);
+            std::vector<int32_t> sub_t(fits.size());
+            for (size_t k = 0; k < fits.size(); ++k) {
+                std::memcpy(&sub_par[k * 5], params + fits[k] * 5, 5 * sizeof(double));
+                sub_t[k] = t[(size_t)fits[k]];
+            }
+            FactoredPlan pl;
+            rc = build_list_plan(m, (int64_t)fits.size(), sub_par.data(), sub_t, pl);
+            if (rc != COVEST_OK)
+                return rc;
+            HIP_TRY(launch_ll_factored(m->dm, m->tv, pl, m->ws_out.as<double>(), nullptr));
+            std::vector<double> got(fits.size());
+            HIP_TRY(hipMemcpy(got.data(), m->ws_out.ptr, fits.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < fits.size(); ++k)
+                out_ll[fits[k]] = got[k];
+        }
+        if (!rest.empty()) {
+            std::vector<double> sub_par(rest.size() * 5);
+            std::vector<int32_t> sub_t(rest.size());
+            for (size_t k = 0; k < rest.size(); ++k) {
+                std::memcpy(&sub_par[k * 5], params + rest[k] * 5, 5 * sizeof(double));
+                sub_t[k] = t[(size_t)rest[k]];
+            }
+            HIP_TRY(hipMemcpy(m->ws_params.ptr, sub_par.data(), sub_par.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(m->ws_t.ptr, sub_t.data(), sub_t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(launch_ll(m, COVEST_KERNEL_DIRECT, src, (int64_t)rest.size(), m->ws_out.as<double>(), nullptr, nullptr));
+            std::vector<double> got(rest.size());
+            HIP_TRY(hipMemcpy(got.data(), m->ws_out.ptr, rest.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < rest.size(); ++k)
+                out_ll[rest[k]] = got[k];
+        }
+        return COVEST_OK;
     }
     HIP_TRY(launch_ll(m, kern, src, n, m->ws_out.as<double>(), nullptr, nullptr));
     HIP_TRY(hipMemcpy(out_ll, m->ws_out.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));

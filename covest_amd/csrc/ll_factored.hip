@@ -93,8 +93,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 
     // ---- the (c, e) of this workgroup ----
     const int64_t ce = plan.ce_begin + blockIdx.x;
-    const int64_t ic = ce / plan.n_e;
-    const int64_t ie = ce - ic * plan.n_e;
+    // (list mode: workgroup i takes point i of a point list -- its own (c, e) AND its own single weight
+    // vector, see tiles.h FactoredPlan::list_mode)
+    const bool list = plan.list_mode != 0;
+    const int64_t ic = list ? ce : ce / plan.n_e;
+    const int64_t ie = list ? ce : ce - ic * plan.n_e;
     double par[kMaxParams] = {plan.c_axis[ic], plan.e_axis[ie], 0, 0, 0};
     clamp_point<2>(m, par);
     const bool finite = isfinite(par[0]) && isfinite(par[1]);
@@ -127,7 +130,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     double r4[MU], llacc[MU];
     uint64_t dead[MU]; // lanes that met a p_j <= 0 with h_j != 0
     CompSum spacc[MU];
-    const int slot_base = ((int)blockIdx.y * NW + wave) * MU;
+    // wave w's block of MU slots in the unit tables
+    auto wave_block = [&](int w) -> int {
+        if (list) // block 0 is empty (waves with no unit); point i owns blocks 1 + 2 i and 2 + 2 i, for the last two waves
+            return w >= NW - 2 ? 1 + 2 * (int)blockIdx.x + (w - (NW - 2)) : 0;
+        return (int)blockIdx.y * NW + w;
+    };
+    const int slot_base = wave_block(wave) * MU;
 #pragma unroll
     for (int k = 0; k < MU; ++k) {
         const int at = slot_base + k;
@@ -356,14 +365,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // one thread per (wave, unit, q) entry of a half-0 unit; it looks up the half-1 partner
     for (int e = tid; e < NW * MU * 16; e += NT) {
         const int w = e / (MU * 16), k = (e / 16) % MU, c = e & 15;
-        const int at = ((int)blockIdx.y * NW + w) * MU + k;
+        const int at = wave_block(w) * MU + k;
         const int qt = plan.unit_tile[at];
         if (qt < 0 || plan.unit_half[at] != 0 || plan.unit_cont[at])
             continue;
         int pe = -1; // the unit with the same tile and half 1 (always in the same workgroup)
         for (int w2 = 0; w2 < NW && pe < 0; ++w2)
             for (int k2 = 0; k2 < MU; ++k2) {
-                const int at2 = ((int)blockIdx.y * NW + w2) * MU + k2;
+                const int at2 = wave_block(w2) * MU + k2;
                 if (plan.unit_tile[at2] == qt && plan.unit_half[at2] == 1 && !plan.unit_cont[at2]) {
                     pe = (w2 * MU + k2) * 16 + c;
                     break;

@@ -98,6 +98,10 @@ struct FactoredPlan {
     const double *q_first8;        // [8][n_qtiles*16] b_o, o = 1..8   (covest/models.py:193-208)
     const double *q_r4;            // [n_qtiles*16] (1 - q)^4
     int64_t flat_begin, flat_end;  // flat indices whose LL is written (ragged block ends)
+    int32_t list_mode;             // 1: a POINT LIST, not a grid: workgroup i (gridDim.y == 1) evaluates point i =
+                                   //   (c_axis[i], e_axis[i]) with the single weight vector of q-tile i (slot 16 i;
+                                   //   n_q == 1).  The unit tables then hold one empty wave block followed by two
+                                   //   blocks per point, for the workgroup's last two waves (ll_factored.hip)
     long long *diag;               // PROFILING ONLY (env COVEST_FACTORED_DIAG): per-wave s_memtime sums [wg][wave][8]
     int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
 };

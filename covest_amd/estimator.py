@@ -11,9 +11,20 @@ parameter space and the model's: optimiser vectors carry the error rate multipli
 
 What differs is how the likelihood gets evaluated: every call lands on the HIP kernels, and the
 grid search asks for a whole grid at once (`negll_grid`) instead of mapping pickled calls over a
-process pool.  Multi-start refinements run one after the other in-process (each is a stream of
-single-point GPU evaluations; a pool would only add pickling).
+process pool.
+
+Refinement.  The reference hands scipy's L-BFGS-B a scalar objective, so
+scipy differentiates it numerically: P + 1 separate evaluations per gradient, and `-sp N` starts run
+in N worker processes.  Here one gradient is ONE launch -- the point and its P finite-difference
+neighbours go to the GPU together (`negll_points`) -- and the N starts advance in lock step, their
+requests merged into one launch per round (`_LockStep`).  Which neighbours scipy would visit (step
+1e-8, flipped at an upper bound, ...) is not re-derived: scipy's own `approx_derivative` is run twice,
+first against a recorder to learn the points, then against the batch's values, so the gradient -- and
+with it every iterate -- is bit-identical to what `minimize(..., jac=None)` computes from the same
+likelihood values.  The kernels are deterministic per point, whatever else shares the launch.
 """
+import threading
+
 import numpy as np
 
 from . import constants
@@ -23,10 +34,11 @@ from .grid import DenseGrid, initial_grid, optimize_grid
 class CoverageEstimator:
     ERROR_RATE = 1  # index of the parameter that err_scale applies to
 
-    def __init__(self, model, err_scale=1, fix=None):
+    def __init__(self, model, err_scale=1, fix=None, batched=True):
         self.model = model
         self.fix = fix
         self.err_scale = err_scale
+        self.batched = batched
         bounds = [tuple(b) for b in model.bounds]
         lo, hi = bounds[self.ERROR_RATE]
         bounds[self.ERROR_RATE] = (lo, hi * err_scale)
@@ -63,18 +75,56 @@ class CoverageEstimator:
         finally:
             grid.close()
 
+    def negll_points(self, xs):
+        """likelihood_f of several optimiser-space vectors in one launch: ndarray."""
+        pts = np.array([self._model_args(x) for x in xs], dtype=np.float64)
+        return -self.model.loglikelihood_points(pts)
+
     # ------------------------------------------------------------------ refinement
-    def _optimize(self, start):
-        """One bounded quasi-Newton refinement with finite-difference gradients, the reference's
-        choice (method and options of covest/covest.py:33-39)."""
+    FD_STEP = 1e-8  # scipy's default `eps` of L-BFGS-B, what the reference runs with
+
+    def _value_and_gradient(self, x, evaluate):
+        """(f, grad f) as scipy's 2-point scheme defines them, all P + 1 evaluations through one call of
+        `evaluate(list of points)`."""
+        from scipy.optimize._numdiff import approx_derivative
+        x = np.asarray(x, dtype=np.float64)
+        lo = np.array([-np.inf if b[0] is None else b[0] for b in self.bounds])
+        hi = np.array([np.inf if b[1] is None else b[1] for b in self.bounds])
+        visited = []
+
+        def record(z):
+            visited.append(np.array(z, dtype=np.float64))
+            return 0.0
+
+        approx_derivative(record, x, method='2-point', abs_step=self.FD_STEP, f0=0.0, bounds=(lo, hi))
+        values = evaluate([x] + visited)
+        replay = iter(values[1:])
+        grad = approx_derivative(lambda z: next(replay), x, method='2-point', abs_step=self.FD_STEP,
+                                 f0=values[0], bounds=(lo, hi))
+        return float(values[0]), np.asarray(grad, dtype=np.float64)
+
+    def _optimize(self, start, evaluate=None):
+        """One bounded quasi-Newton refinement, the reference's choice (method and options of
+        covest/covest.py:33-39).  batched=False is the reference's call pattern (scipy differentiates
+        a scalar objective itself); the default feeds scipy value and gradient from one launch."""
         from scipy.optimize import minimize
-        return minimize(self.likelihood_f, start, method=constants.OPTIMIZATION_METHOD,
-                        bounds=self.bounds, options={'disp': False})
+        if not self.batched:
+            return minimize(self.likelihood_f, start, method=constants.OPTIMIZATION_METHOD,
+                            bounds=self.bounds, options={'disp': False})
+        evaluate = evaluate or self.negll_points
+        return minimize(lambda x: self._value_and_gradient(x, evaluate), start, jac=True,
+                        method=constants.OPTIMIZATION_METHOD, bounds=self.bounds, options={'disp': False})
 
     def _best_of(self, starts):
-        """Refine every start; keep the first result with the strictly smallest objective."""
+        """Refine every start; keep the first result with the strictly smallest objective
+        (covest/covest.py:60-69).  Batched: the starts run as threads in lock step."""
+        starts = list(starts)
+        if self.batched and len(starts) > 1:
+            results = _LockStep(self.negll_points, len(starts)).map(self._optimize, starts)
+        else:
+            results = [self._optimize(s) for s in starts]
         best = None
-        for res in map(self._optimize, starts):
+        for res in results:
             if best is None or best.fun > res.fun:
                 best = res
         return best
@@ -97,3 +147,78 @@ class CoverageEstimator:
         x = list(x)
         x[self.ERROR_RATE] /= self.err_scale
         return x, success
+
+
+class _LockStep:
+    """Merge the evaluation requests of N concurrently running refinements into one launch per round.
+
+    Every client thread calls `evaluate(points)` and blocks; when all clients still running have a
+    request pending, the last one to arrive evaluates the concatenation and hands each its slice.  A
+    client that finishes leaves the round (and, if everybody else is already waiting, fires it)."""
+
+    def __init__(self, evaluate_batch, n_clients):
+        self._evaluate_batch = evaluate_batch
+        self._active = n_clients
+        self._cv = threading.Condition()
+        self._pending = {}   # client id -> list of points
+        self._answers = {}   # client id -> ndarray
+        self._failure = None
+        self.rounds = 0
+        self.points = 0
+
+    def _fire(self):
+        """Called with the lock held and every active client pending."""
+        order = sorted(self._pending)
+        merged = [p for cid in order for p in self._pending[cid]]
+        try:
+            values = np.asarray(self._evaluate_batch(merged))
+        except BaseException as exc:  # hand the failure to every waiter
+            self._failure = exc
+            values = np.full(len(merged), np.nan)
+        self.rounds += 1
+        self.points += len(merged)
+        at = 0
+        for cid in order:
+            n = len(self._pending[cid])
+            self._answers[cid] = values[at:at + n]
+            at += n
+        self._pending.clear()
+        self._cv.notify_all()
+
+    def _evaluate(self, cid, points):
+        with self._cv:
+            self._pending[cid] = list(points)
+            if len(self._pending) == self._active:
+                self._fire()
+            while cid not in self._answers:
+                self._cv.wait()
+            if self._failure is not None:
+                raise self._failure
+            return self._answers.pop(cid)
+
+    def _leave(self):
+        with self._cv:
+            self._active -= 1
+            if self._active > 0 and len(self._pending) == self._active:
+                self._fire()
+
+    def map(self, refine, starts):
+        results = [None] * len(starts)
+        errors = []
+
+        def client(cid):
+            try:
+                results[cid] = refine(starts[cid], lambda pts: self._evaluate(cid, pts))
+            except BaseException as exc:
+                errors.append(exc)
+            finally:
+                self._leave()
+
+        threads = [threading.Thread(target=client, args=(cid,), daemon=True) for cid in range(len(starts))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results
