@@ -344,7 +344,7 @@ def bench_refine(args):
         "ms_per_step": 1e3 * batched_s, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "F2: RepeatsModel k=21 r=100, H10k_rep.hist (981 bins evaluated), 20 starts "
-                               "(initial_grid, seed 20240521)", "kernel": "ll_factored in list mode, one workgroup per point (ll_direct for threshold_o > 513)",
+                               "(initial_grid, seed 20240521)", "kernel": "ll_factored in list mode: one workgroup per point, chunks of 512 copy numbers beyond that",
                    "evaluations": evals, "launch_rounds": lock.rounds, "points_per_round": lock.points / lock.rounds,
                    "best_negll": float(best.fun), "best_x": [float(v) for v in best.x]},
     }

@@ -91,7 +91,7 @@ struct covest_model {
     TileView tv{};
     bool has_tiles = false;
     // scratch for covest_eval_points / covest_probabilities
-    DevBuf ws_params, ws_t, ws_out, ws_p, ws_plan;
+    DevBuf ws_params, ws_t, ws_out, ws_p, ws_plan, ws_plan2, ws_partial, ws_items;
     std::mutex lock;
 };
 
@@ -498,6 +498,8 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     pl.flat_begin = g->flat_begin;
     pl.flat_end = g->flat_end;
     pl.list_mode = 0;
+    pl.item_obase = nullptr;
+    pl.partial = nullptr;
     {
         const char *skip = std::getenv("COVEST_FACTORED_SKIP"); // profiling aid, see tiles.h
         pl.skip_phases = skip ? std::atoi(skip) : 0;
@@ -519,13 +521,16 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
 // a q-tile of one real column.  What a refinement step needs -- a handful of points, each a full likelihood --
 // then costs one workgroup's pass over the keys (the recurrence over o in 5 waves, a few MFMAs) instead of
 // K-direct's single wave looping over every (key, o, s).  Built per call: ~13 KB of tables per point.
+// An item is a point (o_base 0, list_mode 1) or a chunk of a point's copy numbers (list_mode 2): params of the
+// point, threshold_o of the point, copy numbers before the chunk.
 int build_list_plan(covest_model *m, int64_t n, const double *params, const std::vector<int32_t> &t_list,
-                    FactoredPlan &pl)
+                    const std::vector<int32_t> *o_base_list, DevBuf &buf, FactoredPlan &pl)
 {
     constexpr int NW = 8, MU = kMaxUnits;
-    int t_max = 1;
+    auto o_base_of = [&](int64_t i) { return o_base_list ? (*o_base_list)[(size_t)i] : 0; };
+    int t_max = 1; // largest LOCAL threshold: copy numbers of an item are o_base + 1 .. o_base + t_local - 1
     for (int64_t i = 0; i < n; ++i)
-        t_max = std::max(t_max, (int)t_list[(size_t)i]);
+        t_max = std::max(t_max, std::min(513, (int)t_list[(size_t)i] - o_base_of(i)));
     const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
     const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 1024 <= 160 * 1024 ? 2 : 1;
     const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
@@ -537,7 +542,9 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
         axes[(size_t)p] = par[0];
         axes[(size_t)n + (size_t)p] = par[1];
         const double q1 = clamp_one(m->dm, 2, par[2]), q2 = clamp_one(m->dm, 3, par[3]), q = clamp_one(m->dm, 4, par[4]);
-        const int t = t_list[(size_t)p];
+        const int ob = o_base_of(p);
+        // local threshold: the kernel's lanes count from the chunk's start, and a chunk ends after 512 copy numbers
+        const int t = std::min(513, std::max(0, (int)t_list[(size_t)p] - ob));
         const size_t slot = (size_t)p * 16;
         q_t[slot] = t;
         q_orig[slot] = 0;
@@ -557,7 +564,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
                 for (int which = 0; which < 2; ++which)
                     for (int kq = 0; kq < 4; ++kq) // column 0 only: lanes 16 kq
                         piece_w[(at * 2 + (size_t)which) * 64 + (size_t)(16 * kq)] =
-                            copy_number_weight_host(q1, q2, q, 1 + 4 * (unit_s0[at] + which) + kq);
+                            copy_number_weight_host(q1, q2, q, ob + 1 + 4 * (unit_s0[at] + which) + kq);
             }
     }
     std::vector<std::pair<const void *, size_t>> dparts = {{axes.data(), axes.size()}, {r4.data(), r4.size()},
@@ -571,10 +578,10 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
         n_dbl += pr.second;
     for (auto &pr : iparts)
         n_int += pr.second;
-    HIP_TRY(m->ws_plan.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
+    HIP_TRY(buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
     // one staging buffer, one copy
     std::vector<char> stage(n_dbl * sizeof(double) + n_int * sizeof(int32_t));
-    double *dbase = m->ws_plan.as<double>();
+    double *dbase = buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
     std::vector<const double *> dptr;
     std::vector<const int32_t *> iptr;
@@ -590,7 +597,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
         iptr.push_back(ibase + off);
         off += pr.second;
     }
-    HIP_TRY(hipMemcpy(m->ws_plan.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(buf.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice));
     pl = FactoredPlan{};
     pl.c_axis = dptr[0];
     pl.e_axis = dptr[0] + n;
@@ -620,6 +627,8 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     pl.flat_begin = 0;
     pl.flat_end = n;
     pl.list_mode = 1;
+    pl.item_obase = nullptr;
+    pl.partial = nullptr;
     pl.diag = nullptr;
     pl.skip_phases = 0;
     return COVEST_OK;
@@ -752,6 +761,10 @@ void covest_model_destroy(covest_model *m)
     m->ws_t.release();
     m->ws_out.release();
     m->ws_p.release();
+    m->ws_plan.release();
+    m->ws_plan2.release();
+    m->ws_partial.release();
+    m->ws_items.release();
     delete m;
 }
 
@@ -852,17 +865,18 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         src.t_list = m->ws_t.as<int32_t>();
     }
     if (kern == COVEST_KERNEL_FACTORED) {
-        // repeats model point list: one workgroup per point (build_list_plan).  A point's kernel must not
-        // depend on what else is in the call (refinements compare values across calls), so the points whose
-        // threshold_o does not fit a workgroup (or is 1: nothing to sum) go to K-direct on their own.
+        // repeats model point list: one workgroup per point (build_list_plan); a point whose threshold_o
+        // exceeds a workgroup's 512 lanes is cut into chunks of 512 copy numbers, one workgroup each, and
+        // finished by ll_finish_partials.  A point's route depends on its own threshold_o only -- never on
+        // what else is in the call (refinements compare values across calls).  threshold_o == 1 (nothing to
+        // sum) goes to K-direct.
         std::vector<int32_t> t((size_t)n);
-        std::vector<int64_t> fits, rest;
+        std::vector<int64_t> fits, big, rest;
         for (int64_t i = 0; i < n; ++i) {
             t[(size_t)i] = threshold_for_point(m, params + i * P);
-            (t[(size_t)i] - 1 >= 1 && t[(size_t)i] - 1 <= 512 ? fits : rest).push_back(i);
+            const int o_max = t[(size_t)i] - 1;
+            (o_max < 1 ? rest : o_max <= 512 ? fits : big).push_back(i);
         }
-        if (!rest.empty() && kernel == COVEST_KERNEL_FACTORED)
-            return fail(COVEST_E_INVALID, "factored kernel: threshold_o must be in 2..513 for every point");
         if (!fits.empty()) {
             std::vector<double> sub_par(fits.size() * 5);
             std::vector<int32_t> sub_t(fits.size());
@@ -871,7 +885,7 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
                 sub_t[k] = t[(size_t)fits[k]];
             }
             FactoredPlan pl;
-            rc = build_list_plan(m, (int64_t)fits.size(), sub_par.data(), sub_t, pl);
+            rc = build_list_plan(m, (int64_t)fits.size(), sub_par.data(), sub_t, nullptr, m->ws_plan, pl);
             if (rc != COVEST_OK)
                 return rc;
             HIP_TRY(launch_ll_factored(m->dm, m->tv, pl, m->ws_out.as<double>(), nullptr));
@@ -879,6 +893,46 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
             HIP_TRY(hipMemcpy(got.data(), m->ws_out.ptr, fits.size() * sizeof(double), hipMemcpyDeviceToHost));
             for (size_t k = 0; k < fits.size(); ++k)
                 out_ll[fits[k]] = got[k];
+        }
+        if (!big.empty()) {
+            std::vector<double> item_par, point_ce(2 * big.size());
+            std::vector<int32_t> item_t, item_ob, first_item(big.size() + 1, 0);
+            for (size_t k = 0; k < big.size(); ++k) {
+                const double *par = params + big[k] * 5;
+                point_ce[2 * k] = par[0];
+                point_ce[2 * k + 1] = par[1];
+                for (int ob = 0; ob < t[(size_t)big[k]] - 1; ob += 512) {
+                    item_par.insert(item_par.end(), par, par + 5);
+                    item_t.push_back(t[(size_t)big[k]]);
+                    item_ob.push_back(ob);
+                }
+                first_item[k + 1] = (int32_t)item_t.size();
+            }
+            const int64_t n_items = (int64_t)item_t.size();
+            const size_t n_keys = (size_t)m->tv.n_tiles * kTileBins;
+            FactoredPlan pl;
+            rc = build_list_plan(m, n_items, item_par.data(), item_t, &item_ob, m->ws_plan2, pl);
+            if (rc != COVEST_OK)
+                return rc;
+            HIP_TRY(m->ws_partial.reserve((size_t)n_items * n_keys * sizeof(double)));
+            const size_t items_bytes = (size_t)n_items * sizeof(int32_t), first_bytes = first_item.size() * sizeof(int32_t);
+            const size_t int_bytes = ((items_bytes + first_bytes + 7) / 8) * 8;
+            HIP_TRY(m->ws_items.reserve(int_bytes + point_ce.size() * sizeof(double)));
+            char *ib = m->ws_items.as<char>();
+            HIP_TRY(hipMemcpy(ib, item_ob.data(), items_bytes, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(ib + items_bytes, first_item.data(), first_bytes, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(ib + int_bytes, point_ce.data(), point_ce.size() * sizeof(double), hipMemcpyHostToDevice));
+            pl.list_mode = 2;
+            pl.item_obase = reinterpret_cast<const int32_t *>(ib);
+            pl.partial = m->ws_partial.as<double>();
+            HIP_TRY(launch_ll_factored(m->dm, m->tv, pl, m->ws_out.as<double>(), nullptr));
+            HIP_TRY(launch_ll_finish_partials(m->dm, m->tv, pl.partial, reinterpret_cast<const int32_t *>(ib + items_bytes),
+                                              reinterpret_cast<const double *>(ib + int_bytes), (int64_t)big.size(),
+                                              m->ws_out.as<double>(), nullptr));
+            std::vector<double> got(big.size());
+            HIP_TRY(hipMemcpy(got.data(), m->ws_out.ptr, big.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < big.size(); ++k)
+                out_ll[big[k]] = got[k];
         }
         if (!rest.empty()) {
             std::vector<double> sub_par(rest.size() * 5);

@@ -24,6 +24,12 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
 hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                               double *out_ll, hipStream_t stream);
 
+// Chunked point list (tiles.h FactoredPlan::list_mode 2): combine the chunks' shares of p_j per point and
+// take the logs.  first_item[n_points + 1] delimits each point's chunks; point_ce[2 n_points] = (c, e).
+hipError_t launch_ll_finish_partials(const DevModel &m, const TileView &tv, const double *partial,
+                                     const int32_t *first_item, const double *point_ce, int64_t n_points,
+                                     double *out_ll, hipStream_t stream);
+
 // (min -LL, lowest index) over ll[n]: two-stage reduction (argmin.hip).
 // partial_val/partial_idx need kArgminBlocks entries; result[0] = {min, bits of idx}.
 constexpr int kArgminBlocks = 256;

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // ---- phase-A state: lane = copy number o = tid + 1 ----
     const bool wave_builds = wave * kWave < plan.max_o; // wave-uniform
     StreamSet<8> st;
-    st.init(m, lam, tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o);
+    const int o_base = plan.list_mode == 2 ? plan.item_obase[blockIdx.x] : 0; // chunked point list: tiles.h
+    st.init(m, lam, o_base + tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o);
     const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
     if (tid < 64)
         Gs[(size_t)plan.n_buf * kTileBins * LD + tid] = 0.0; // the slack behind the buffers (see launch)
@@ -297,6 +298,15 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
+            if (plan.list_mode == 2) { // a chunk of a point's copy numbers: hand p_j's share on (column 0 only)
+                if (qslot[k] >= 0 && !cont[k] && col == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        plan.partial[((int64_t)blockIdx.x * tv.n_tiles + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] =
+                            acc[k][r];
+                }
+                continue;
+            }
             if (qslot[k] >= 0 && !cont[k] && !(plan.skip_phases & 4)) { // wave-uniform: first slot of a unit
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -329,6 +339,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         d[4] = dg_b0;
     }
 #undef STAMP
+    if (plan.list_mode == 2)
+        return; // (wave-uniform for the whole workgroup) the chunks are combined by ll_finish_partials
     // ---- per-q results: sum the 4 row groups of the accumulator layout, then the two
     //      halves of each q-tile (they may live on different waves) through LDS ----
     double *part_ll = Gs;                               // [NW][MU][16]
@@ -402,6 +414,51 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
 }
 
+// Chunked point list (tiles.h list_mode 2): one wave per point adds the chunks' shares of p_j in chunk order
+// and takes the logs.  LL = sum_j h_j log p_j + tail log(1 - sp), covest/models.py:100-107.
+__global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, const int32_t n_tiles,
+                                                           const double *__restrict__ tile_dbl,
+                                                           const int32_t *__restrict__ tile_int,
+                                                           const double *__restrict__ partial,
+                                                           const int32_t *__restrict__ first_item,
+                                                           const double *__restrict__ point_ce, double *__restrict__ out_ll)
+{
+    const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int c0 = first_item[p], c1 = first_item[p + 1];
+    const int64_t n_keys = (int64_t)n_tiles * kTileBins;
+    double ll = 0.0;
+    bool dead = false;
+    CompSum sp = {0.0, 0.0};
+    for (int64_t key = lane; key < n_keys; key += kWave) {
+        double pj = 0.0;
+        for (int c = c0; c < c1; ++c)
+            pj += partial[(int64_t)c * n_keys + key];
+        const double h = tv.cnt[key];
+        if (m.tail != 0.0 && tv.in_sp[key] != 0.0)
+            sp.add(pj);
+        if (h != 0.0) {
+            dead |= pj <= 0.0; // utils.safe_log
+            ll = fma(h, log(pj > 0.0 ? pj : 1.0), ll);
+        }
+    }
+    ll = wave_sum(ll);
+    double tail_term = 0.0;
+    if (m.tail != 0.0) {
+        double s = wave_comp_sum(sp);
+        if (!(s < 1.0))
+            s = 1.0;
+        if (s < 1.0)
+            tail_term = m.tail * log(1.0 - s);
+    }
+    if (__ballot(dead))
+        ll = isnan(ll) ? ll : -INFINITY;
+    double par[kMaxParams] = {point_ce[2 * p], point_ce[2 * p + 1], 0, 0, 0};
+    clamp_point<2>(m, par);
+    if (lane == 0)
+        out_ll[p] = isfinite(par[0]) && isfinite(par[1]) ? ll + tail_term : NAN;
+}
+
 template <int NT, int HU, bool TAIL>
 hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                           double *out_ll, hipStream_t stream)
@@ -443,6 +500,17 @@ hipError_t launch_nt(const DevModel &m, const TileView &tv, const FactoredPlan &
 }
 
 } // namespace
+
+hipError_t launch_ll_finish_partials(const DevModel &m, const TileView &tv, const double *partial,
+                                     const int32_t *first_item, const double *point_ce, int64_t n_points,
+                                     double *out_ll, hipStream_t stream)
+{
+    if (n_points <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(ll_finish_partials, dim3((unsigned)n_points), dim3(kWave), 0, stream, m, tv.n_tiles, tv.dbl_base,
+                       tv.int_base, partial, first_item, point_ce, out_ll);
+    return hipGetLastError();
+}
 
 hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                               double *out_ll, hipStream_t stream)

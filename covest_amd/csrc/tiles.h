@@ -98,10 +98,16 @@ struct FactoredPlan {
     const double *q_first8;        // [8][n_qtiles*16] b_o, o = 1..8   (covest/models.py:193-208)
     const double *q_r4;            // [n_qtiles*16] (1 - q)^4
     int64_t flat_begin, flat_end;  // flat indices whose LL is written (ragged block ends)
-    int32_t list_mode;             // 1: a POINT LIST, not a grid: workgroup i (gridDim.y == 1) evaluates point i =
+    int32_t list_mode;             // 1, 2: a POINT LIST, not a grid: workgroup i (gridDim.y == 1) evaluates ITEM i =
                                    //   (c_axis[i], e_axis[i]) with the single weight vector of q-tile i (slot 16 i;
                                    //   n_q == 1).  The unit tables then hold one empty wave block followed by two
-                                   //   blocks per point, for the workgroup's last two waves (ll_factored.hip)
+                                   //   blocks per item, for the workgroup's last two waves (ll_factored.hip).
+                                   //   1: an item is a whole point, its LL is written.  2: an item is a CHUNK of a
+                                   //   point's copy numbers, o = item_obase[i] + 1 .. + 512 (threshold_o beyond one
+                                   //   workgroup's lanes); the workgroup stores its share of p_j to `partial` and
+                                   //   ll_finish_partials adds the chunks and takes the logs
+    const int32_t *item_obase;     // [items] list_mode 2: copy numbers before this chunk (multiple of 512); else NULL
+    double *partial;               // [items][n_tiles * 32] list_mode 2: sum over the chunk's o of b_o G[o][key]
     long long *diag;               // PROFILING ONLY (env COVEST_FACTORED_DIAG): per-wave s_memtime sums [wg][wave][8]
     int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
 };

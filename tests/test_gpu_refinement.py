@@ -53,3 +53,46 @@ def test_lock_step_multi_start(hip_lib):
     got, ok = est.compute_coverage([10.0, 0.05, 0.8, 0.5, 0.3], starting_points=6)
     want = min(seq, key=lambda r: r.fun)
     assert list(got) == list(want.x) and ok == want.success
+
+
+def test_point_lists_of_any_threshold(hip_lib, oracle):
+    """A repeats-model point list goes to K-factored in list mode: one workgroup per point, and a point whose
+    threshold_o exceeds the workgroup's 512 lanes in chunks of 512 copy numbers.  Against K-direct (pinned to
+    the reference elsewhere) on the 10 000-key histogram, against the oracle where it finishes in seconds,
+    and independent of what else shares the call."""
+    from covest_amd import RepeatsModel
+    hist = load_hist("H10k_rep")
+    m = RepeatsModel(21, 100, hist, 0, max_error=8)
+    pts = np.array([
+        [25.0, 0.02, 0.6, 0.5, 0.1],        # T ~ 140
+        [25.0, 0.02, 0.6, 0.5, 0.03],       # T ~ 480: one workgroup, nearly full
+        [25.0, 0.02, 0.6, 0.5, 0.0254],     # T = 514: two chunks, the second holds one copy number
+        [25.0, 0.02, 0.6, 0.5, 0.02],       # two chunks
+        [18.0, 0.05, 0.3, 0.2, 0.01],       # T ~ 1500
+        [30.0, 0.01, 0.9, 0.9, 0.002],      # T ~ 6000
+        [22.0, 0.03, 0.5, 0.5, 1e-6],       # b_o never reaches the threshold: T = max(hist) = 10000
+        [25.0, 0.02, 1.0, 0.0, 0.5],        # q1 = 1: T = 2
+        [25.0, 0.02, 0.6, 0.5, 1.0],        # q = 1
+    ])
+    T = m.get_hist_threshold_values(pts[:, 2:5])
+    assert T.max() == 10000 and (T > 513).sum() >= 4 and (T <= 513).sum() >= 3 and ((T > 513) & (T < 540)).any(), T
+    auto = m.loglikelihood_points(pts)
+    direct = m.loglikelihood_points(pts, kernel="direct")
+    for a, b, t in zip(auto, direct, T):
+        assert rel_err(float(a), float(b)) <= 1e-11, (t, a, b)
+    # batch composition does not matter: singly, reversed, duplicated
+    assert np.array_equal(auto, np.array([m.loglikelihood_points(pts[i:i + 1])[0] for i in range(len(pts))]))
+    assert np.array_equal(auto[::-1], m.loglikelihood_points(pts[::-1].copy()))
+    # with a tail, on a small histogram the oracle can afford (T up to max(hist) = 700)
+    rng = np.random.default_rng(5)
+    small = {j: int(v) for j, v in zip(range(1, 120), rng.integers(1, 5000, size=119))}
+    small[700] = 2
+    for tail in (0, 77):
+        ms = RepeatsModel(21, 100, small, tail, max_error=8)
+        om = oracle.OracleModel("repeats", 21, 100, small, tail, max_error=8)
+        ps = np.array([[8.0, 0.03, 0.5, 0.4, 0.02], [5.0, 0.01, 0.7, 0.3, 0.004], [9.0, 0.02, 0.4, 0.6, 1e-5]])
+        assert ms.get_hist_threshold_values(ps[:, 2:5]).max() == 700
+        got = ms.loglikelihood_points(ps)
+        want = om.compute_loglikelihood_many(ps, n_threads=8)
+        for a, b in zip(got, want):
+            assert rel_err(float(a), float(b)) <= 1e-9, (tail, a, b)
