@@ -141,6 +141,24 @@ with open(tmp) as f:
 h2, meta = D.load_histogram(tmp)
 out["load_histogram"] = {"hist": items(h2), "meta": meta}
 
+# ---- the whole default flow of covest/covest.py:main on the reference's own test histogram ----
+import argparse  # noqa: E402
+import yaml  # noqa: E402
+import covest.covest as C  # noqa: E402
+out["end_to_end"] = {}
+for model_name in ("basic", "repeats"):
+    args = argparse.Namespace(
+        load=None, input_histogram=os.path.join(HERE, "sim_c10_e0.05.hist"), kmer_size=21, read_length=100, trim=None,
+        sample_factor=None, error_scale=1, coverage=None, model=model_name, max_coverage=None, min_q1=0.3,
+        error_rate=None, params=tuple(), fix=False, ll_only=False, start_original=False, starting_points=1, grid=False,
+        thread_count=1, reads_size=None, plot=None)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        C.main(args)
+    rec = yaml.safe_load(buf.getvalue())
+    rec.pop("version", None)
+    out["end_to_end"][model_name] = rec
+
 with open(os.path.join(HERE, "hist_steps.json"), "w") as f:
     json.dump(out, f)
 print("wrote hist_steps.json", os.path.getsize(os.path.join(HERE, "hist_steps.json")), "bytes")

@@ -111,3 +111,27 @@ def test_result_record(hip_lib, kind):
             assert rel_err(rec[key], v) <= TOL, (key, rec[key], v)
         else:
             assert rec[key] == v, (key, rec[key], v)
+
+
+@pytest.mark.parametrize("model", ["basic", "repeats"])
+def test_whole_default_flow(hip_lib, model):
+    """covest_amd.pipeline.estimate == covest.covest.main on the reference's own test histogram (file in,
+    record out): the guess and its likelihood to 1e-9, the optimum's likelihood to 1e-9; where L-BFGS-B stops on
+    the flat optimum depends on rounding noise in the finite differences (coverage to 2e-3, genome size to 0.1 %,
+    and for the repeats model only the likelihood pins the weakly determined q's)."""
+    import os
+    from conftest import GOLDEN
+    from covest_amd.pipeline import estimate
+    want = G["end_to_end"][model]
+    rec = estimate(os.path.join(GOLDEN, "sim_c10_e0.05.hist"), model=model)
+    rec.pop("version")
+    assert set(rec) == set(want)
+    for key in ("model", "hist_size", "sample_factor", "orig_sample_factor", "starting_points", "use_grid_search", "success"):
+        assert rec[key] == want[key], key
+    for key in ("guessed_coverage", "guessed_error_rate"):
+        assert rec[key] == want[key], key  # host arithmetic: bit-identical
+    assert rel_err(rec["guessed_loglikelihood"], want["guessed_loglikelihood"]) <= TOL
+    assert rel_err(rec["loglikelihood"], want["loglikelihood"]) <= TOL
+    assert abs(rec["coverage"] - want["coverage"]) <= 2e-3 and abs(rec["error_rate"] - want["error_rate"]) <= 1e-5
+    assert rec["orig_coverage"] == rec["coverage"]
+    assert abs(rec["genome_size"] / want["genome_size"] - 1.0) <= 1e-3
