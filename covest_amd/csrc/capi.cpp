@@ -498,6 +498,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     pl.flat_begin = g->flat_begin;
     pl.flat_end = g->flat_end;
     pl.list_mode = 0;
+    pl.n_seg = 1;
     pl.item_obase = nullptr;
     pl.partial = nullptr;
     {
@@ -627,6 +628,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     pl.flat_begin = 0;
     pl.flat_end = n;
     pl.list_mode = 1;
+    pl.n_seg = std::max(1, std::min(kListSegments, (int)m->tv.n_tiles)); // a function of the histogram alone
     pl.item_obase = nullptr;
     pl.partial = nullptr;
     pl.diag = nullptr;
@@ -852,11 +854,14 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
     const int P = m->n_par;
     HIP_TRY(m->ws_params.reserve((size_t)n * P * sizeof(double)));
     HIP_TRY(m->ws_out.reserve((size_t)n * sizeof(double)));
-    HIP_TRY(hipMemcpy(m->ws_params.ptr, params, (size_t)n * P * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(m->ws_t.reserve((size_t)n * sizeof(int32_t)));
     PointSource src{};
     src.is_grid = 0;
     src.params = m->ws_params.as<double>();
-    if (P == 5) {
+    src.t_list = P == 5 ? m->ws_t.as<int32_t>() : nullptr;
+    if (kern != COVEST_KERNEL_FACTORED) // (the list mode uploads its own tables: every copy is ~10 us of latency)
+        HIP_TRY(hipMemcpy(m->ws_params.ptr, params, (size_t)n * P * sizeof(double), hipMemcpyHostToDevice));
+    if (P == 5 && kern != COVEST_KERNEL_FACTORED) {
         std::vector<int32_t> t((size_t)n);
         for (int64_t i = 0; i < n; ++i)
             t[(size_t)i] = threshold_for_point(m, params + i * P);
@@ -888,11 +893,32 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
             rc = build_list_plan(m, (int64_t)fits.size(), sub_par.data(), sub_t, nullptr, m->ws_plan, pl);
             if (rc != COVEST_OK)
                 return rc;
+            // {LL part, sp_j part (hi, lo)} per (point, key segment); the segments are added here, in order
+            const size_t n_parts = fits.size() * (size_t)pl.n_seg;
+            HIP_TRY(m->ws_partial.reserve(n_parts * 3 * sizeof(double)));
+            pl.partial = m->ws_partial.as<double>();
             HIP_TRY(launch_ll_factored(m->dm, m->tv, pl, m->ws_out.as<double>(), nullptr));
-            std::vector<double> got(fits.size());
-            HIP_TRY(hipMemcpy(got.data(), m->ws_out.ptr, fits.size() * sizeof(double), hipMemcpyDeviceToHost));
-            for (size_t k = 0; k < fits.size(); ++k)
-                out_ll[fits[k]] = got[k];
+            std::vector<double> got(n_parts * 3);
+            HIP_TRY(hipMemcpy(got.data(), m->ws_partial.ptr, got.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < fits.size(); ++k) {
+                double ll = 0.0, hi = 0.0, lo = 0.0;
+                for (int sg = 0; sg < pl.n_seg; ++sg) {
+                    const double *o = &got[(k * (size_t)pl.n_seg + (size_t)sg) * 3];
+                    ll += o[0];
+                    const double sum = hi + o[1], bb = sum - hi; // two-sum, as the kernels' CompSum
+                    lo += ((hi - (sum - bb)) + (o[1] - bb)) + o[2];
+                    hi = sum;
+                }
+                double tail_term = 0.0;
+                if (m->dm.tail != 0.0) { // tail * log(1 - min(1, sp)), covest/models.py:103-105
+                    double sp = hi + lo;
+                    if (!(sp < 1.0))
+                        sp = 1.0;
+                    if (sp < 1.0)
+                        tail_term = m->dm.tail * std::log(1.0 - sp);
+                }
+                out_ll[fits[k]] = ll + tail_term;
+            }
         }
         if (!big.empty()) {
             std::vector<double> item_par, point_ce(2 * big.size());

@@ -92,7 +92,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
 
     // ---- the (c, e) of this workgroup ----
-    const int64_t ce = plan.ce_begin + blockIdx.x;
+    // list mode: workgroup = (unit, key segment); a unit is a point or a chunk of a point's copy numbers, the
+    // key tiles are cut into n_seg contiguous segments so that even ONE point spreads over several CUs
+    const int n_seg = plan.list_mode ? plan.n_seg : 1;
+    const int unit = plan.list_mode ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+    const int seg = plan.list_mode ? (int)blockIdx.x - unit * n_seg : 0;
+    const int seg_tiles = (n_tiles + n_seg - 1) / n_seg;
+    const int t_begin = seg * seg_tiles, t_end = min(n_tiles, t_begin + seg_tiles);
+    const int64_t ce = plan.ce_begin + unit;
     // (list mode: workgroup i takes point i of a point list -- its own (c, e) AND its own single weight
     // vector, see tiles.h FactoredPlan::list_mode)
     const bool list = plan.list_mode != 0;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // ---- phase-A state: lane = copy number o = tid + 1 ----
     const bool wave_builds = wave * kWave < plan.max_o; // wave-uniform
     StreamSet<8> st;
-    const int o_base = plan.list_mode == 2 ? plan.item_obase[blockIdx.x] : 0; // chunked point list: tiles.h
+    const int o_base = plan.list_mode == 2 ? plan.item_obase[ce] : 0; // chunked point list: tiles.h
     st.init(m, lam, o_base + tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o);
     const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
     if (tid < 64)
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // wave w's block of MU slots in the unit tables
     auto wave_block = [&](int w) -> int {
         if (list) // block 0 is empty (waves with no unit); point i owns blocks 1 + 2 i and 2 + 2 i, for the last two waves
-            return w >= NW - 2 ? 1 + 2 * (int)blockIdx.x + (w - (NW - 2)) : 0;
+            return w >= NW - 2 ? 1 + 2 * (int)ce + (w - (NW - 2)) : 0;
         return (int)blockIdx.y * NW + w;
     };
     const int slot_base = wave_block(wave) * MU;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
         st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                      tv.run_start[t] != 0);
+                      tv.run_start[t] != 0 || t == t_begin); // (a key segment starts like a run: every stream anchored)
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         double *colp = dst + (lane_in_row ? tid : 0);
         if (nb == kTileBins) { // the common case: straight-line code, scales in SGPRs
@@ -231,18 +238,18 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // With two buffers the builders fill tile t+1 while every wave contracts tile t: one
     // barrier per tile, and the host's unit assignment charges the builders for phase A.
     const bool dbuf = plan.n_buf == 2;
-    if (dbuf) {
+    if (dbuf && t_begin < t_end) {
         if (wave_builds)
-            build_tile(0, Gs);
+            build_tile(t_begin, Gs + (t_begin & 1) * kTileBins * LD);
         __syncthreads();
     }
-    for (int t = 0; t < tv.n_tiles; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         const double *cur = Gs + (dbuf ? (t & 1) * kTileBins * LD : 0);
         if (!dbuf) {
             if (wave_builds)
                 build_tile(t, Gs);
             __syncthreads();
-        } else if (wave_builds && t + 1 < tv.n_tiles) {
+        } else if (wave_builds && t + 1 < t_end) {
             build_tile(t + 1, Gs + ((t + 1) & 1) * kTileBins * LD);
         }
         STAMP(dg_a)
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 if (qslot[k] >= 0 && !cont[k] && col == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        plan.partial[((int64_t)blockIdx.x * tv.n_tiles + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] =
+                        plan.partial[(ce * tv.n_tiles + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] =
                             acc[k][r];
                 }
                 continue;
@@ -392,13 +399,26 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
         const double ll = part_ll[e] + (pe >= 0 ? part_ll[pe] : 0.0);
         double tail_term = 0.0;
+        double hi = 0.0, lo = 0.0;
         if (TAIL) {
-            double hi = part_hi[e], lo = part_lo[e];
+            hi = part_hi[e];
+            lo = part_lo[e];
             if (pe >= 0) {
                 double err;
                 two_sum(hi, part_hi[pe], hi, err);
                 lo += part_lo[pe] + err;
             }
+        }
+        if (plan.list_mode == 1) { // a key segment of a point: {LL part, sp_j part (hi, lo)}; the host adds the segments
+            if (plan.q_orig[qt * 16 + c] >= 0) {
+                double *o = plan.partial + ((int64_t)ce * n_seg + seg) * 3;
+                o[0] = finite ? ll : NAN;
+                o[1] = hi;
+                o[2] = lo;
+            }
+            continue;
+        }
+        if (TAIL) {
             double s = hi + lo;
             if (!(s < 1.0))
                 s = 1.0; // min(1, fsum(...)), NaN -> 1
@@ -484,7 +504,8 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
         FactoredPlan part = plan;
         part.ce_begin = first;
         part.ce_end = std::min(plan.ce_end, first + per_launch);
-        const dim3 grid((unsigned)(part.ce_end - part.ce_begin), (unsigned)plan.n_qblocks);
+        const dim3 grid((unsigned)((part.ce_end - part.ce_begin) * (plan.list_mode ? plan.n_seg : 1)),
+                        (unsigned)plan.n_qblocks);
         hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles,
                            tv.dbl_base, tv.int_base, part, out_ll);
     }

@@ -67,6 +67,7 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, const double *dbl
 constexpr int kMaxUnits = 6;       // accumulator slots per wave
 constexpr int kHalfUnits = 3;      // (kept for the 256-thread capacity rule: 4 waves x 6 slots)
 constexpr int kBuildCost = 36;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3)
+constexpr int kListSegments = 8;   // key segments of a point-list evaluation (list mode): latency of ONE point
 constexpr int kMinPieceSteps = 6;  // pieces are not made shorter than this
 constexpr int kUnitOverhead = 3;   // per-unit cost besides its MFMA steps (logs, setup), same unit
 
@@ -106,8 +107,13 @@ struct FactoredPlan {
                                    //   point's copy numbers, o = item_obase[i] + 1 .. + 512 (threshold_o beyond one
                                    //   workgroup's lanes); the workgroup stores its share of p_j to `partial` and
                                    //   ll_finish_partials adds the chunks and takes the logs
-    const int32_t *item_obase;     // [items] list_mode 2: copy numbers before this chunk (multiple of 512); else NULL
-    double *partial;               // [items][n_tiles * 32] list_mode 2: sum over the chunk's o of b_o G[o][key]
+    int32_t n_seg;                 // list modes: key tiles are cut into n_seg contiguous segments, workgroup
+                                   //   blockIdx.x = unit * n_seg + segment (unit = point or chunk); a segment starts
+                                   //   like a run (streams anchored).  list_mode 1 then writes {LL part, sp part hi, lo}
+                                   //   per (point, segment) to `partial` and the host adds the segments in order
+    const int32_t *item_obase;     // [units] list_mode 2: copy numbers before this chunk (multiple of 512); else NULL
+    double *partial;               // list_mode 2: [units][n_tiles * 32] sum over the chunk's o of b_o G[o][key];
+                                   //   list_mode 1: [points][n_seg][3]
     long long *diag;               // PROFILING ONLY (env COVEST_FACTORED_DIAG): per-wave s_memtime sums [wg][wave][8]
     int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
 };
