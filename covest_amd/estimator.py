@@ -16,8 +16,8 @@ process pool.
 Refinement.  The reference hands scipy's L-BFGS-B a scalar objective, so
 scipy differentiates it numerically: P + 1 separate evaluations per gradient, and `-sp N` starts run
 in N worker processes.  Here one gradient is ONE launch -- the point and its P finite-difference
-neighbours go to the GPU together (`negll_points`) -- and the N starts advance in lock step, their
-requests merged into one launch per round (`_LockStep`).  Which neighbours scipy would visit (step
+neighbours go to the GPU together (`negll_points`) -- and the N starts can advance in lock step, their
+requests merged into one launch per round (`_LockStep`, opt-in: see `_best_of`).  Which neighbours scipy would visit (step
 1e-8, flipped at an upper bound, ...) is not re-derived: scipy's own `approx_derivative` is run twice,
 first against a recorder to learn the points, then against the batch's values, so the gradient -- and
 with it every iterate -- is bit-identical to what `minimize(..., jac=None)` computes from the same
@@ -34,11 +34,12 @@ from .grid import DenseGrid, initial_grid, optimize_grid
 class CoverageEstimator:
     ERROR_RATE = 1  # index of the parameter that err_scale applies to
 
-    def __init__(self, model, err_scale=1, fix=None, batched=True):
+    def __init__(self, model, err_scale=1, fix=None, batched=True, lock_step=False):
         self.model = model
         self.fix = fix
         self.err_scale = err_scale
-        self.batched = batched
+        self.batched = batched      # value and gradient from one launch (else scipy differences a scalar objective)
+        self.lock_step = lock_step  # multi-start: all starts advance together, one launch per round (see _best_of)
         bounds = [tuple(b) for b in model.bounds]
         lo, hi = bounds[self.ERROR_RATE]
         bounds[self.ERROR_RATE] = (lo, hi * err_scale)
@@ -117,9 +118,13 @@ class CoverageEstimator:
 
     def _best_of(self, starts):
         """Refine every start; keep the first result with the strictly smallest objective
-        (covest/covest.py:60-69).  Batched: the starts run as threads in lock step."""
+        (covest/covest.py:60-69).  The results do not depend on how the starts are scheduled.  Default: one
+        after the other, each gradient one launch.  lock_step=True runs them as threads whose requests are
+        merged into one launch per round -- fewer, fuller launches, but measured SLOWER on one GPU once a
+        single evaluation costs < 0.1 ms (bench.py --workload f2: the threads' hand-offs through the GIL cost
+        more than the launches they save); it pays when an evaluation is expensive (huge threshold_o)."""
         starts = list(starts)
-        if self.batched and len(starts) > 1:
+        if self.batched and self.lock_step and len(starts) > 1:
             results = _LockStep(self.negll_points, len(starts)).map(self._optimize, starts)
         else:
             results = [self._optimize(s) for s in starts]

@@ -49,10 +49,11 @@ def test_lock_step_multi_start(hip_lib):
     assert all(_same(a, b) for a, b in zip(seq, par))
     assert lock.rounds == max(r.nfev for r in par)
     # compute_coverage picks the first strictly smallest objective, as covest/covest.py:60-69
-    random.seed(3)
-    got, ok = est.compute_coverage([10.0, 0.05, 0.8, 0.5, 0.3], starting_points=6)
     want = min(seq, key=lambda r: r.fun)
-    assert list(got) == list(want.x) and ok == want.success
+    for flag in (False, True):
+        random.seed(3)
+        got, ok = CoverageEstimator(m, lock_step=flag).compute_coverage([10.0, 0.05, 0.8, 0.5, 0.3], starting_points=6)
+        assert list(got) == list(want.x) and ok == want.success
 
 
 def test_point_lists_of_any_threshold(hip_lib, oracle):

@@ -70,9 +70,10 @@ def test_lock_step_multi_start_equals_sequential():
     # rounds: as many launches as the LONGEST refinement needs, not the sum
     longest = max(r.nfev for r in par)
     assert lock.rounds == longest == model.calls and lock.points == sum(6 * r.nfev for r in par)
-    best = est._best_of(starts)
     want = min(seq, key=lambda r: r.fun)
-    assert np.array_equal(best.x, want.x)
+    for flag in (False, True):  # the schedule does not change the answer
+        best = CoverageEstimator(_StubModel(), lock_step=flag)._best_of(starts)
+        assert np.array_equal(best.x, want.x)
 
 
 def test_a_failing_evaluation_reaches_the_caller():
