@@ -210,6 +210,7 @@ int upload_bins(DevBuf &buf, BinView &view, const std::vector<double> &key,
 // into runs of consecutive keys (gaps of up to kGapFill keys are bridged with
 // filler keys that are stepped over but neither logged nor summed), each run cut
 // into tiles of <= 32 keys.  Returns false when the fast kernels do not apply.
+constexpr int64_t kListModeMaxPoints = 4096; // longer point lists are throughput work: K-direct
 constexpr int kGapFill = 12;
 constexpr int kMaxFastKey = 16384;
 
@@ -798,7 +799,9 @@ static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_gr
         // the factored kernel pays when many weight vectors share each (c, e)
         if (factored_ok && g->plan.n_q >= 32)
             return COVEST_KERNEL_FACTORED;
-        // a repeats-model point list: one workgroup per point (list mode) instead of one wave
+        // a repeats-model point list: one workgroup per (point, key segment) (list mode) instead of one wave --
+        // the latency path of refinements.  Long lists are throughput work and go to K-direct (and the list
+        // mode's per-point tables, 13 KB each, stay small): see covest_eval_points.
         if (!g && m->has_tiles && m->dm.kind == COVEST_MODEL_REPEATS)
             return COVEST_KERNEL_FACTORED;
         return COVEST_KERNEL_DIRECT;
@@ -844,9 +847,14 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         return fail(COVEST_E_INVALID, "covest_eval_points: bad argument");
     if (n == 0)
         return COVEST_OK;
-    const int kern = resolve_kernel(m, kernel, nullptr);
+    int kern = resolve_kernel(m, kernel, nullptr);
     if (kern < 0)
         return kern;
+    if (kern == COVEST_KERNEL_FACTORED && n > kListModeMaxPoints) {
+        if (kernel == COVEST_KERNEL_FACTORED)
+            return fail(COVEST_E_INVALID, "factored kernel: a point list of more than 4096 points (use a grid, or K-direct)");
+        kern = COVEST_KERNEL_DIRECT; // AUTO: throughput work
+    }
     std::lock_guard<std::mutex> guard(m->lock);
     int rc = use_device(m);
     if (rc != COVEST_OK)

@@ -100,7 +100,11 @@ int covest_threshold_o(int64_t n, const double *q123, double threshold, int32_t 
 
 /* model.compute_loglikelihood(*params) for a list of points: covest/models.py:100-107,
  * batched like compute_loglikelihood_multi (models.py:109-117).
- * params is [n][param_count] on the HOST; out_ll[n] on the HOST. */
+ * params is [n][param_count] on the HOST; out_ll[n] on the HOST.
+ * COVEST_KERNEL_AUTO: basic model -> the recurrence kernel; repeats model -> up to 4096 points go to the
+ * factored kernel's list mode (one workgroup per point and key segment, points whose threshold_o exceeds 513 in
+ * chunks of 512 copy numbers: the latency path of scipy-driven refinements, ~85 us for one point), longer lists
+ * to the direct kernel.  Within either range a point's value does not depend on what else is in the call. */
 int covest_eval_points(covest_model *m, int64_t n, const double *params, double *out_ll,
                        int32_t kernel);
 
