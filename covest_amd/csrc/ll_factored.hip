@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const bool wave_builds = wave * kWave < plan.max_o; // wave-uniform
     StreamSet<8> st;
     const int o_base = plan.list_mode == 2 ? plan.item_obase[ce] : 0; // chunked point list: tiles.h
-    st.init(m, lam, o_base + tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o);
+    st.init(m, lam, o_base + tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o, log_tab);
     const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
     if (tid < 64)
         Gs[(size_t)plan.n_buf * kTileBins * LD + tid] = 0.0; // the slack behind the buffers (see launch)

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_model.h"
+#include "fastmath.h"
 #include "point_fetch.h"
 #include "tiles.h"
 
@@ -63,7 +64,10 @@ struct StreamSet {
 
     // Mixture weights and constants of one (copy number o) over the S error
     // classes: covest/models.py:85-90 (o = 1) and :217-233.
-    __device__ __forceinline__ void init(const DevModel &m, const double *lam, int o, bool live)
+    // `log_tab`: the workgroup's LDS copy of the fast_log table (fastmath.h).  ln x and ln a need an ABSOLUTE
+    // accuracy of a few 1e-16 (they are exponents of the anchors), which fast_log delivers at a quarter of the
+    // device library's cost -- the prologue is 8 streams x (2 logs + exp + the normaliser) per lane.
+    __device__ __forceinline__ void init(const DevModel &m, const double *lam, int o, bool live, const double *log_tab)
     {
         double n_os[S];
         double tot = 0.0;
@@ -80,8 +84,8 @@ struct StreamSet {
             const double a = n_os[s] / tot;
             v[s] = 0.0;
             if (live && x[s] > 0.0 && a > 0.0) {
-                const double lx = log(x[s]);
-                an.set(s, lx, log(a) - log_trunc_norm(x[s], lx));
+                const double lx = fast_log(x[s], log_tab);
+                an.set(s, lx, fast_log(a, log_tab) - log_trunc_norm(x[s], lx));
             } else { // contributes exactly 0 (x == 0: TP returns 0, c_src/covest_poissonmodule.c:15)
                 x[s] = 0.0;
                 an.set(s, 0.0, -INFINITY);
