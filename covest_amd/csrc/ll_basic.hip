@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     StreamSet<S, LdsAnchors<S>> st;
     st.an.mine = anchors + threadIdx.x;
     st.an.stride = 256;
-    st.init(m, lam, 1, finite, log_tab);
+    st.init(m, lam, 1, finite, log_tab, log_tab);
 
     double acc_ll = 0.0;
     uint64_t dead = 0; // lanes that met a p_j <= 0 with h_j != 0

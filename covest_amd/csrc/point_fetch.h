@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_model.h"
+#include "fastmath.h"
 
 namespace covest {
 
@@ -113,7 +114,8 @@ __device__ __forceinline__ double exp_neg_rn(double x)
 // x is just above a multiple of 200.  Parity is with what the reference computes,
 // so this is reproduced, together with its two small-argument branches: x <= 1e-8 divides by
 // x itself (:20,29), and a residual <= 1e-8 divides by the ORIGINAL x (:29-31).
-__device__ __forceinline__ double log_trunc_norm(double x, double log_x)
+// `log_tab`: optional LDS copy of the fast_log table (fastmath.h) -- the two logs below need absolute accuracy.
+__device__ __forceinline__ double log_trunc_norm(double x, double log_x, const double *log_tab = nullptr)
 {
     if (x <= 1e-8)
         return log_x;
@@ -139,9 +141,10 @@ __device__ __forceinline__ double log_trunc_norm(double x, double log_x)
         double m = expm1(xr);
         if (xr < 0x1p-10)
             m = rint(m * 0x1p63) * 0x1p-63;
-        return base + log(m);
+        return base + (log_tab ? fast_log(m, log_tab) : log(m));
     }
-    return base + (xr + log1p(-exp(-xr)));
+    // ln(e^xr - 1) = xr + ln(1 - e^-xr), e^-xr <= 0.37: the rounding of 1 - e^-xr is an absolute 1.1e-16
+    return base + (xr + (log_tab ? fast_log(1.0 - exp(-xr), log_tab) : log1p(-exp(-xr))));
 }
 
 } // namespace covest

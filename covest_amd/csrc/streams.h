@@ -67,7 +67,10 @@ struct StreamSet {
     // `log_tab`: the workgroup's LDS copy of the fast_log table (fastmath.h).  ln x and ln a need an ABSOLUTE
     // accuracy of a few 1e-16 (they are exponents of the anchors), which fast_log delivers at a quarter of the
     // device library's cost -- the prologue is 8 streams x (2 logs + exp + the normaliser) per lane.
-    __device__ __forceinline__ void init(const DevModel &m, const double *lam, int o, bool live, const double *log_tab)
+    // `norm_tab`: the same table for the two logs inside the normaliser, or nullptr for the device library's
+    // (K-factored: the shorter code there costs it more in register allocation than it saves -- measured).
+    __device__ __forceinline__ void init(const DevModel &m, const double *lam, int o, bool live, const double *log_tab,
+                                         const double *norm_tab = nullptr)
     {
         double n_os[S];
         double tot = 0.0;
@@ -85,7 +88,7 @@ struct StreamSet {
             v[s] = 0.0;
             if (live && x[s] > 0.0 && a > 0.0) {
                 const double lx = fast_log(x[s], log_tab);
-                an.set(s, lx, fast_log(a, log_tab) - log_trunc_norm(x[s], lx));
+                an.set(s, lx, fast_log(a, log_tab) - log_trunc_norm(x[s], lx, norm_tab));
             } else { // contributes exactly 0 (x == 0: TP returns 0, c_src/covest_poissonmodule.c:15)
                 x[s] = 0.0;
                 an.set(s, 0.0, -INFINITY);
