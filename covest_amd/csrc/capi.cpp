@@ -79,7 +79,9 @@ struct covest_model {
     int device = 0;
     int n_par = 2;
     DevModel dm{};       // bins = the evaluated view
-    BinView all_bins{};  // every key, in dict order (compute_probabilities)
+    BinView all_bins{};  // every key, in dict order (compute_probabilities); uploaded on first use
+    std::vector<double> host_all_key, host_all_lgam, host_all_cnt;
+    bool all_bins_ready = false;
     int64_t n_keys = 0;
     int hist_max = 0;    // max(self.hist)
     double threshold = 0.0;
@@ -187,6 +189,27 @@ int use_device(const covest_model *m)
     return COVEST_OK;
 }
 
+// ln j! = lgamma(j + 1) rounded from long double, for j = 0, 1, 2, ...: a process-wide table grown on demand
+// (lgammal costs ~100 ns; a 10 000-key histogram paid 1 ms of it per model handle).
+double lgamma_of_factorial(int64_t j)
+{
+    static std::mutex lock;
+    static std::vector<double> table;
+    if (j < 0)
+        j = 0;
+    if (j > (int64_t)1 << 22) // beyond any histogram the fast paths accept: not cached
+        return (double)lgammal((long double)j + 1.0L);
+    std::lock_guard<std::mutex> guard(lock);
+    if ((size_t)j >= table.size()) {
+        const size_t old = table.size(), want = std::max<size_t>((size_t)j + 1, 2 * old);
+        table.resize(want);
+        for (size_t v = old; v < want; ++v)
+            table[v] = (double)lgammal((long double)v + 1.0L);
+    }
+    return table[(size_t)j];
+}
+
+// One buffer, one copy: [key | lgam | cnt].
 int upload_bins(DevBuf &buf, BinView &view, const std::vector<double> &key,
                 const std::vector<double> &lgam, const std::vector<double> &cnt)
 {
@@ -197,9 +220,11 @@ int upload_bins(DevBuf &buf, BinView &view, const std::vector<double> &key,
         return COVEST_OK;
     HIP_TRY(buf.reserve(3 * n * sizeof(double)));
     double *base = buf.as<double>();
-    HIP_TRY(hipMemcpy(base, key.data(), n * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + n, lgam.data(), n * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(base + 2 * n, cnt.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> stage(3 * n);
+    std::copy(key.begin(), key.end(), stage.begin());
+    std::copy(lgam.begin(), lgam.end(), stage.begin() + (std::ptrdiff_t)n);
+    std::copy(cnt.begin(), cnt.end(), stage.begin() + (std::ptrdiff_t)(2 * n));
+    HIP_TRY(hipMemcpy(base, stage.data(), stage.size() * sizeof(double), hipMemcpyHostToDevice));
     view.key = base;
     view.lgam = base + n;
     view.cnt = base + 2 * n;
@@ -270,8 +295,8 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     for (size_t t = 0; t < nt; ++t) {
         const Tile &tl = tiles[t];
         dbl[t] = (double)tl.k0;
-        dbl[nt + t] = (double)lgammal((long double)tl.k0);
-        dbl[2 * nt + t] = (double)lgammal((long double)(tl.k0 + tl.nb));
+        dbl[nt + t] = lgamma_of_factorial((int64_t)tl.k0 - 1);
+        dbl[2 * nt + t] = lgamma_of_factorial((int64_t)(tl.k0 + tl.nb) - 1);
         long double rn = 1.0L;
         for (int b = 0; b < tl.nb; ++b)
             rn /= (long double)(tl.k0 + b);
@@ -280,15 +305,22 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
         ints[nt + t] = tl.run_start;
     }
     const size_t n_dbl = 4 * nt + 3 * nt * kTileBins;
-    HIP_TRY(m->tiles_buf.reserve(n_dbl * sizeof(double) + 2 * nt * sizeof(int32_t)));
+    const size_t bytes = n_dbl * sizeof(double) + 2 * nt * sizeof(int32_t);
+    HIP_TRY(m->tiles_buf.reserve(bytes));
     double *base = m->tiles_buf.as<double>();
-    HIP_TRY(hipMemcpy(base, dbl.data(), 4 * nt * sizeof(double), hipMemcpyHostToDevice));
-    double *per_bin = base + 4 * nt;
-    HIP_TRY(hipMemcpy(per_bin, scal.data(), nt * kTileBins * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(per_bin + nt * kTileBins, cnt.data(), nt * kTileBins * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(per_bin + 2 * nt * kTileBins, insp.data(), nt * kTileBins * sizeof(double), hipMemcpyHostToDevice));
     int32_t *ibase = reinterpret_cast<int32_t *>(base + n_dbl);
-    HIP_TRY(hipMemcpy(ibase, ints.data(), 2 * nt * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<char> stage(bytes); // one copy instead of five
+    char *sp = stage.data();
+    auto put = [&](const void *src, size_t n) {
+        std::memcpy(sp, src, n);
+        sp += n;
+    };
+    put(dbl.data(), 4 * nt * sizeof(double));
+    put(scal.data(), nt * kTileBins * sizeof(double));
+    put(cnt.data(), nt * kTileBins * sizeof(double));
+    put(insp.data(), nt * kTileBins * sizeof(double));
+    put(ints.data(), 2 * nt * sizeof(int32_t));
+    HIP_TRY(hipMemcpy(base, stage.data(), bytes, hipMemcpyHostToDevice));
     m->tv = tile_view_from((int32_t)nt, base, ibase);
     m->has_tiles = true;
     return COVEST_OK;
@@ -457,19 +489,27 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     HIP_TRY(g->plan_buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
     double *dbase = g->plan_buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
-    HIP_TRY(hipMemcpy(dbase, first8.data(), 8 * n_slots * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dbase + 8 * n_slots, r4.data(), n_slots * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ibase, nsteps.data(), (size_t)n_qtiles * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ibase + n_qtiles, q_t.data(), n_slots * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ibase + n_qtiles + n_slots, q_orig.data(), n_slots * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ibase + n_qtiles + 2 * n_slots, unit_tile.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ibase + n_qtiles + 2 * n_slots + n_unit, nfull.data(), (size_t)n_qtiles * sizeof(int32_t), hipMemcpyHostToDevice));
     int32_t *piece_base = ibase + 2 * n_qtiles + 2 * n_slots + n_unit;
-    HIP_TRY(hipMemcpy(piece_base, unit_half.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(piece_base + n_unit, unit_s0.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(piece_base + 2 * n_unit, unit_len.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(piece_base + 3 * n_unit, unit_cont.data(), n_unit * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dbase + 9 * n_slots, piece_w.data(), piece_w.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        // staged on the host in the device layout, ONE copy (a dozen small copies cost ~150 us of the plan build)
+        std::vector<char> stage(n_dbl * sizeof(double) + n_int * sizeof(int32_t));
+        double *sd = reinterpret_cast<double *>(stage.data());
+        int32_t *si = reinterpret_cast<int32_t *>(sd + n_dbl);
+        std::copy(first8.begin(), first8.end(), sd);
+        std::copy(r4.begin(), r4.end(), sd + 8 * n_slots);
+        std::copy(piece_w.begin(), piece_w.end(), sd + 9 * n_slots);
+        std::copy(nsteps.begin(), nsteps.end(), si);
+        std::copy(q_t.begin(), q_t.end(), si + n_qtiles);
+        std::copy(q_orig.begin(), q_orig.end(), si + n_qtiles + n_slots);
+        std::copy(unit_tile.begin(), unit_tile.end(), si + n_qtiles + 2 * n_slots);
+        std::copy(nfull.begin(), nfull.end(), si + n_qtiles + 2 * n_slots + n_unit);
+        int32_t *sp = si + 2 * n_qtiles + 2 * n_slots + n_unit;
+        std::copy(unit_half.begin(), unit_half.end(), sp);
+        std::copy(unit_s0.begin(), unit_s0.end(), sp + n_unit);
+        std::copy(unit_len.begin(), unit_len.end(), sp + 2 * n_unit);
+        std::copy(unit_cont.begin(), unit_cont.end(), sp + 3 * n_unit);
+        HIP_TRY(hipMemcpy(g->plan_buf.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice));
+    }
     FactoredPlan &pl = g->plan;
     pl.c_axis = g->src.axis[0];
     pl.e_axis = g->src.axis[1];
@@ -723,7 +763,7 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
             hist_max = j;
         const int je = j > 0 ? j : 0; // the product loop of the C extension is empty for j <= 0
         const double kd = (double)je;
-        const double lg = (double)lgammal((long double)je + 1.0L);
+        const double lg = lgamma_of_factorial(je);
         const double h = d->counts[b];
         key_a.push_back(kd);
         lg_a.push_back(lg);
@@ -738,10 +778,19 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
     m->hist_max = d->n_keys > 0 ? hist_max : 0;
 
     int rc = use_device(m);
-    if (rc == COVEST_OK)
-        rc = upload_bins(m->bins_all, m->all_bins, key_a, lg_a, cnt_a);
+    if (d->tail != 0.0) { // the evaluated view IS the full view
+        m->host_all_key.clear();
+    } else {
+        m->host_all_key = std::move(key_a);
+        m->host_all_lgam = std::move(lg_a);
+        m->host_all_cnt = std::move(cnt_a);
+    }
     if (rc == COVEST_OK)
         rc = upload_bins(m->bins_eval, dm.bins, key_e, lg_e, cnt_e);
+    if (rc == COVEST_OK && d->tail != 0.0) {
+        m->all_bins = dm.bins;
+        m->all_bins_ready = true;
+    }
     if (rc == COVEST_OK)
         rc = build_tiles(m, std::move(eval_bins));
     if (rc != COVEST_OK) {
@@ -1014,6 +1063,12 @@ int covest_probabilities(covest_model *m, const double *params, int32_t clamp, d
         HIP_TRY(m->ws_t.reserve(sizeof(int32_t)));
         HIP_TRY(hipMemcpy(m->ws_t.ptr, &t, sizeof(int32_t), hipMemcpyHostToDevice));
         src.t_list = m->ws_t.as<int32_t>();
+    }
+    if (!m->all_bins_ready) { // the view over EVERY key is only needed here: uploaded on first use
+        rc = upload_bins(m->bins_all, m->all_bins, m->host_all_key, m->host_all_lgam, m->host_all_cnt);
+        if (rc != COVEST_OK)
+            return rc;
+        m->all_bins_ready = true;
     }
     DevModel full = m->dm;
     full.bins = m->all_bins;
