@@ -97,3 +97,21 @@ def test_point_lists_of_any_threshold(hip_lib, oracle):
         want = om.compute_loglikelihood_many(ps, n_threads=8)
         for a, b in zip(got, want):
             assert rel_err(float(a), float(b)) <= 1e-9, (tail, a, b)
+
+
+def test_long_point_lists_take_the_throughput_kernel(hip_lib):
+    """More than 4096 points in one call are throughput work: AUTO hands them to K-direct (same values to 1e-11),
+    an explicit request for the factored kernel is refused."""
+    from covest_amd import RepeatsModel
+    from covest_amd._capi import CovestHipError
+    m = RepeatsModel(21, 100, load_hist("sim_c10_e0.05"), 0, max_error=8)
+    rng = np.random.default_rng(0)
+    pts = np.column_stack([rng.uniform(5, 15, 5000), rng.uniform(0.01, 0.1, 5000), rng.uniform(0.3, 1, 5000),
+                           rng.uniform(0, 1, 5000), rng.uniform(0.05, 1, 5000)])
+    long_auto = m.loglikelihood_points(pts)
+    short_auto = m.loglikelihood_points(pts[:4096])
+    direct = m.loglikelihood_points(pts, kernel="direct")
+    assert np.array_equal(long_auto, direct)
+    assert all(rel_err(float(a), float(b)) <= 1e-11 for a, b in zip(short_auto, direct[:4096]))
+    with pytest.raises(CovestHipError):
+        m.loglikelihood_points(pts, kernel="factored")
