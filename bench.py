@@ -9,7 +9,7 @@ A "step" is one pass of the hot path over one batch of synthetic input: every
 point of this rank's block of a dense parameter grid is evaluated on the GPU
 (likelihood kernel), reduced to (min -LL, lowest index) on the GPU (arg-min
 kernels), the 16-byte result is read back, and -- for N > 1 -- the global winner
-is agreed with one RCCL all-reduce(min) pair.  The histogram (model handle) and
+is agreed with one RCCL all-gather of the ranks' 16-byte (min, index) pairs.  The histogram (model handle) and
 the grid axes are resident in HBM before the timed region starts.
 
 Workloads; the default is the one BASELINE.json's metric is
@@ -514,7 +514,7 @@ def main():
                                    "grid c%dxe1000" % (model.bins_evaluated, shape[0]),
                              "c1": "C1: BasicModel k=21 r=100 S=8, H256.hist, grid c%dxe50" % shape[0]}[args.workload],
                 "grid_points": total, "points_per_gpu": n_local, "kernel": kernel_name,
-                "partition": "contiguous flat-index block per GPU, one RCCL all-reduce(min) pair per step",
+                "partition": "contiguous flat-index block per GPU, one RCCL all-gather of 16-byte (min, index) pairs per step",
             },
             "argmin": {"min_negll": gmin, "flat_index": gidx},
             "time_to_argmin_ms": {"first_call_incl_module_load": 1e3 * time_to_argmin_first,

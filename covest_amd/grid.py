@@ -68,9 +68,10 @@ def partition_flat_range(total, world_size, weights=None, period=None):
 def distributed_argmin(local_min, local_idx, group=None, device=None):
     """Global (min, lowest flat index) from every rank's local pair.
 
-    RCCL has no MINLOC for fp64, so: all_reduce(MIN) on the value, then
-    all_reduce(MIN) on `idx if value == global_min else INT64_MAX`.  NaN is
-    mapped to +inf first (a NaN never wins the scan of covest/grid.py:67).
+    RCCL has no MINLOC for fp64.  ONE collective: every rank contributes the 16-byte pair
+    (value, index as an exactly representable double -- flat indices stay below 2^53) to an all-gather
+    and scans the N pairs itself: strict <, lowest index on ties, as the scan of covest/grid.py:65-70
+    would over the concatenated blocks.  NaN is mapped to +inf first (a NaN never wins, :67).
     Works with any backend (nccl == RCCL on GPUs, gloo on CPU for tests).
     Without an initialised process group this is the identity.
     """
@@ -78,20 +79,26 @@ def distributed_argmin(local_min, local_idx, group=None, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local_min, local_idx
-    no_idx = torch.iinfo(torch.int64).max
+    world = dist.get_world_size(group)
     v = float(local_min)
     if v != v or local_idx < 0:
         v, local_idx = math.inf, -1
-    val = torch.tensor([v], dtype=torch.float64, device=device)
-    dist.all_reduce(val, op=dist.ReduceOp.MIN, group=group)
-    gmin = float(val.item())
-    mine = local_idx if (local_idx >= 0 and v == gmin and v < math.inf) else no_idx
-    idx = torch.tensor([mine], dtype=torch.int64, device=device)
-    dist.all_reduce(idx, op=dist.ReduceOp.MIN, group=group)
-    gidx = int(idx.item())
-    if gidx == no_idx:
-        return math.inf, -1
-    return gmin, gidx
+    if local_idx >= 1 << 53:
+        raise ValueError("flat index does not fit a double exactly")
+    pair = torch.tensor([v, float(local_idx)], dtype=torch.float64, device=device)
+    gathered = torch.empty((world, 2), dtype=torch.float64, device=device)
+    try:
+        dist.all_gather_into_tensor(gathered, pair, group=group)
+    except (RuntimeError, AttributeError, NotImplementedError):  # a backend without the flat variant
+        parts = [torch.empty(2, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(parts, pair, group=group)
+        gathered = torch.stack(parts)
+    best, arg = math.inf, -1
+    for val, idx in gathered.cpu().tolist():
+        idx = int(idx)
+        if idx >= 0 and (val < best or (val == best and val < math.inf and idx < arg)):
+            best, arg = val, idx
+    return best, arg
 
 
 # --------------------------------------------------------------------------- dense grid
