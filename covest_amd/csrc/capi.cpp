@@ -256,7 +256,7 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
         int k0, nb, run_start;
     };
     std::vector<Tile> tiles;
-    std::vector<double> scal, cnt, insp;
+    std::vector<double> scal, cnt;
     size_t i = 0;
     while (i < bins.size()) {
         // one run: keys bins[i..j) with gaps <= kGapFill
@@ -270,26 +270,26 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
             tiles.push_back({k0, nb, k0 == first ? 1 : 0});
             long double sc = ldexpl(1.0L, -kScaleBits);
             for (int b = 0; b < kTileBins; ++b) {
-                double sv = 0.0, cv = 0.0, iv = 0.0;
+                double sv = 0.0, cv = 0.0;
                 if (b < nb) {
                     const int key = k0 + b;
                     sc /= (long double)key;
-                    sv = (double)sc;
                     if (cur < j && bins[cur].key == key) {
+                        sv = (double)sc;
                         cv = bins[cur].cnt;
-                        iv = 1.0;
                         ++cur;
-                    }
+                    } // else a FILLER key (a gap of the histogram the recurrence walks through): scale 0, so
+                      // that its p_j is exactly 0 -- it is no key of the reference's p_j dict, and must add
+                      // nothing to sp_j (covest/models.py:103) and take no log
                 }
                 scal.push_back(sv);
                 cnt.push_back(cv);
-                insp.push_back(iv);
             }
         }
         i = j;
     }
     const size_t nt = tiles.size();
-    // layout: [first_key | lgam_prev | lgam_last | renorm] doubles, then scal/cnt/in_sp, then int32 n_bins/run_start
+    // layout: [first_key | lgam_prev | lgam_last | renorm] doubles, then scal/cnt, then int32 n_bins/run_start
     std::vector<double> dbl(4 * nt);
     std::vector<int32_t> ints(2 * nt);
     for (size_t t = 0; t < nt; ++t) {
@@ -304,7 +304,7 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
         ints[t] = tl.nb;
         ints[nt + t] = tl.run_start;
     }
-    const size_t n_dbl = 4 * nt + 3 * nt * kTileBins;
+    const size_t n_dbl = 4 * nt + 2 * nt * kTileBins;
     const size_t bytes = n_dbl * sizeof(double) + 2 * nt * sizeof(int32_t);
     HIP_TRY(m->tiles_buf.reserve(bytes));
     double *base = m->tiles_buf.as<double>();
@@ -318,7 +318,6 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     put(dbl.data(), 4 * nt * sizeof(double));
     put(scal.data(), nt * kTileBins * sizeof(double));
     put(cnt.data(), nt * kTileBins * sizeof(double));
-    put(insp.data(), nt * kTileBins * sizeof(double));
     put(ints.data(), 2 * nt * sizeof(int32_t));
     HIP_TRY(hipMemcpy(base, stage.data(), bytes, hipMemcpyHostToDevice));
     m->tv = tile_view_from((int32_t)nt, base, ibase);

@@ -66,9 +66,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     // one key's p_j (flushed like the reference's double): into sp_j, and its log (all branches
     // wave-uniform)
-    auto account = [&](double p, double h, bool in_sp) {
-        if (TAIL && in_sp)
-            acc_sp.add(p);
+    auto account = [&](double p, double h) {
+        if (TAIL)
+            acc_sp.add(p); // (filler keys have scale 0: p == 0)
         if (h != 0.0) { // filler keys and zero counts: no log (`if h`, covest/models.py:106)
             // utils.safe_log: p_j <= 0 makes the whole sum -inf.  Remembered as a lane mask in
             // SGPRs (one compare) instead of a select per key; fast_log(0) is finite.
@@ -84,7 +84,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                       tv.run_start[t] != 0);
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         const double *cnt = tv.cnt + (int64_t)t * kTileBins;
-        const double *insp = tv.in_sp + (int64_t)t * kTileBins;
         if (nb == kTileBins) {
             double xx[S]; // squared rates, recomputed per tile (S multiplies) rather than held in 2 S registers
             st.squares(xx);
@@ -94,24 +93,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 double sc[16], hc[16];
-                bool in[16];
 #pragma unroll
                 for (int b = 0; b < 16; ++b) {
                     sc[b] = scal[16 * half + b];
                     hc[b] = cnt[16 * half + b];
-                    in[b] = TAIL ? insp[16 * half + b] != 0.0 : true;
                 }
 #pragma unroll
                 for (int b = 0; b < 16; b += 2) {
                     double g1, g2;
                     st.step2(xx, g1, g2);
-                    account(g1 * sc[b], hc[b], in[b]);
-                    account(g2 * sc[b + 1], hc[b + 1], in[b + 1]);
+                    account(g1 * sc[b], hc[b]);
+                    account(g2 * sc[b + 1], hc[b + 1]);
                 }
             }
         } else {
             for (int b = 0; b < nb; ++b)
-                account(st.step() * scal[b], cnt[b], TAIL ? insp[b] != 0.0 : true);
+                account(st.step() * scal[b], cnt[b]);
         }
         st.leave_tile(tv.renorm[t]);
     }

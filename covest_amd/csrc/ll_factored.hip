@@ -257,14 +257,12 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // ================= phase B: P = G x b on the matrix pipe =================
         // counts of the 8 rows this lane will log (latency hidden under the MFMAs)
         double hrow[2][4];
-        bool inrow[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int bin = 16 * u + kq + 4 * r;
                 hrow[u][r] = tv.cnt[(int64_t)t * kTileBins + bin];
-                inrow[u][r] = TAIL ? tv.in_sp[(int64_t)t * kTileBins + bin] != 0.0 : true;
             }
         d4 acc[MU];
         // the piece's first step (weights wfirst/wrun were fetched during the previous tile's logs)
@@ -318,10 +316,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
-                    const bool in_sp = uhalf[k] ? inrow[1][r] : inrow[0][r];
                     const double p = acc[k][r];
-                    if (TAIL && in_sp)
-                        spacc[k].add(p);
+                    if (TAIL)
+                        spacc[k].add(p); // (filler and padding keys: p == 0)
                     // No branch on h (it differs between the lanes' rows): the four logs of a unit are
                     // straight-line code and interleave.  Filler and padding keys have h == 0 (`if h`,
                     // covest/models.py:106) and add 0 * log p -- fast_log(0) is finite.  utils.safe_log:
@@ -455,7 +452,7 @@ __global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, co
         for (int c = c0; c < c1; ++c)
             pj += partial[(int64_t)c * n_keys + key];
         const double h = tv.cnt[key];
-        if (m.tail != 0.0 && tv.in_sp[key] != 0.0)
+        if (m.tail != 0.0)
             sp.add(pj);
         if (h != 0.0) {
             dead |= pj <= 0.0; // utils.safe_log

@@ -16,7 +16,7 @@ constexpr double kWindowLn = -760.0; // terms below e^-760 are 0 in double
 // indexed by tile is wave-uniform and read through the scalar cache.
 struct TileView {
     int32_t n_tiles;
-    // raw buffers behind the views below: [4*nt + 3*nt*32] doubles, [2*nt] int32.  The fast
+    // raw buffers behind the views below: [4*nt + 2*nt*32] doubles, [2*nt] int32.  The fast
     // kernels take these two as separate `const __restrict__` kernel arguments and rebuild the
     // view from them (tile_view_from): only then does hipcc know the table is read-only and
     // never aliased, and fetches the wave-uniform entries with s_load into SGPRs.
@@ -28,9 +28,9 @@ struct TileView {
     const double *lgam_prev;   // [n_tiles] lgamma(k0)       = ln (k0-1)!
     const double *lgam_last;   // [n_tiles] lgamma(k0 + nb)  = ln (k0+nb-1)!
     const double *renorm;      // [n_tiles] (k0-1)! / (k0+nb-1)!   carries v into the next tile
-    const double *scal;        // [n_tiles][32] 2^-SC (k0-1)!/(k0+b)!
+    const double *scal;        // [n_tiles][32] 2^-SC (k0-1)!/(k0+b)!; 0 for filler keys (gaps of the histogram the
+                               //   recurrence walks through) and padding: their p_j is exactly 0, so they add nothing to sp_j
     const double *cnt;         // [n_tiles][32] h_j (0 for padding and filler keys)
-    const double *in_sp;       // [n_tiles][32] 1.0 if the key is a histogram key (counts in sp_j), else 0.0
 };
 
 // The layout of capi.cpp: build_tiles.
@@ -46,7 +46,6 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, const double *dbl
     tv.renorm = dbl + 3 * (int64_t)nt;
     tv.scal = dbl + 4 * (int64_t)nt;
     tv.cnt = tv.scal + (int64_t)nt * kTileBins;
-    tv.in_sp = tv.cnt + (int64_t)nt * kTileBins;
     tv.n_bins = ints;
     tv.run_start = ints + nt;
     return tv;
