@@ -6,6 +6,8 @@ IEEE specials (-inf / NaN) identical, arg-min index identical.
 """
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -67,6 +69,29 @@ def _tail_noise(om, points, lls, tail):
         noise = abs(tail) * 4 * eps / gap if gap > 0 else math.inf
         out.append(abs(tail) * 40.0 if noise > 1e-10 * abs(ll) else 0.0)
     return out
+
+
+def _subnormal_noise(om, hist, points, lls):
+    """Where the reference's own p_j is a SUBNORMAL double (< 2.2e-308) at a key with h_j != 0.  Its value there
+    is whatever the order of the reference's roundings leaves: every a_s * tp_s is rounded twice onto the
+    4.9e-324 grid (c_src/covest_poissonmodule.c:32 casts the long double to double, covest/models.py:93
+    multiplies by a_s) before the sum.  K-direct evaluates term by term and lands on the same grid points; the
+    recurrence kernels round the finished sum once and may differ by one grid step per term: an absolute
+    16 * h_j * 4.9e-324 / p_j in the log-likelihood (1.26 for h_j = 6316 at p_j = 2.5e-320, found by the
+    fuzz test's seed 42).  Returns that bound per point (0 = no subnormal p_j with weight)."""
+    tiny, grid = 2.2250738585072014e-308, 4.9406564584124654e-324
+    out = []
+    for p, ll in zip(points, lls):
+        if not math.isfinite(ll):
+            out.append(0.0)
+            continue
+        probs = om.compute_probabilities(*p)
+        out.append(sum(16.0 * hist[j] * grid / pj for j, pj in probs.items() if 0.0 < pj < tiny and hist[j]))
+    return out
+
+
+def _wider(a, b):
+    return [max(x, y) for x, y in zip(a, b)]
 
 
 def test_device_present(hip_lib):
@@ -366,7 +391,7 @@ def test_optimize_grid_trace(hip_lib):
         assert list(res) == tr["result"], (tr["model"], res, tr["result"])
 
 
-@pytest.mark.parametrize("seed", list(range(1, 11)))
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("COVEST_FUZZ_SEEDS", "10")))))
 def test_fuzz_random_histograms(hip_lib, oracle, seed):
     """Random histograms (gapped keys, zero counts, huge counts, tail or not) and random points incl.
     the bound corners: every kernel that accepts the request against the oracle."""
@@ -387,8 +412,10 @@ def test_fuzz_random_histograms(hip_lib, oracle, seed):
     pts[:4] = [(0.01, 0.0), (0.01, 0.5), (400.0, 0.0), (400.0, 0.5)]
     ref = om.compute_loglikelihood_many(pts, n_threads=16)
     slack = _tail_noise(om, pts, ref, tail)
+    fast_slack = _wider(slack, _subnormal_noise(om, hist, pts, ref))  # the recurrence kernels only
     for kernel in ("direct", "recur"):
-        _check(m.loglikelihood_points(pts, kernel=kernel), ref, "fuzz basic %s seed %d" % (kernel, seed), slack=slack)
+        _check(m.loglikelihood_points(pts, kernel=kernel), ref, "fuzz basic %s seed %d" % (kernel, seed),
+               slack=slack if kernel == "direct" else fast_slack)
     # --- repeats model: dense grid through direct and factored, point list through direct ---
     rm = RepeatsModel(k, r, hist, tail, max_error=8)
     orm = oracle.OracleModel("repeats", k, r, hist, tail, max_error=8)
@@ -398,11 +425,12 @@ def test_fuzz_random_histograms(hip_lib, oracle, seed):
     gp = np.array([grid.point(i) for i in range(grid.total)])
     gref = orm.compute_loglikelihood_many(gp, n_threads=16)
     gslack = _tail_noise(orm, gp, gref, tail)
+    gfast = _wider(gslack, _subnormal_noise(orm, hist, gp, gref))
     for kernel in ("direct", "factored"):
         grid.evaluate(kernel=kernel)
         ll = grid.loglikelihoods()
-        _check(ll, gref, "fuzz repeats %s seed %d" % (kernel, seed), slack=gslack)
+        _check(ll, gref, "fuzz repeats %s seed %d" % (kernel, seed), slack=gslack if kernel == "direct" else gfast)
         k_ref, _ = oracle.first_min(-gref)
         val, arg = grid.argmin()
         assert arg == k_ref or rel_err(float(ll[arg]), float(gref[k_ref])) <= TOL
-    _check(rm.loglikelihood_points(gp[::7]), gref[::7], "fuzz repeats list seed %d" % seed, slack=gslack[::7])
+    _check(rm.loglikelihood_points(gp[::7]), gref[::7], "fuzz repeats list seed %d" % seed, slack=gfast[::7])
