@@ -22,8 +22,9 @@ EXPORTS = (
     "covest_abi_version", "covest_device_count", "covest_last_error",
     "covest_model_create", "covest_model_destroy", "covest_model_param_count",
     "covest_model_bins_evaluated", "covest_threshold_o", "covest_eval_points",
-    "covest_probabilities", "covest_grid_create", "covest_grid_destroy", "covest_grid_size",
-    "covest_grid_eval", "covest_grid_argmin", "covest_grid_ll_device", "covest_grid_ll_host",
+    "covest_probabilities", "covest_reference_overflow", "covest_grid_create", "covest_grid_destroy", "covest_grid_size",
+    "covest_grid_eval", "covest_grid_argmin", "covest_grid_argmin_pair_device", "covest_grid_ll_device",
+    "covest_grid_ll_host",
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
     "covest_kmer_create", "covest_kmer_destroy", "covest_kmer_reserve", "covest_kmer_add",
     "covest_kmer_add_device", "covest_kmer_histogram", "covest_kmer_slots", "covest_kmer_clear",
@@ -90,6 +91,8 @@ def lib():
     L.covest_threshold_o.argtypes = [i64, dp, ctypes.c_double, i32, i32, ctypes.POINTER(i32)]
     L.covest_eval_points.restype = ctypes.c_int
     L.covest_eval_points.argtypes = [vp, i64, dp, dp, i32]
+    L.covest_reference_overflow.restype = ctypes.c_int
+    L.covest_reference_overflow.argtypes = [vp, i64, dp, ctypes.POINTER(ctypes.c_uint8)]
     L.covest_probabilities.restype = ctypes.c_int
     L.covest_probabilities.argtypes = [vp, dp, i32, dp]
     L.covest_grid_create.restype = ctypes.c_int
@@ -103,6 +106,8 @@ def lib():
     L.covest_grid_eval.argtypes = [vp, i32, vp]
     L.covest_grid_argmin.restype = ctypes.c_int
     L.covest_grid_argmin.argtypes = [vp, dp, ctypes.POINTER(i64)]
+    L.covest_grid_argmin_pair_device.restype = vp
+    L.covest_grid_argmin_pair_device.argtypes = [vp]
     L.covest_grid_ll_device.restype = vp
     L.covest_grid_ll_device.argtypes = [vp]
     L.covest_grid_ll_host.restype = ctypes.c_int

@@ -5,12 +5,16 @@
 // from +inf:  `if val < min_val` is STRICT, so the lowest index wins ties, NaN
 // never wins, +inf (LL = -inf) never wins, -inf (LL = +inf) does.
 //
-// HBM-bound streaming read of 8 bytes per grid point, two launches: a fixed
-// 256-workgroup grid-stride pass (one workgroup per CU) that leaves one
-// candidate per workgroup, then one workgroup over the 256 candidates.  No
-// atomics, so the result is deterministic.
+// HBM-bound streaming read of 8 bytes per grid point, two launches: a
+// grid-stride pass of at most 256 workgroups (one per CU) that leaves one
+// candidate per workgroup, then one workgroup over the candidates.  No
+// atomics, so the result is deterministic.  The first pass also re-evaluates
+// the points a recurrence kernel handed back (redo marker, direct_point.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
+#include "direct_point.h"
 #include "kernels.h"
 #include "wave.h"
 
@@ -60,15 +64,35 @@ __device__ __forceinline__ Cand block_best(Cand c)
     return wave_best(r); // valid in wave 0
 }
 
-__global__ __launch_bounds__(256) void argmin_stage1(const double *__restrict__ ll, int64_t n,
-                                                     double *__restrict__ pv, int64_t *__restrict__ pi)
+// First stage, fused with the hand-back of the recurrence kernels: a point whose value is the
+// redo marker (direct_point.h: a key with h_j != 0 has a subnormal p_j there) is evaluated again,
+// term by term, by the whole wave that meets it, and the LL buffer is patched in place.  Such points
+// are rare (a model that gives probability 1e-310 to a key that was observed); without any, the
+// pass costs one compare per point on top of the 8-byte read.
+template <int P>
+__global__ __launch_bounds__(256) void argmin_stage1(const DevModel m, const PointSource src, double *__restrict__ ll,
+                                                     int64_t n, double *__restrict__ pv, int64_t *__restrict__ pi)
 {
     Cand c;
     c.v = INFINITY;
     c.i = INT64_MAX;
+    const int lane = threadIdx.x & (kWave - 1);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double v = -ll[i];
+    // wave-uniform trip count: lanes past the end hold +inf
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < n; base += stride) {
+        const int64_t i = base + lane;
+        double val = i < n ? ll[i] : -INFINITY;
+        uint64_t redo = __ballot(i < n && is_redo_marker(val));
+        while (redo) { // wave-uniform
+            const int who = __builtin_ctzll(redo);
+            redo &= redo - 1;
+            const double again = direct_point_ll<P, false>(m, src, base + who, nullptr);
+            if (lane == who) {
+                val = again;
+                ll[i] = again;
+            }
+        }
+        const double v = -val;
         // ascending i within a thread: strict < keeps the first occurrence
         if (v < c.v) {
             c.v = v;
@@ -83,7 +107,7 @@ __global__ __launch_bounds__(256) void argmin_stage1(const double *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void argmin_stage2(const double *__restrict__ pv,
-                                                     const int64_t *__restrict__ pi, int n_part,
+                                                     const int64_t *__restrict__ pi, int n_part, int64_t flat_begin,
                                                      ArgminResult *__restrict__ result)
 {
     Cand c;
@@ -99,18 +123,27 @@ __global__ __launch_bounds__(256) void argmin_stage2(const double *__restrict__ 
     if (threadIdx.x == 0) {
         result->min_negll = c.v;
         result->index = (c.i == INT64_MAX) ? -1 : c.i;
+        // the same as a pair of doubles with the GLOBAL flat index, for the cross-GPU exchange (flat indices
+        // stay below 2^53)
+        result->pair[0] = c.v;
+        result->pair[1] = (c.i == INT64_MAX) ? -1.0 : (double)(flat_begin + c.i);
     }
 }
 
 } // namespace
 
-hipError_t launch_argmin(const double *ll, int64_t n, double *partial_val, int64_t *partial_idx,
-                         ArgminResult *result, hipStream_t stream)
+hipError_t launch_argmin(const DevModel &m, const PointSource &src, double *ll, int64_t n, int64_t flat_begin,
+                         double *partial_val, int64_t *partial_idx, ArgminResult *result, hipStream_t stream)
 {
-    hipLaunchKernelGGL(argmin_stage1, dim3(kArgminBlocks), dim3(256), 0, stream, ll, n, partial_val,
-                       partial_idx);
-    hipLaunchKernelGGL(argmin_stage2, dim3(1), dim3(256), 0, stream, partial_val, partial_idx,
-                       kArgminBlocks, result);
+    // (a small grid needs no more workgroups than it has waves of points)
+    const int blocks = (int)std::min<int64_t>(kArgminBlocks, std::max<int64_t>(1, (n + 255) / 256));
+    if (m.kind == 0)
+        hipLaunchKernelGGL(argmin_stage1<2>, dim3(blocks), dim3(256), 0, stream, m, src, ll, n, partial_val,
+                           partial_idx);
+    else
+        hipLaunchKernelGGL(argmin_stage1<5>, dim3(blocks), dim3(256), 0, stream, m, src, ll, n, partial_val,
+                           partial_idx);
+    hipLaunchKernelGGL(argmin_stage2, dim3(1), dim3(256), 0, stream, partial_val, partial_idx, blocks, flat_begin, result);
     return hipGetLastError();
 }
 

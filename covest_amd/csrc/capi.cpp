@@ -17,6 +17,7 @@
 
 #include "../../include/covest_amd.h"
 #include "device_model.h"
+#include "direct_point.h"
 #include "kernels.h"
 
 using namespace covest;
@@ -84,6 +85,7 @@ struct covest_model {
     bool all_bins_ready = false;
     int64_t n_keys = 0;
     int hist_max = 0;    // max(self.hist)
+    int64_t key_max = 0; // the largest key the reference evaluates a pmf term for (0 if none is positive)
     double threshold = 0.0;
     bool has_threshold = true;
     // device storage of the two bin views
@@ -181,11 +183,51 @@ int threshold_for_point(const covest_model *m, const double *par)
                             clamp_one(m->dm, 4, par[4]), m->threshold, m->has_threshold, m->hist_max);
 }
 
-int use_device(const covest_model *m)
+// Every entry point works on ITS handle's device and leaves the calling thread's current device as it found
+// it: the caller (torch, another library, a rank bound to another GPU) never sees its device change underneath.
+class DeviceGuard {
+  public:
+    explicit DeviceGuard(int device)
+    {
+        had_prev_ = hipGetDevice(&prev_) == hipSuccess;
+        if (had_prev_ && prev_ == device)
+            return; // nothing to switch, nothing to restore
+        const hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess)
+            status_ = fail_hip(e, "hipSetDevice");
+        else
+            switched_ = true;
+    }
+    ~DeviceGuard()
+    {
+        if (switched_ && had_prev_)
+            (void)hipSetDevice(prev_);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+    int status() const { return status_; }
+
+  private:
+    int prev_ = 0;
+    bool had_prev_ = false, switched_ = false;
+    int status_ = COVEST_OK;
+};
+
+// device < 0 = the calling thread's current device (include/covest_amd.h); checked against the device count.
+int resolve_device(int device, const char *who, int *out)
 {
-    hipError_t e = hipSetDevice(m->device);
+    if (device < 0) {
+        hipError_t e = hipGetDevice(&device);
+        if (e != hipSuccess)
+            return fail_hip(e, "hipGetDevice");
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess)
-        return fail_hip(e, "hipSetDevice");
+        return fail_hip(e, "hipGetDeviceCount");
+    if (n_dev <= 0 || device >= n_dev)
+        return fail(COVEST_E_NO_DEVICE, std::string(who) + ": no such HIP device");
+    *out = device;
     return COVEST_OK;
 }
 
@@ -711,19 +753,11 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
                     "covest_model_create: repeats model needs a non-empty histogram "
                     "(max() of an empty dict raises in covest/models.py:186)");
 
-    int device = d->device;
-    if (device < 0) {
-        hipError_t e = hipGetDevice(&device);
-        if (e != hipSuccess)
-            return fail_hip(e, "hipGetDevice");
-    }
-    int n_dev = 0;
+    int device = 0;
     {
-        hipError_t e = hipGetDeviceCount(&n_dev);
-        if (e != hipSuccess)
-            return fail_hip(e, "hipGetDeviceCount");
-        if (n_dev <= 0 || device >= n_dev)
-            return fail(COVEST_E_NO_DEVICE, "covest_model_create: no such HIP device");
+        const int drc = resolve_device(d->device, "covest_model_create", &device);
+        if (drc != COVEST_OK)
+            return drc;
     }
 
     covest_model *m = new (std::nothrow) covest_model();
@@ -775,8 +809,10 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
         }
     }
     m->hist_max = d->n_keys > 0 ? hist_max : 0;
+    m->key_max = hist_max > 0 ? hist_max : 0;
 
-    int rc = use_device(m);
+    DeviceGuard dev_guard(m->device);
+    int rc = dev_guard.status();
     if (d->tail != 0.0) { // the evaluated view IS the full view
         m->host_all_key.clear();
     } else {
@@ -804,7 +840,7 @@ void covest_model_destroy(covest_model *m)
 {
     if (!m)
         return;
-    (void)hipSetDevice(m->device);
+    DeviceGuard dev_guard(m->device);
     m->bins_eval.release();
     m->bins_all.release();
     m->tiles_buf.release();
@@ -832,6 +868,43 @@ int covest_threshold_o(int64_t n, const double *q123, double threshold, int32_t 
         out[i] = threshold_o_host(q123[3 * i], q123[3 * i + 1], q123[3 * i + 2], threshold,
                                   has_threshold != 0, hist_max);
     return COVEST_OK;
+}
+
+// ---- where the REFERENCE overflows (documented divergence) ----
+// c_src/covest_poissonmodule.c:19-24 forms the whole product prod_{i<=j} (l / i) in x87 long double BEFORE any
+// scaling, so truncated_poisson(l, j) is +inf as soon as the running product passes LDBL_MAX -- its largest
+// value is reached at i = min(j, floor(l)): l^i / i!.  A likelihood evaluation calls it for every key j of the
+// histogram and every l = o * l_s, o < threshold_o (covest/models.py:92-97, :235-241); the largest l against the
+// largest key decides.  The kernels return the finite value the formula defines; this reports, per point,
+// whether the reference itself would have returned inf / NaN there (and optimize_grid, covest/grid.py:65-70,
+// would have selected it).
+static bool reference_product_overflows(long double l, int64_t j_max)
+{
+    if (!(l > 0.0L) || j_max < 1)
+        return false;
+    const long double i_top = std::min<long double>((long double)j_max, floorl(l));
+    if (i_top < 1.0L)
+        return false;
+    const long double ln_ldbl_max = 11356.523406294143949492L;
+    return i_top * logl(l) - lgammal(i_top + 1.0L) > ln_ldbl_max;
+}
+
+static bool reference_overflows_at(const DevModel &dm, int n_par, const double *par_in, int T, int64_t key_max)
+{
+    double par[kMaxParams] = {0, 0, 0, 0, 0};
+    for (int d = 0; d < n_par; ++d)
+        par[d] = clamp_one(dm, d, par_in[d]);
+    const double ck = par[0] * (double)(dm.r - dm.k + 1) / (double)dm.r; // covest/models.py:71-72
+    double l_max = 0.0;
+    for (int sidx = 0; sidx < dm.n_err; ++sidx) { // covest/models.py:76-79, same evaluation order
+        double v = ck * dm.pow3neg[sidx];
+        v = v * std::pow(1.0 - par[1], (double)(dm.k - sidx));
+        v = v * std::pow(par[1], (double)sidx);
+        if (v > l_max)
+            l_max = v;
+    }
+    const int o_max = n_par == 5 ? T - 1 : 1;
+    return o_max >= 1 && reference_product_overflows((long double)((double)o_max * l_max), key_max);
 }
 
 // Resolve COVEST_KERNEL_* for a request (g == nullptr: a point list).  Returns the
@@ -888,6 +961,56 @@ static hipError_t launch_ll(const covest_model *m, int kernel, const PointSource
     return launch_ll_direct(m->dm, src, n, out, nullptr, st);
 }
 
+static bool is_redo_marker_host(double v)
+{
+    unsigned long long bits;
+    std::memcpy(&bits, &v, sizeof bits);
+    return bits == kRedoBits;
+}
+
+static double redo_marker_host()
+{
+    const unsigned long long bits = kRedoBits;
+    double v;
+    std::memcpy(&v, &bits, sizeof v);
+    return v;
+}
+
+// Point lists: the points a recurrence kernel handed back (redo marker in out_ll, direct_point.h: a key with
+// h_j != 0 has a subnormal p_j there) are evaluated by K-direct and patched.  Called with the model locked.
+static int redo_points_direct(covest_model *m, int64_t n, const double *params, double *out_ll)
+{
+    std::vector<int64_t> again;
+    for (int64_t i = 0; i < n; ++i)
+        if (is_redo_marker_host(out_ll[i]))
+            again.push_back(i);
+    if (again.empty())
+        return COVEST_OK;
+    const int P = m->n_par;
+    std::vector<double> sub_par(again.size() * (size_t)P);
+    std::vector<int32_t> sub_t(again.size(), 2);
+    for (size_t k = 0; k < again.size(); ++k) {
+        std::memcpy(&sub_par[k * (size_t)P], params + again[k] * P, (size_t)P * sizeof(double));
+        if (P == 5)
+            sub_t[k] = threshold_for_point(m, params + again[k] * P);
+    }
+    HIP_TRY(m->ws_params.reserve(sub_par.size() * sizeof(double)));
+    HIP_TRY(m->ws_t.reserve(sub_t.size() * sizeof(int32_t)));
+    HIP_TRY(m->ws_out.reserve(again.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(m->ws_params.ptr, sub_par.data(), sub_par.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->ws_t.ptr, sub_t.data(), sub_t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    PointSource src{};
+    src.is_grid = 0;
+    src.params = m->ws_params.as<double>();
+    src.t_list = P == 5 ? m->ws_t.as<int32_t>() : nullptr;
+    HIP_TRY(launch_ll_direct(m->dm, src, (int64_t)again.size(), m->ws_out.as<double>(), nullptr, nullptr));
+    std::vector<double> got(again.size());
+    HIP_TRY(hipMemcpy(got.data(), m->ws_out.ptr, got.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < again.size(); ++k)
+        out_ll[again[k]] = got[k];
+    return COVEST_OK;
+}
+
 int covest_eval_points(covest_model *m, int64_t n, const double *params, double *out_ll,
                        int32_t kernel)
 {
@@ -904,7 +1027,8 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         kern = COVEST_KERNEL_DIRECT; // AUTO: throughput work
     }
     std::lock_guard<std::mutex> guard(m->lock);
-    int rc = use_device(m);
+    DeviceGuard dev_guard(m->device);
+    int rc = dev_guard.status();
     if (rc != COVEST_OK)
         return rc;
     const int P = m->n_par;
@@ -958,9 +1082,13 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
             HIP_TRY(hipMemcpy(got.data(), m->ws_partial.ptr, got.size() * sizeof(double), hipMemcpyDeviceToHost));
             for (size_t k = 0; k < fits.size(); ++k) {
                 double ll = 0.0, hi = 0.0, lo = 0.0;
+                bool redo = false; // a segment met a subnormal p_j with weight (ll_factored.hip, phase C)
                 for (int sg = 0; sg < pl.n_seg; ++sg) {
                     const double *o = &got[(k * (size_t)pl.n_seg + (size_t)sg) * 3];
-                    ll += o[0];
+                    if (is_redo_marker_host(o[0]))
+                        redo = true;
+                    else
+                        ll += o[0];
                     const double sum = hi + o[1], bb = sum - hi; // two-sum, as the kernels' CompSum
                     lo += ((hi - (sum - bb)) + (o[1] - bb)) + o[2];
                     hi = sum;
@@ -973,7 +1101,8 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
                     if (sp < 1.0)
                         tail_term = m->dm.tail * std::log(1.0 - sp);
                 }
-                out_ll[fits[k]] = ll + tail_term;
+                const double v = ll + tail_term;
+                out_ll[fits[k]] = redo && std::isfinite(v) ? redo_marker_host() : v;
             }
         }
         if (!big.empty()) {
@@ -1031,10 +1160,24 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
             for (size_t k = 0; k < rest.size(); ++k)
                 out_ll[rest[k]] = got[k];
         }
-        return COVEST_OK;
+        return redo_points_direct(m, n, params, out_ll);
     }
     HIP_TRY(launch_ll(m, kern, src, n, m->ws_out.as<double>(), nullptr, nullptr));
     HIP_TRY(hipMemcpy(out_ll, m->ws_out.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (kern == COVEST_KERNEL_RECUR)
+        return redo_points_direct(m, n, params, out_ll);
+    return COVEST_OK;
+}
+
+int covest_reference_overflow(const covest_model *m, int64_t n, const double *params, uint8_t *flags)
+{
+    if (!m || n < 0 || (n > 0 && (!params || !flags)))
+        return fail(COVEST_E_INVALID, "covest_reference_overflow: bad argument");
+    const int P = m->n_par;
+    for (int64_t i = 0; i < n; ++i) {
+        const int T = P == 5 ? threshold_for_point(m, params + i * P) : 2;
+        flags[i] = reference_overflows_at(m->dm, P, params + i * P, T, m->key_max) ? 1 : 0;
+    }
     return COVEST_OK;
 }
 
@@ -1045,7 +1188,8 @@ int covest_probabilities(covest_model *m, const double *params, int32_t clamp, d
     if (m->n_keys == 0)
         return COVEST_OK;
     std::lock_guard<std::mutex> guard(m->lock);
-    int rc = use_device(m);
+    DeviceGuard dev_guard(m->device);
+    int rc = dev_guard.status();
     if (rc != COVEST_OK)
         return rc;
     const int P = m->n_par;
@@ -1111,7 +1255,8 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
     const int64_t n = flat_end - flat_begin;
 
     std::lock_guard<std::mutex> guard(m->lock);
-    int rc = use_device(m);
+    DeviceGuard dev_guard(m->device);
+    int rc = dev_guard.status();
     auto bail = [&](int code) {
         g->axes.release();
         g->t_table.release();
@@ -1197,7 +1342,7 @@ void covest_grid_destroy(covest_grid *g)
 {
     if (!g)
         return;
-    (void)hipSetDevice(g->model->device);
+    DeviceGuard dev_guard(g->model->device);
     g->axes.release();
     g->t_table.release();
     g->ll.release();
@@ -1225,7 +1370,8 @@ int covest_grid_kernel_ms(covest_grid *g, double *total_ms, int64_t *launches)
 {
     if (!g || !total_ms || !launches)
         return fail(COVEST_E_INVALID, "covest_grid_kernel_ms: null argument");
-    int rc = use_device(g->model);
+    DeviceGuard dev_guard(g->model->device);
+    int rc = dev_guard.status();
     if (rc != COVEST_OK)
         return rc;
     double sum = 0.0;
@@ -1251,7 +1397,8 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
     if (kern < 0)
         return kern;
     std::lock_guard<std::mutex> guard(m->lock);
-    int rc = use_device(m);
+    DeviceGuard dev_guard(m->device);
+    int rc = dev_guard.status();
     if (rc != COVEST_OK)
         return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1274,7 +1421,7 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
     g->last_kernel_id = kern;
     if (e1)
         HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->partial_val.as<double>(),
+    HIP_TRY(launch_argmin(m->dm, g->src, g->ll.as<double>(), n, g->flat_begin, g->partial_val.as<double>(),
                           g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), st));
     g->last_stream = st;
     g->evaluated = true;
@@ -1287,7 +1434,8 @@ int covest_grid_argmin(covest_grid *g, double *min_negll, int64_t *argmin_flat)
         return fail(COVEST_E_INVALID, "covest_grid_argmin: null argument");
     if (!g->evaluated)
         return fail(COVEST_E_INVALID, "covest_grid_argmin: covest_grid_eval has not run");
-    int rc = use_device(g->model);
+    DeviceGuard dev_guard(g->model->device);
+    int rc = dev_guard.status();
     if (rc != COVEST_OK)
         return rc;
     ArgminResult r;
@@ -1300,13 +1448,19 @@ int covest_grid_argmin(covest_grid *g, double *min_negll, int64_t *argmin_flat)
 
 const double *covest_grid_ll_device(const covest_grid *g) { return g ? g->ll.as<double>() : nullptr; }
 
+const double *covest_grid_argmin_pair_device(const covest_grid *g)
+{
+    return g ? g->result.as<ArgminResult>()->pair : nullptr; // (address arithmetic only: nothing is read here)
+}
+
 int covest_grid_ll_host(covest_grid *g, double *out_ll)
 {
     if (!g || !out_ll)
         return fail(COVEST_E_INVALID, "covest_grid_ll_host: null argument");
     if (!g->evaluated)
         return fail(COVEST_E_INVALID, "covest_grid_ll_host: covest_grid_eval has not run");
-    int rc = use_device(g->model);
+    DeviceGuard dev_guard(g->model->device);
+    int rc = dev_guard.status();
     if (rc != COVEST_OK)
         return rc;
     const int64_t n = g->flat_end - g->flat_begin;
@@ -1365,10 +1519,10 @@ int covest_kmer_create(int32_t k, int32_t canonical, int64_t min_slots, int32_t 
     *out = nullptr;
     if (k < 1 || k > 31)
         return fail(COVEST_E_INVALID, "covest_kmer_create: k must be in 1..31 (2k bits + an empty marker in 64)");
-    if (device < 0) {
-        hipError_t e = hipGetDevice(&device);
-        if (e != hipSuccess)
-            return fail_hip(e, "hipGetDevice");
+    {
+        const int drc = resolve_device(device, "covest_kmer_create", &device);
+        if (drc != COVEST_OK)
+            return drc;
     }
     covest_kmer *c = new (std::nothrow) covest_kmer();
     if (!c)
@@ -1376,8 +1530,9 @@ int covest_kmer_create(int32_t k, int32_t canonical, int64_t min_slots, int32_t 
     c->device = device;
     c->k = k;
     c->canonical = canonical != 0;
-    hipError_t e = hipSetDevice(device);
-    int rc = e == hipSuccess ? COVEST_OK : fail_hip(e, "hipSetDevice");
+    DeviceGuard dev_guard(device);
+    hipError_t e = hipSuccess;
+    int rc = dev_guard.status();
     if (rc == COVEST_OK)
         rc = kmer_alloc_table(c, min_slots, c->table, c->slots);
     if (rc == COVEST_OK) {
@@ -1401,7 +1556,7 @@ void covest_kmer_destroy(covest_kmer *c)
 {
     if (!c)
         return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dev_guard(c->device);
     c->slots.release();
     c->flag.release();
     c->stats.release();
@@ -1418,7 +1573,9 @@ int covest_kmer_clear(covest_kmer *c, void *stream)
     if (!c)
         return fail(COVEST_E_INVALID, "covest_kmer_clear: null counter");
     std::lock_guard<std::mutex> guard(c->lock);
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
     HIP_TRY(launch_kmer_fill_empty(c->table, static_cast<hipStream_t>(stream)));
     HIP_TRY(hipMemsetAsync(c->flag.ptr, 0, sizeof(int), static_cast<hipStream_t>(stream)));
     return COVEST_OK;
@@ -1431,7 +1588,9 @@ int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
     std::lock_guard<std::mutex> guard(c->lock);
     if ((int64_t)(c->table.mask + 1) >= min_slots)
         return COVEST_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
     KmerTable bigger{};
     DevBuf slots;
     int rc = kmer_alloc_table(c, min_slots, bigger, slots);
@@ -1439,6 +1598,10 @@ int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
         slots.release();
         return rc;
     }
+    // the flag now reports THIS rehash only: an overflow of an earlier covest_kmer_add has been reported by
+    // that call (the batch it was inserting is partly counted -- see the header: clear and recount, or count
+    // through covest_amd.kmer_hist, which grows ahead of every batch)
+    HIP_TRY(hipMemset(c->flag.ptr, 0, sizeof(int)));
     HIP_TRY(launch_kmer_rehash(c->table, bigger, c->flag.as<int>(), nullptr));
     HIP_TRY(hipDeviceSynchronize());
     c->slots.release();
@@ -1453,7 +1616,9 @@ int covest_kmer_add_device(covest_kmer *c, const uint8_t *d_bases, const int64_t
     if (!c || n_reads < 0 || (n_reads > 0 && !d_bases) || (!d_offsets && read_len < 0))
         return fail(COVEST_E_INVALID, "covest_kmer_add_device: bad argument");
     std::lock_guard<std::mutex> guard(c->lock);
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
     HIP_TRY(launch_kmer_count(d_bases, d_offsets, n_reads, read_len, c->k, c->canonical, c->table,
                               c->flag.as<int>(), static_cast<hipStream_t>(stream)));
     return COVEST_OK;
@@ -1468,9 +1633,11 @@ int covest_kmer_add(covest_kmer *c, const uint8_t *bases, const int64_t *offsets
     const int64_t n_bytes = offsets[n_reads] - offsets[0];
     if (n_bytes < 0 || (n_bytes > 0 && !bases))
         return fail(COVEST_E_INVALID, "covest_kmer_add: bad offsets");
+    DeviceGuard dev_guard(c->device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
     {
         std::lock_guard<std::mutex> guard(c->lock);
-        HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(c->ws_bases.reserve((size_t)(n_bytes > 0 ? n_bytes : 1)));
         HIP_TRY(c->ws_offsets.reserve((size_t)(n_reads + 1) * sizeof(int64_t)));
         if (n_bytes > 0)
@@ -1493,7 +1660,9 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
     if (!c)
         return fail(COVEST_E_INVALID, "covest_kmer_histogram: null counter");
     std::lock_guard<std::mutex> guard(c->lock);
-    HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard dev_guard(c->device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
     HIP_TRY(hipDeviceSynchronize());
     int rc = kmer_check_overflow(c);
     if (rc != COVEST_OK)
@@ -1535,11 +1704,14 @@ static int thin_histogram_impl(int32_t device, int64_t n, const int32_t *keys, c
         *kernel_ms = 0.0;
     if (out_len == 0)
         return COVEST_OK;
-    int n_dev = 0;
-    HIP_TRY(hipGetDeviceCount(&n_dev));
-    if (n_dev < 1)
-        return fail(COVEST_E_NO_DEVICE, "covest_thin_histogram: no HIP device");
-    HIP_TRY(hipSetDevice(device < 0 ? 0 : device));
+    {
+        const int drc = resolve_device(device, "covest_thin_histogram", &device);
+        if (drc != COVEST_OK)
+            return drc;
+    }
+    DeviceGuard dev_guard(device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
     const int64_t top = std::max<int64_t>(max_key, out_len);
     std::vector<double> lgam((size_t)top + 1);
     for (int64_t v = 0; v <= top; ++v)

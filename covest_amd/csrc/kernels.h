@@ -35,10 +35,13 @@ hipError_t launch_ll_finish_partials(const DevModel &m, const TileView &tv, cons
 constexpr int kArgminBlocks = 256;
 struct ArgminResult {
     double min_negll;
-    int64_t index; // local index, -1 if no value is < +inf
+    int64_t index;  // local index, -1 if no value is < +inf
+    double pair[2]; // {min_negll, GLOBAL flat index as a double (-1 if none)}: what the ranks exchange
 };
-hipError_t launch_argmin(const double *ll, int64_t n, double *partial_val, int64_t *partial_idx,
-                         ArgminResult *result, hipStream_t stream);
+// The first pass also replaces every redo marker in ll (direct_point.h) by K-direct's value of that point:
+// m / src must be the model and point source the LL kernel ran with.
+hipError_t launch_argmin(const DevModel &m, const PointSource &src, double *ll, int64_t n, int64_t flat_begin,
+                         double *partial_val, int64_t *partial_idx, ArgminResult *result, hipStream_t stream);
 
 // ---- K-kmer: k-mer abundance histogram (kmer_count.hip), SURVEY 8(f) row F1 ----
 // Open-addressing table in HBM, slots = 2^log2_slots, one 16-byte entry per slot: {key, count}

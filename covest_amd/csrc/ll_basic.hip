@@ -19,6 +19,7 @@
 // Algorithmic HBM bytes: 16 in (or the two axes) + 8 out per point.
 #include <hip/hip_runtime.h>
 
+#include "direct_point.h"
 #include "fastmath.h"
 #include "kernels.h"
 #include "point_fetch.h"
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     double acc_ll = 0.0;
     uint64_t dead = 0; // lanes that met a p_j <= 0 with h_j != 0
+    uint64_t tiny = 0; // lanes that met a p_j below the normal range with h_j != 0 (p_j <= 0 included)
     CompSum acc_sp = {0.0, 0.0};
 
     // one key's p_j (flushed like the reference's double): into sp_j, and its log (all branches
@@ -73,6 +75,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // utils.safe_log: p_j <= 0 makes the whole sum -inf.  Remembered as a lane mask in
             // SGPRs (one compare) instead of a select per key; fast_log(0) is finite.
             dead |= __ballot(p <= 0.0);
+            // a SUBNORMAL p_j: the reference's value hangs on the rounding of every single term onto the
+            // 4.9e-324 grid -- the point is handed to the term-by-term kernel
+            tiny |= __ballot(p < kMinNormal);
             acc_ll = fma(h, fast_log(p, log_tab), acc_ll);
         }
     };
@@ -124,6 +129,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if ((dead >> (threadIdx.x & (kWave - 1))) & 1)
         acc_ll = isnan(acc_ll) ? acc_ll : -INFINITY; // h * -inf summed with finite terms
     double ll = acc_ll + tail_term;
+    if (((tiny & ~dead) >> (threadIdx.x & (kWave - 1))) & 1)
+        ll = isfinite(ll) ? redo_marker() : ll; // replaced by K-direct's value before anyone sees it
     if (!finite)
         ll = NAN; // a NaN parameter poisons every p_j in the reference
     if (live)

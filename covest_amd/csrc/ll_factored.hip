@@ -38,7 +38,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 
+#include "direct_point.h"
 #include "fastmath.h"
 #include "kernels.h"
 #include "point_fetch.h"
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU];
     double r4[MU], llacc[MU];
     uint64_t dead[MU]; // lanes that met a p_j <= 0 with h_j != 0
+    uint64_t tiny[MU]; // lanes that met a p_j below the normal range (<= 0 included) with h_j != 0
     CompSum spacc[MU];
     // wave w's block of MU slots in the unit tables
     auto wave_block = [&](int w) -> int {
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         r4[k] = plan.q_r4[slot];
         llacc[k] = 0.0;
         dead[k] = 0;
+        tiny[k] = 0;
         spacc[k].hi = 0.0;
         spacc[k].lo = 0.0;
     }
@@ -324,6 +328,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     // covest/models.py:106) and add 0 * log p -- fast_log(0) is finite.  utils.safe_log:
                     // p_j <= 0 with h_j != 0 makes the sum -inf; kept as a lane mask in SGPRs.
                     dead[k] |= __ballot(p <= 0.0 && h != 0.0);
+                    // a SUBNORMAL p_j: the reference's value hangs on the rounding of every single term onto
+                    // the 4.9e-324 grid -- such a point is handed to the strict kernel
+                    tiny[k] |= __ballot(p < kMinNormal && h != 0.0);
                     llacc[k] = fma(h, fast_log(p, log_tab), llacc[k]);
                 }
                 __builtin_amdgcn_sched_barrier(0); // ... one unit at a time: registers
@@ -350,6 +357,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     double *part_ll = Gs;                               // [NW][MU][16]
     double *part_hi = Gs + (size_t)NW * MU * 16; // compensated sp_j parts
     double *part_lo = part_hi + (size_t)NW * MU * 16;
+    double *part_sub = part_lo + (size_t)NW * MU * 16; // > 0: a subnormal p_j with weight was met (and no p_j <= 0)
 #pragma unroll
     for (int k = 0; k < MU; ++k) {
         double ll = llacc[k];
@@ -357,6 +365,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             ll = isnan(ll) ? ll : -INFINITY; // h * -inf summed with finite terms
         ll += __shfl_xor(ll, 16, kWave);
         ll += __shfl_xor(ll, 32, kWave);
+        double sub = ((tiny[k] & ~dead[k]) >> lane) & 1 ? 1.0 : 0.0;
+        sub += __shfl_xor(sub, 16, kWave);
+        sub += __shfl_xor(sub, 32, kWave);
         CompSum sp = spacc[k];
         if (TAIL) {
 #pragma unroll
@@ -371,6 +382,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         if (lane < 16) {
             const int at = (wave * MU + k) * 16 + lane;
             part_ll[at] = ll;
+            part_sub[at] = sub;
             if (TAIL) {
                 part_hi[at] = sp.hi;
                 part_lo[at] = sp.lo;
@@ -395,6 +407,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
             }
         const double ll = part_ll[e] + (pe >= 0 ? part_ll[pe] : 0.0);
+        const bool sub = part_sub[e] + (pe >= 0 ? part_sub[pe] : 0.0) > 0.0;
         double tail_term = 0.0;
         double hi = 0.0, lo = 0.0;
         if (TAIL) {
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         if (plan.list_mode == 1) { // a key segment of a point: {LL part, sp_j part (hi, lo)}; the host adds the segments
             if (plan.q_orig[qt * 16 + c] >= 0) {
                 double *o = plan.partial + ((int64_t)ce * n_seg + seg) * 3;
-                o[0] = finite ? ll : NAN;
+                o[0] = !finite ? NAN : (sub && isfinite(ll)) ? redo_marker() : ll;
                 o[1] = hi;
                 o[2] = lo;
             }
@@ -425,8 +438,12 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const int32_t qo = plan.q_orig[qt * 16 + c];
         if (qo >= 0) {
             const int64_t flat = ce * plan.n_q + qo;
-            if (flat >= plan.flat_begin && flat < plan.flat_end)
-                out_ll[flat - plan.flat_begin] = finite ? ll + tail_term : NAN;
+            if (flat >= plan.flat_begin && flat < plan.flat_end) {
+                double v = ll + tail_term;
+                if (sub && isfinite(v))
+                    v = redo_marker(); // replaced by K-direct's value in the arg-min pass (argmin.hip)
+                out_ll[flat - plan.flat_begin] = finite ? v : NAN;
+            }
         }
     }
 }
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, co
     const int c0 = first_item[p], c1 = first_item[p + 1];
     const int64_t n_keys = (int64_t)n_tiles * kTileBins;
     double ll = 0.0;
-    bool dead = false;
+    bool dead = false, sub = false, poisoned = false;
     CompSum sp = {0.0, 0.0};
     for (int64_t key = lane; key < n_keys; key += kWave) {
         double pj = 0.0;
@@ -456,6 +473,8 @@ __global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, co
             sp.add(pj);
         if (h != 0.0) {
             dead |= pj <= 0.0; // utils.safe_log
+            sub |= pj > 0.0 && pj < kMinNormal; // see ll_factored_kernel, phase C
+            poisoned |= pj != pj; // a NaN parameter: NaN, as in the reference (math.log(nan))
             ll = fma(h, log(pj > 0.0 ? pj : 1.0), ll);
         }
     }
@@ -472,8 +491,13 @@ __global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, co
         ll = isnan(ll) ? ll : -INFINITY;
     double par[kMaxParams] = {point_ce[2 * p], point_ce[2 * p + 1], 0, 0, 0};
     clamp_point<2>(m, par);
+    double v = ll + tail_term;
+    if (__ballot(sub) && isfinite(v))
+        v = redo_marker();
+    if (__ballot(poisoned) || !(isfinite(par[0]) && isfinite(par[1])))
+        v = NAN;
     if (lane == 0)
-        out_ll[p] = isfinite(par[0]) && isfinite(par[1]) ? ll + tail_term : NAN;
+        out_ll[p] = v;
 }
 
 template <int NT, int HU, bool TAIL>
@@ -482,9 +506,13 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
 {
     // + 64 zeroed doubles: the last piece of a unit may run a few (masked, weight 0) steps past the end
     // of a G row; what it reads there must be finite
-    const size_t lds = ((size_t)plan.n_buf * kTileBins * plan.ld + 64) * sizeof(double);
+    // (the per-q combine at the end reuses the buffer for four [waves][slots][16] arrays)
+    const size_t lds = std::max((size_t)plan.n_buf * kTileBins * plan.ld + 64, (size_t)4 * (NT / kWave) * 2 * HU * 16) *
+                       sizeof(double);
     // the dynamic-LDS ceiling is a per-device attribute of the kernel: raise it once per device
     static size_t configured[64] = {0};
+    static std::mutex configured_lock; // two model handles may be used from two host threads
+    std::lock_guard<std::mutex> guard(configured_lock);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         dev = 0;

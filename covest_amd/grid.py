@@ -65,40 +65,71 @@ def partition_flat_range(total, world_size, weights=None, period=None):
     return bounds
 
 
-def distributed_argmin(local_min, local_idx, group=None, device=None):
+def scan_min_pairs(pairs):
+    """The selection scan of covest/grid.py:65-70 over the ranks' (min -LL, lowest flat index) pairs, taken in
+    rank order (= flat-index order of the blocks): strict <, the lowest index wins a tie, NaN never wins, an
+    index < 0 means "this block had nothing below +inf".  Returns (min, index), (inf, -1) if nobody has one.
+    The host-side statement of the rule; `_scan_pairs_tensor` is the same on a tensor."""
+    best, arg = math.inf, -1
+    for val, idx in pairs:
+        val, idx = float(val), int(idx)
+        if idx < 0 or val != val or val == math.inf:
+            continue
+        if val < best or (val == best and idx < arg):
+            best, arg = val, idx
+    return best, arg
+
+
+def _scan_pairs_tensor(gathered):
+    """scan_min_pairs on a (world, 2) float64 tensor, wherever it lives (HBM after an RCCL all-gather, host memory
+    under gloo): returns a 2-element tensor {min, index} -- index -1 if nothing is below +inf."""
+    import torch
+    vals, idx = gathered[:, 0], gathered[:, 1]
+    inf = torch.full_like(vals, math.inf)
+    vals = torch.where((idx < 0) | torch.isnan(vals), inf, vals)
+    best = vals.min()
+    arg = torch.where(vals == best, idx, inf).min()  # the lowest index among the holders of the minimum
+    arg = torch.where(best < math.inf, arg, torch.full_like(arg, -1.0))
+    return torch.stack([best, arg])
+
+
+def distributed_argmin(local_min, local_idx, group=None, device=None, pair=None):
     """Global (min, lowest flat index) from every rank's local pair.
 
     RCCL has no MINLOC for fp64.  ONE collective: every rank contributes the 16-byte pair
     (value, index as an exactly representable double -- flat indices stay below 2^53) to an all-gather
     and scans the N pairs itself: strict <, lowest index on ties, as the scan of covest/grid.py:65-70
     would over the concatenated blocks.  NaN is mapped to +inf first (a NaN never wins, :67).
+    `pair`: the rank's pair already in a 2-element float64 tensor (DenseGrid.argmin_pair_tensor: the arg-min
+    kernel's own output in HBM) -- then nothing visits the host between the likelihood kernel and the
+    collective; the gathered pairs are scanned where they land and 16 bytes are copied back, once.
     Works with any backend (nccl == RCCL on GPUs, gloo on CPU for tests).
     Without an initialised process group this is the identity.
     """
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if pair is not None:
+            v, i = pair.cpu().tolist()
+            return v, int(i)
         return local_min, local_idx
     world = dist.get_world_size(group)
-    v = float(local_min)
-    if v != v or local_idx < 0:
-        v, local_idx = math.inf, -1
-    if local_idx >= 1 << 53:
-        raise ValueError("flat index does not fit a double exactly")
-    pair = torch.tensor([v, float(local_idx)], dtype=torch.float64, device=device)
-    gathered = torch.empty((world, 2), dtype=torch.float64, device=device)
+    if pair is None:
+        v = float(local_min)
+        if v != v or local_idx < 0:
+            v, local_idx = math.inf, -1
+        if local_idx >= 1 << 53:
+            raise ValueError("flat index does not fit a double exactly")
+        pair = torch.tensor([v, float(local_idx)], dtype=torch.float64, device=device)
+    gathered = torch.empty((world, 2), dtype=torch.float64, device=pair.device)
     try:
         dist.all_gather_into_tensor(gathered, pair, group=group)
     except (RuntimeError, AttributeError, NotImplementedError):  # a backend without the flat variant
-        parts = [torch.empty(2, dtype=torch.float64, device=device) for _ in range(world)]
+        parts = [torch.empty(2, dtype=torch.float64, device=pair.device) for _ in range(world)]
         dist.all_gather(parts, pair, group=group)
         gathered = torch.stack(parts)
-    best, arg = math.inf, -1
-    for val, idx in gathered.cpu().tolist():
-        idx = int(idx)
-        if idx >= 0 and (val < best or (val == best and val < math.inf and idx < arg)):
-            best, arg = val, idx
-    return best, arg
+    best, arg = _scan_pairs_tensor(gathered).cpu().tolist()  # the only copy to the host: 16 bytes
+    return best, int(arg)
 
 
 # --------------------------------------------------------------------------- dense grid
@@ -167,6 +198,18 @@ class DenseGrid:
     def ll_device_ptr(self):
         return _capi.lib().covest_grid_ll_device(self._handle)
 
+    def argmin_pair_tensor(self, device_index):
+        """The reduction of the last evaluate() where the arg-min kernel left it: a 2-element float64 torch
+        tensor {min -LL, GLOBAL flat index (-1: none)} aliasing the handle's 16 bytes in HBM (no copy, no
+        synchronisation: consume it on the stream evaluate() ran on)."""
+        import torch
+        ptr = _capi.lib().covest_grid_argmin_pair_device(self._handle)
+
+        class _View:  # the CUDA array interface is how torch adopts foreign device memory (HIP included)
+            __cuda_array_interface__ = {"shape": (2,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+        return torch.as_tensor(_View(), device=torch.device("cuda", device_index))
+
     def work(self):
         """(pmf terms, algorithmic flops, kernel name) of the last evaluate()."""
         t, f, name = ctypes.c_double(), ctypes.c_double(), ctypes.c_char_p()
@@ -218,13 +261,16 @@ def dense_grid_argmin(model, axes, kernel="auto", group=None, balance=True):
     bounds = partition_flat_range(total, world, weights)
     grid = DenseGrid(model, axes, (bounds[rank], bounds[rank + 1]))
     try:
-        grid.evaluate(kernel=kernel)
-        local_min, local_idx = grid.argmin()
-        device = None
         if world > 1 and dist.get_backend(group) == "nccl":
+            # likelihood, arg-min, exchange and scan all on the current stream; one 16-byte copy at the end
             import torch
-            device = torch.device("cuda", torch.cuda.current_device())
-        gmin, gidx = distributed_argmin(local_min, local_idx, group=group, device=device)
+            grid.evaluate(kernel=kernel, stream=torch.cuda.current_stream().cuda_stream)
+            gmin, gidx = distributed_argmin(None, None, group=group,
+                                            pair=grid.argmin_pair_tensor(torch.cuda.current_device()))
+        else:
+            grid.evaluate(kernel=kernel)
+            local_min, local_idx = grid.argmin()
+            gmin, gidx = distributed_argmin(local_min, local_idx, group=group)
         params = grid.point(gidx) if gidx >= 0 else None
     finally:
         grid.close()

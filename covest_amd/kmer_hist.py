@@ -73,7 +73,8 @@ class KmerCounts:
     def __init__(self, k=20, canonical=False, device=-1, min_slots=1 << 16):
         self.k = int(k)
         self.canonical = bool(canonical)
-        self._added = 0  # upper bound of the k-mers inserted so far
+        self._distinct = 0  # distinct k-mers in the table when last measured
+        self._added = 0     # k-mer occurrences inserted since: _distinct + _added bounds the distinct count
         h = ctypes.c_void_p()
         _capi.check(_capi.lib().covest_kmer_create(self.k, 1 if canonical else 0, int(min_slots),
                                                    int(device), ctypes.byref(h)), "covest_kmer_create")
@@ -95,9 +96,17 @@ class KmerCounts:
         return int(_capi.lib().covest_kmer_slots(self._handle))
 
     def _reserve_for(self, n_new):
-        self._added += int(n_new)
-        _capi.check(_capi.lib().covest_kmer_reserve(self._handle, 2 * self._added + 1024),
-                    "covest_kmer_reserve")
+        """Keep the table at most half full of DISTINCT k-mers.  The distinct count is bounded by what was
+        measured last plus every occurrence inserted since; only when that bound no longer fits is the table
+        asked (one small kernel), and it grows for the measured count plus the batch about to be added --
+        never for the cumulative number of occurrences (10 Gbp of reads of a 100 Mbp genome need a table for
+        ~1e8 k-mers, not 1e10)."""
+        n_new = int(n_new)
+        if 2 * (self._distinct + self._added + n_new) + 1024 > self.slots:
+            self._distinct, self._added = self.stats()[1], 0
+            _capi.check(_capi.lib().covest_kmer_reserve(self._handle, 2 * (self._distinct + n_new) + 1024),
+                        "covest_kmer_reserve")
+        self._added += n_new
 
     def add_reads(self, reads):
         """Count the k-mers of preprocessed reads (only a/c/g/t, either case) in one launch."""
@@ -130,7 +139,7 @@ class KmerCounts:
 
     def clear(self, stream=None):
         """Drop every count but keep the table (a fresh `defaultdict(int)` of the same size)."""
-        self._added = 0
+        self._distinct = self._added = 0
         _capi.check(_capi.lib().covest_kmer_clear(self._handle, ctypes.c_void_p(stream or 0)),
                     "covest_kmer_clear")
 

@@ -18,7 +18,7 @@ import sys
 
 import numpy as np
 
-from . import _capi
+from . import _capi, constants
 
 MODEL_CLASS_SUFFIX = 'Model'
 _DP = ctypes.POINTER(ctypes.c_double)
@@ -183,6 +183,18 @@ class BasicModel:
                         "covest_eval_points")
         return out
 
+    def reference_overflows(self, points):
+        """Where the REFERENCE's own evaluation would overflow to inf / NaN (its long-double pmf product is
+        formed before it is scaled, c_src/covest_poissonmodule.c:19-24) while this library returns the finite
+        value: boolean ndarray, one entry per point of an (n, param_count) array.  Host arithmetic only."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, self.param_count)
+        out = np.zeros(len(pts), dtype=np.uint8)
+        if len(pts):
+            _capi.check(_capi.lib().covest_reference_overflow(
+                self.handle, len(pts), _as_dp(pts), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))),
+                "covest_reference_overflow")
+        return out.astype(bool)
+
     def compute_probabilities(self, *args, clamp=False):
         """covest/models.py:81-98 (:211-242 for repeats): {j: p_j} for every key."""
         par = np.asarray([float(v) for v in args[:self.param_count]], dtype=np.float64)
@@ -195,9 +207,10 @@ class BasicModel:
         """covest/models.py:100-107."""
         return float(self.loglikelihood_points(self._points_array([args]))[0])
 
-    def compute_loglikelihood_multi(self, args_list, thread_count=None):
+    def compute_loglikelihood_multi(self, args_list, thread_count=constants.DEFAULT_THREAD_COUNT):
         """covest/models.py:109-117: {tuple(args): LL}.  One batched kernel launch
-        replaces Pool.starmap; thread_count is accepted and ignored."""
+        replaces Pool.starmap; thread_count (same default as the reference, None included) is
+        accepted and ignored."""
         args_list = list(args_list)
         lls = self.loglikelihood_points(self._points_array(args_list))
         return {tuple(args): float(ll) for args, ll in zip(args_list, lls)}

@@ -14,16 +14,17 @@ def estimate(input_histogram, kmer_size=constants.DEFAULT_K, read_length=constan
              model='basic', trim=None, sample_factor=None, coverage=None, error_rate=None, params=(), fix=False,
              start_original=False, starting_points=1, grid=False, error_scale=constants.DEFAULT_ERR_SCALE,
              max_coverage=None, min_q1=constants.DEFAULT_MIN_SINGLECOPY_RATIO, reads_size=None, silent=True,
-             rng=None, save_sampled=False):
+             rng=None, save_sampled=False, device=-1):
     """Returns the record print_output builds (and prints it unless `silent`).  `input_histogram` is a path or
-    a {count: multiplicity} dict.  Keyword names follow the reference's command line options."""
+    a {count: multiplicity} dict.  Keyword names follow the reference's command line options.  `device`: the HIP
+    ordinal every step runs on (-1 = the calling thread's current device)."""
     if isinstance(input_histogram, dict):
         hist_orig, meta, stem = dict(input_histogram), {}, 'histogram'
     else:
         hist_orig, meta = load_histogram(input_histogram)
         stem = Path(input_histogram).stem
     hist, tail, sample_factor, guess_c, guess_e = process_histogram(
-        hist_orig, kmer_size, read_length, trim=trim, sample_factor=sample_factor, rng=rng)
+        hist_orig, kmer_size, read_length, trim=trim, sample_factor=sample_factor, rng=rng, device=device)
     orig_sample_factor = 1
     if 'sample_factor' in meta:
         try:
@@ -36,7 +37,7 @@ def estimate(input_histogram, kmer_size=constants.DEFAULT_K, read_length=constan
     if coverage:
         coverage /= sample_factor
     m = select_model(model)(kmer_size, read_length, hist, tail, max_error=constants.MAX_ERRORS,
-                            max_cov=max_coverage, min_single_copy_ratio=min_q1)
+                            max_cov=max_coverage, min_single_copy_ratio=min_q1, device=device)
     given = [None] * m.param_count
     for i, v in zip(range(m.param_count), (coverage, error_rate) + tuple(params)):
         given[i] = v

@@ -108,6 +108,15 @@ int covest_threshold_o(int64_t n, const double *q123, double threshold, int32_t 
 int covest_eval_points(covest_model *m, int64_t n, const double *params, double *out_ll,
                        int32_t kernel);
 
+/* Documented divergence made visible: the reference forms its pmf product in x87 long double BEFORE
+ * scaling it (c_src/covest_poissonmodule.c:19-24), so for large rates against large keys
+ * (ln(l^i / i!) > 11356.5 at i = min(j, floor(l))) truncated_poisson returns +inf, the likelihood
+ * becomes +inf or NaN, and optimize_grid would select it (covest/grid.py:65-70).  This library
+ * returns the finite value the formula defines.  flags[i] = 1 where the reference itself would have
+ * overflowed at params[i] (HOST arrays, [n][param_count] and [n]); pure host arithmetic, no device
+ * work.  No benchmark configuration contains such a point. */
+int covest_reference_overflow(const covest_model *m, int64_t n, const double *params, uint8_t *flags);
+
 /* model.compute_probabilities(*params): models.py:81-98, :211-242.  out_p[n_keys]
  * in key order (host).  clamp != 0 applies fit_to_bounds first, which is how
  * compute_loglikelihood calls it (models.py:101-102); clamp == 0 is the raw
@@ -138,6 +147,13 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream);
  * < +inf. */
 int covest_grid_argmin(covest_grid *g, double *min_negll, int64_t *argmin_flat);
 
+/* Device pointer of the reduction of the last covest_grid_eval as two doubles in HBM,
+ * {min -LL, GLOBAL flat index of the arg-min as a double (-1 if none; flat indices stay
+ * below 2^53)}: what the ranks of a multi-GPU search exchange (one all-gather of these 16
+ * bytes) without a round trip through the host.  Valid until destroy;
+ * written by covest_grid_eval on its stream. */
+const double *covest_grid_argmin_pair_device(const covest_grid *g);
+
 /* Device pointer of the block's LL values (double[grid_size], valid until
  * destroy) and a copy to the host. */
 const double *covest_grid_ll_device(const covest_grid *g);
@@ -165,7 +181,10 @@ typedef struct covest_kmer covest_kmer; /* opaque */
 int covest_kmer_create(int32_t k, int32_t canonical, int64_t min_slots, int32_t device, covest_kmer **out);
 void covest_kmer_destroy(covest_kmer *c);
 /* Grow the table to at least min_slots (power of two), re-inserting what it holds.  The caller
- * keeps the table at most half full: slots >= 2 * (k-mers added so far + those about to be). */
+ * keeps the table at most half full: slots >= 2 * (DISTINCT k-mers held + those the next batch can
+ * add).  Overflow contract: a covest_kmer_add / covest_kmer_histogram that returns COVEST_E_NOMEM has
+ * counted PART of its batch; the counter is then only good for covest_kmer_clear (recount with a larger
+ * table).  covest_kmer_reserve clears the overflow state before re-inserting and reports only its own. */
 int covest_kmer_reserve(covest_kmer *c, int64_t min_slots);
 /* compute_counts(seq, prev_counts=counts, k) for n_reads preprocessed reads (bin/kmer_hist.py:44-54
  * already applied: only a/c/g/t in either case).  bases: the reads back to back; offsets[n_reads+1].

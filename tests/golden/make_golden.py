@@ -14,7 +14,8 @@ One session-local alias is needed: covest/models.py:10 does
 copied.  Interpreter-dependent semantics are recorded in every fixture's "env".
 
 Usage:  python tests/golden/make_golden.py [section ...]
-Sections: tp basic repeats threshold hists c1 c2 c3 gridtrace   (default: all)
+Sections: tp basic repeats threshold hists c1 c2 c3 c3tail c3argmin gridtrace   (default: all)
+(c3argmin reads c3_candidates_gpu.json: flat indices written on the GPU box by tools/dump_c3_candidates.py)
 """
 import itertools
 import json
@@ -299,6 +300,26 @@ def _ll_job(args):
     return v, time.time() - t0
 
 
+def _ll_sp_job(args):
+    """_ll_job that also reports sp_j = fsum(p_j) as the reference's compute_loglikelihood saw it
+    (covest/models.py:102-103), by listening in on its call of compute_probabilities."""
+    model_name, hist, tail, point = args
+    cls = BasicModel if model_name == "basic" else RepeatsModel
+    m = cls(21, 100, hist, tail, max_error=8)
+    seen = {}
+    inner = m.compute_probabilities
+
+    def listen(*a):
+        probs = inner(*a)
+        seen["sp"] = math.fsum(probs.values())
+        return probs
+
+    m.compute_probabilities = listen
+    t0 = time.time()
+    v = m.compute_loglikelihood(*point)
+    return v, time.time() - t0, seen["sp"]
+
+
 def section_c1(pool):
     hist = synth_hist("H256", pool)
     cs = [50 + i * 100 / 49 for i in range(50)]
@@ -336,30 +357,112 @@ def section_c2(pool):
                             "cpu_seconds_per_point": [t for _, t in res]})
 
 
-def section_c3(pool):
-    hist = synth_hist("H10k_rep", pool)
-    cs = linspace(15.0, 30.0, 32)
-    es = linspace(0.005, 0.08, 32)
-    q1s = linspace(0.3, 0.95, 16)
-    qs = linspace(0.05, 0.95, 16)
-    rnd = random.Random(20240522)
-    idx = sorted(rnd.sample(range(32 * 32 * 16 * 16), 64))
-    pts = []
-    for i in idx:
-        ic, ie, iq1, iq = i // (32 * 256), (i // 256) % 32, (i // 16) % 16, i % 16
-        pts.append((cs[ic], es[ie], q1s[iq1], 0.5, qs[iq]))
+def c3_axes():
+    return (linspace(15.0, 30.0, 32), linspace(0.005, 0.08, 32), linspace(0.3, 0.95, 16), linspace(0.05, 0.95, 16))
+
+
+def c3_point(i):
+    cs, es, q1s, qs = c3_axes()
+    ic, ie, iq1, iq = i // (32 * 256), (i // 256) % 32, (i // 16) % 16, i % 16
+    return (cs[ic], es[ie], q1s[iq1], 0.5, qs[iq])
+
+
+def _c3_eval(pool, hist, tail, idx, cache):
+    """Reference LL at the given flat indices of the C3 grid; `cache` maps flat index -> (ll, seconds[, sp_j]) of
+    an earlier run of this very script (the reference costs ~0.6 core-seconds per copy number and point here).
+    With a tail the third list is the reference's sp_j per point (what its tail term was computed from)."""
+    todo = [i for i in idx if i not in cache]
     # cheapest first would starve the pool at the end: longest (small q) first
-    order = sorted(range(len(pts)), key=lambda t: pts[t][4])
-    res_sorted = pool.map(_ll_job, [("repeats", hist, 0, pts[t]) for t in order], chunksize=1)
-    res = [None] * len(pts)
-    for t, r in zip(order, res_sorted):
-        res[t] = r
-    dump("c3_sample.json", {"what": "config 3: RepeatsModel on H10k_rep.hist, q2 fixed 0.5, 64 "
+    todo.sort(key=lambda i: c3_point(i)[4])
+    res = pool.map(_ll_sp_job if tail else _ll_job, [("repeats", hist, tail, c3_point(i)) for i in todo], chunksize=1)
+    got = dict(cache)
+    got.update({i: r for i, r in zip(todo, res)})
+    return [got[i][0] for i in idx], [got[i][1] for i in idx], [got[i][2] if tail else None for i in idx]
+
+
+def _cached(name, tail):
+    path = os.path.join(HERE, name)
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        old = json.load(f)
+    if old.get("tail") != tail:
+        return {}
+    out = {}
+    sps = old.get("sp") or [None] * len(old["ll"])
+    for i, p, v, t, sp in zip(old["flat_index"], old["points"], old["ll"], old["cpu_seconds_per_point"], sps):
+        if list(c3_point(i)) == list(p) and (not tail or sp is not None):
+            out[i] = (v, t, sp)
+    return out
+
+
+def section_c3(pool):
+    """>= 256 seeded points of the C3 grid: the 64 of seed 20240522 plus 192 of seed 20240523."""
+    hist = synth_hist("H10k_rep", pool)
+    n = 32 * 32 * 16 * 16
+    idx = set(random.Random(20240522).sample(range(n), 64))
+    for i in random.Random(20240523).sample(range(n), 400):
+        if len(idx) >= 256:
+            break
+        idx.add(i)
+    idx = sorted(idx)
+    ll, secs, _ = _c3_eval(pool, hist, 0, idx, _cached("c3_sample.json", 0))
+    dump("c3_sample.json", {"what": "config 3: RepeatsModel on H10k_rep.hist, q2 fixed 0.5, 256 "
                                     "seeded points of the 32x32x16x16 grid (c,e,q1,q)",
                             "hist": "H10k_rep", "k": 21, "r": 100, "max_error": 8, "tail": 0,
-                            "flat_index": idx, "points": [list(p) for p in pts],
-                            "ll": [v for v, _ in res],
-                            "cpu_seconds_per_point": [t for _, t in res]})
+                            "flat_index": idx, "points": [list(c3_point(i)) for i in idx],
+                            "ll": ll, "cpu_seconds_per_point": secs})
+
+
+def section_c3tail(pool):
+    """The same grid with a tail (tail = 1000: every one of the 10 000 keys enters sp_j, covest/models.py:103-104)."""
+    hist = synth_hist("H10k_rep", pool)
+    idx = sorted(random.Random(20240524).sample(range(32 * 32 * 16 * 16), 48))
+    ll, secs, sp = _c3_eval(pool, hist, 1000, idx, _cached("c3_tail_sample.json", 1000))
+    dump("c3_tail_sample.json", {"what": "config 3 with tail = 1000: RepeatsModel on H10k_rep.hist, 48 seeded points "
+                                         "of the 32x32x16x16 grid (c,e,q1,q), q2 fixed 0.5",
+                                 "hist": "H10k_rep", "k": 21, "r": 100, "max_error": 8, "tail": 1000,
+                                 "flat_index": idx, "points": [list(c3_point(i)) for i in idx],
+                                 "ll": ll, "sp": sp, "cpu_seconds_per_point": secs})
+
+
+def section_c3argmin(pool):
+    """SURVEY.md 8(d) parity procedure for the headline grid: the REFERENCE evaluated at the GPU's top-64
+    candidates and at the 2 P axis neighbours of the GPU's arg-min (flat indices written on the GPU box by
+    tools/dump_c3_candidates.py; only indices are taken from that file), and the reference's own winner among
+    them under the scan of covest/grid.py:65-70 (strict <, first index wins)."""
+    hist = synth_hist("H10k_rep", pool)
+    src = os.environ.get("COVEST_C3_CANDIDATES", os.path.join(HERE, "c3_candidates_gpu.json"))
+    with open(src) as f:
+        cand_all = json.load(f)
+    out = {}
+    for tail in (0, 1000):
+        key = "tail%d" % tail
+        if key not in cand_all:
+            continue
+        cand = sorted(int(i) for i in cand_all[key]["candidates"])
+        cache = {}
+        old_path = os.path.join(HERE, "c3_argmin.json")
+        if os.path.exists(old_path):
+            with open(old_path) as f:
+                old = json.load(f).get(key, {})
+            cache = {i: (v, t, sp) for i, v, t, sp in zip(old.get("flat_index", []), old.get("ll", []),
+                                                          old.get("cpu_seconds_per_point", []),
+                                                          old.get("sp") or [None] * len(old.get("ll", [])))
+                     if not tail or sp is not None}
+        cache.update(_cached("c3_sample.json" if tail == 0 else "c3_tail_sample.json", tail))
+        ll, secs, sp = _c3_eval(pool, hist, tail, cand, cache)
+        best, arg = None, -1
+        for i, v in zip(cand, ll):
+            if v == v and (best is None or -v < best):
+                best, arg = -v, i
+        out[key] = {"flat_index": cand, "points": [list(c3_point(i)) for i in cand], "ll": ll, "sp": sp,
+                    "cpu_seconds_per_point": secs, "reference_argmin_flat": arg, "reference_min_negll": best,
+                    "gpu_argmin_flat": int(cand_all[key]["argmin_flat"])}
+        print("c3argmin", key, "reference winner", arg, best, "GPU said", cand_all[key]["argmin_flat"], flush=True)
+    dump("c3_argmin.json", dict(out, what="config 3 arg-min candidates (GPU top-64 + axis neighbours of its "
+                                          "arg-min) evaluated by the reference; RepeatsModel on H10k_rep.hist",
+                                hist="H10k_rep", k=21, r=100, max_error=8))
 
 
 # ----------------------------------------------------------------------------- (7) grid traces
@@ -396,13 +499,13 @@ def section_gridtrace():
 
 
 def main():
-    wanted = sys.argv[1:] or ["tp", "basic", "repeats", "threshold", "hists", "c1", "c2", "c3",
-                              "gridtrace"]
-    pool = multiprocessing.Pool(8)
+    wanted = sys.argv[1:] or ["tp", "basic", "repeats", "threshold", "hists", "c1", "c2", "c3", "c3tail",
+                              "c3argmin", "gridtrace"]
+    pool = multiprocessing.Pool(int(os.environ.get("COVEST_GOLDEN_PROCS", "8")))
     for name in wanted:
         t0 = time.time()
         fn = globals()["section_" + name]
-        if name in ("hists", "c1", "c2", "c3"):
+        if name in ("hists", "c1", "c2", "c3", "c3tail", "c3argmin"):
             fn(pool)
         else:
             fn()

@@ -4,8 +4,8 @@ from the reference and against the oracle.  Needs a real MI355X: `-m gpu`.
 Tolerance: log-likelihood values <= 1e-9 relative (BASELINE.json north_star),
 IEEE specials (-inf / NaN) identical, arg-min index identical.
 """
+import json
 import math
-
 import os
 
 import numpy as np
@@ -58,40 +58,45 @@ def _tail_noise(om, points, lls, tail):
     absolute error of ~eps and the term an error of tail*eps/(1 - sp_j); when
     sp_j rounds to 1 the term flips between 0 and tail*log(2^-53).  Returns per
     point the absolute slack (0 = well conditioned, compare at 1e-9)."""
-    eps = 2.0 ** -52
     out = []
     for p, ll in zip(points, lls):
         if not tail or not math.isfinite(ll):
             out.append(0.0)
             continue
-        sp = min(1.0, math.fsum(om.compute_probabilities(*p).values()))
-        gap = 1.0 - sp
-        noise = abs(tail) * 4 * eps / gap if gap > 0 else math.inf
-        out.append(abs(tail) * 40.0 if noise > 1e-10 * abs(ll) else 0.0)
+        out.append(_tail_slack(tail, ll, math.fsum(om.compute_probabilities(*p).values())))
     return out
 
 
-def _subnormal_noise(om, hist, points, lls):
-    """Where the reference's own p_j is a SUBNORMAL double (< 2.2e-308) at a key with h_j != 0.  Its value there
-    is whatever the order of the reference's roundings leaves: every a_s * tp_s is rounded twice onto the
-    4.9e-324 grid (c_src/covest_poissonmodule.c:32 casts the long double to double, covest/models.py:93
-    multiplies by a_s) before the sum.  K-direct evaluates term by term and lands on the same grid points; the
-    recurrence kernels round the finished sum once and may differ by one grid step per term: an absolute
-    16 * h_j * 4.9e-324 / p_j in the log-likelihood (1.26 for h_j = 6316 at p_j = 2.5e-320, found by the
-    fuzz test's seed 42).  Returns that bound per point (0 = no subnormal p_j with weight)."""
-    tiny, grid = 2.2250738585072014e-308, 4.9406564584124654e-324
-    out = []
-    for p, ll in zip(points, lls):
-        if not math.isfinite(ll):
-            out.append(0.0)
-            continue
-        probs = om.compute_probabilities(*p)
-        out.append(sum(16.0 * hist[j] * grid / pj for j, pj in probs.items() if 0.0 < pj < tiny and hist[j]))
-    return out
+def _tail_slack(tail, ll, sp):
+    """The criterion of _tail_noise for one point whose sp_j = fsum(p_j) is known."""
+    eps = 2.0 ** -52
+    gap = 1.0 - min(1.0, sp)
+    noise = abs(tail) * 4 * eps / gap if gap > 0 else math.inf
+    return abs(tail) * 40.0 if noise > 1e-10 * abs(ll) else 0.0
 
 
-def _wider(a, b):
-    return [max(x, y) for x, y in zip(a, b)]
+_BOUNDS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tail_noise_bounds.json")
+_RECORD = os.environ.get("COVEST_RECORD_TAIL_BOUNDS")  # a path: write the counts there instead of checking them
+_recorded = {}
+
+
+def _slack_budget(name, slack):
+    """The tail-noise slack must stay the exception: the number of points of case `name` that `_tail_noise`
+    marks (a property of the oracle's numbers alone, so it is the same on every box) may not exceed the count
+    committed in tests/golden/tail_noise_bounds.json.  A change that widened the criterion until every tail
+    point fell under it would fail here.  COVEST_RECORD_TAIL_BOUNDS=<path> records instead (new cases)."""
+    n = sum(1 for v in slack if v > 0)
+    if _RECORD:
+        _recorded[name] = {"marked": n, "points": len(slack)}
+        with open(_RECORD, "w") as f:
+            json.dump(_recorded, f, indent=0, sort_keys=True)
+        return n
+    with open(_BOUNDS_PATH) as f:
+        bounds = json.load(f)
+    assert name in bounds, "no committed tail-noise bound for case %r" % name
+    assert n <= bounds[name]["marked"], "case %r: %d points under the tail-noise slack, committed bound %d of %d" % (
+        name, n, bounds[name]["marked"], bounds[name]["points"])
+    return n
 
 
 def test_device_present(hip_lib):
@@ -107,7 +112,7 @@ def test_golden_loglikelihood(hip_lib, oracle, kind, fname):
         m = _gpu_model(kind, case)
         got = m.loglikelihood_points(np.array(case["points"]), kernel="direct")
         slack = _tail_noise(_oracle_model(oracle, kind, case), case["points"], case["ll"], case["tail"])
-        n_slack += sum(1 for v in slack if v > 0)
+        n_slack += _slack_budget("golden %s #%d" % (kind, g["cases"].index(case)), slack)
         worst = max(worst, _check(got, case["ll"], "%s %s tail=%s S=%s" % (
             kind, case["hist"], case["tail"], case["max_error"]), slack=slack))
         if kind == "basic" and case["max_error"] == 8:  # the recurrence kernel (K-basic) on the same points
@@ -190,17 +195,57 @@ def _verify_argmin_with_oracle(oracle, om, grid, ll, arg, top):
     assert cand[k] == arg
 
 
+def _c3_axes():
+    return [np.linspace(15.0, 30.0, 32), np.linspace(0.005, 0.08, 32), np.linspace(0.3, 0.95, 16),
+            [0.5], np.linspace(0.05, 0.95, 16)]
+
+
+def _argmin_candidates(grid, ll, arg, top=64):
+    """the GPU's `top` best points and the 2 P axis neighbours of its arg-min (flat indices)."""
+    negll = np.where(np.isnan(ll), np.inf, -ll)
+    cand = set(np.argsort(negll, kind="stable")[:top].tolist())
+    idx = np.unravel_index(arg, grid.shape)
+    for d in range(len(grid.shape)):
+        for step in (-1, 1):
+            j = list(idx)
+            j[d] += step
+            if 0 <= j[d] < grid.shape[d]:
+                cand.add(int(np.ravel_multi_index(j, grid.shape)))
+    return sorted(cand)
+
+
+def _verify_argmin_with_reference(fix, grid, ll, arg, slack=None):
+    """The same procedure with the REFERENCE as the judge: tests/golden/c3_argmin.json holds the reference's own
+    log-likelihoods at the candidates (make_golden.py section c3argmin, run in the build container on the
+    indices tools/dump_c3_candidates.py wrote on a GPU box).  The candidate set of THIS run must be the
+    fixture's, every value must agree to 1e-9, and the reference's winner under the scan of
+    covest/grid.py:65-70 (strict <, first index) must be the GPU's arg-min."""
+    cand = _argmin_candidates(grid, ll, arg)
+    assert cand == fix["flat_index"], "arg-min candidates changed: regenerate tests/golden/c3_argmin.json"
+    for i, p in zip(cand, fix["points"]):
+        assert np.allclose(grid.point(i), p, rtol=1e-15, atol=0)
+    worst = _check(ll[cand], fix["ll"], "arg-min candidates vs reference", slack=slack)
+    best, winner = math.inf, -1
+    for i, v in zip(cand, fix["ll"]):
+        if -v < best:  # NaN never wins
+            best, winner = -v, i
+    assert winner == fix["reference_argmin_flat"] == arg
+    assert rel_err(-float(ll[arg]), best) <= TOL
+    return worst
+
+
 @pytest.mark.parametrize("kernel", ["direct", "factored"])
 def test_config3_sample_and_argmin(hip_lib, oracle, kernel):
+    """Config 3 (the headline grid): >= 256 seeded points against the reference's values, and the arg-min
+    confirmed by the reference itself."""
     from covest_amd import DenseGrid
     g = load_golden("c3_sample.json")
+    assert len(g["points"]) >= 256  # SURVEY 8(c)(6)
     m = _gpu_model("repeats", g)
     got = m.loglikelihood_points(np.array(g["points"]), kernel="direct")
     worst = _check(got, g["ll"], "C3 sample")
-    print("C3 sample worst rel err", worst)
-    axes = [np.linspace(15.0, 30.0, 32), np.linspace(0.005, 0.08, 32), np.linspace(0.3, 0.95, 16),
-            [0.5], np.linspace(0.05, 0.95, 16)]
-    grid = DenseGrid(m, axes)
+    print("C3 sample worst rel err", worst, "finite values", sum(1 for v in g["ll"] if math.isfinite(v)))
+    grid = DenseGrid(m, _c3_axes())
     grid.evaluate(kernel=kernel)
     assert grid.work()[2] == "ll_" + kernel
     ll = grid.loglikelihoods()
@@ -210,12 +255,73 @@ def test_config3_sample_and_argmin(hip_lib, oracle, kernel):
         assert rel_err(float(ll[i]), want) <= TOL
     val, arg = grid.argmin()
     assert val == -ll[arg] and arg == int(np.argmin(np.where(np.isnan(ll), np.inf, -ll)))
+    worst = _verify_argmin_with_reference(load_golden("c3_argmin.json")["tail0"], grid, ll, arg)
+    print("C3", kernel, "arg-min", arg, val, "confirmed by the reference; candidates' worst rel err", worst)
     if kernel == "factored":  # whole grid against the direct kernel (itself pinned to the fixture above)
-        ref = DenseGrid(m, axes)
+        ref = DenseGrid(m, _c3_axes())
         ref.evaluate(kernel="direct")
         worst = _check(ll, ref.loglikelihoods(), "C3 factored vs direct", tol=1e-11)
         assert ref.argmin() == (val, arg) or ref.argmin()[1] == arg
         print("C3 factored vs direct worst rel err", worst)
+
+
+def test_config3_with_tail(hip_lib, oracle):
+    """Config 3 with tail = 1000 -- what a trimmed real histogram has (covest/histogram.py:125-134): all 10 000
+    keys enter sp_j (covest/models.py:103-104).  48 seeded points and the arg-min candidates against the
+    reference's values, K-direct on the points and K-factored on the whole grid."""
+    from covest_amd import DenseGrid
+    g = load_golden("c3_tail_sample.json")
+    assert g["tail"] == 1000
+    m = _gpu_model("repeats", g)
+    assert m.bins_evaluated == 10000
+    # where the reference's own tail term is rounding noise (1 - sp_j of a few ulp) the comparison carries the
+    # explicit slack, decided from the sp_j the REFERENCE saw (recorded in the fixture)
+    slack = [_tail_slack(1000, v, sp) if math.isfinite(v) else 0.0 for v, sp in zip(g["ll"], g["sp"])]
+    _slack_budget("C3 tail sample", slack)
+    got = m.loglikelihood_points(np.array(g["points"]), kernel="direct")
+    worst = _check(got, g["ll"], "C3 tail sample (direct)", slack=slack)
+    grid = DenseGrid(m, _c3_axes())
+    grid.evaluate(kernel="factored")
+    assert grid.work()[2] == "ll_factored"
+    ll = grid.loglikelihoods()
+    worst = max(worst, _check(ll[g["flat_index"]], g["ll"], "C3 tail sample (factored)", slack=slack))
+    val, arg = grid.argmin()
+    assert val == -ll[arg] and arg == int(np.argmin(np.where(np.isnan(ll), np.inf, -ll)))
+    fix = load_golden("c3_argmin.json")["tail1000"]
+    aslack = [_tail_slack(1000, v, sp) if math.isfinite(v) else 0.0 for v, sp in zip(fix["ll"], fix["sp"])]
+    _slack_budget("C3 tail arg-min candidates", aslack)
+    _verify_argmin_with_reference(fix, grid, ll, arg, slack=aslack)
+    print("C3 tail=1000 worst rel err", worst, "arg-min", arg, val)
+
+
+def test_config4_c3_in_eight_blocks(hip_lib):
+    """Config 4's workload on one device: the C3 grid cut into 8 contiguous flat-index blocks balanced by
+    sum(T - 1), each evaluated on its own; the values are those of the whole grid bit for bit and
+    the winner of the ranks' (min, index) pairs under distributed_argmin's scan is the whole grid's."""
+    from covest_amd import DenseGrid, RepeatsModel
+    from covest_amd.grid import partition_flat_range, repeats_cost_weights, scan_min_pairs
+    m = RepeatsModel(21, 100, load_hist("H10k_rep"), 0, max_error=8)
+    axes = _c3_axes()
+    whole = DenseGrid(m, axes)
+    whole.evaluate()
+    assert whole.work()[2] == "ll_factored"
+    ll = whole.loglikelihoods()
+    best = whole.argmin()
+    w = repeats_cost_weights(m, axes)
+    bounds = partition_flat_range(whole.total, 8, w)
+    cost = [float(np.sum(np.tile(w, whole.total // len(w))[a:b])) for a, b in zip(bounds[:-1], bounds[1:])]
+    assert max(cost) <= 1.02 * (sum(cost) / 8)  # balanced by work, not by point count
+    parts, pairs = [], []
+    for r in range(8):
+        g = DenseGrid(m, axes, (bounds[r], bounds[r + 1]))
+        g.evaluate()
+        assert g.work()[2] == "ll_factored"
+        parts.append(g.loglikelihoods())
+        pairs.append(g.argmin())
+        g.close()
+    assert np.array_equal(np.concatenate(parts), ll, equal_nan=True)
+    assert scan_min_pairs(pairs) == best
+    assert best[1] == 165489
 
 
 @pytest.mark.parametrize("tail", [0, 1000])
@@ -234,7 +340,9 @@ def test_factored_small_histograms(hip_lib, oracle, hname, tail):
     ll = grid.loglikelihoods()
     pts = np.array([grid.point(i) for i in range(grid.total)])
     ref = om.compute_loglikelihood_many(pts, n_threads=16)
-    worst = _check(ll, ref, "factored %s tail=%d" % (hname, tail), slack=_tail_noise(om, pts, ref, tail))
+    slack = _tail_noise(om, pts, ref, tail)
+    _slack_budget("factored small %s tail=%d" % (hname, tail), slack)
+    worst = _check(ll, ref, "factored %s tail=%d" % (hname, tail), slack=slack)
     k, best = oracle.first_min(-ref)
     val, arg = grid.argmin()
     assert arg == k or ll[arg] == ll[k]
@@ -282,7 +390,9 @@ def test_factored_plan_shapes(hip_lib, oracle):
         sel = rng.choice(fac.total, size=min(24, fac.total), replace=False)
         pts = np.array([fac.point(i) for i in sel])
         want = om.compute_loglikelihood_many(pts, n_threads=16)
-        _check(ll[sel], want, name + " vs oracle", slack=_tail_noise(om, pts, want, tail))
+        slack = _tail_noise(om, pts, want, tail)
+        _slack_budget("plan shape " + name, slack)
+        _check(ll[sel], want, name + " vs oracle", slack=slack)
         print("factored plan shape:", name, "points", fac.total, "worst rel err vs direct", worst)
 
 
@@ -326,8 +436,9 @@ def test_edge_cases(hip_lib, oracle):
         om = oracle.OracleModel("basic", 21, 100, hist, tail, max_error=8)
         pts = np.array([(10.0, 0.05), (300.0, 0.2), (0.01, 0.5), (40.0, 0.0), (1200.0, 0.01), (900.0, 0.3)])
         ref = om.compute_loglikelihood_many(pts)
-        _check(m.loglikelihood_points(pts, kernel="recur"), ref, "ragged recur tail=%d" % tail,
-               slack=_tail_noise(om, pts, ref, tail))
+        slack = _tail_noise(om, pts, ref, tail)
+        _slack_budget("ragged recur tail=%d" % tail, slack)
+        _check(m.loglikelihood_points(pts, kernel="recur"), ref, "ragged recur tail=%d" % tail, slack=slack)
     # NaN parameters poison the result, as in the reference
     m = BasicModel(21, 100, {1: 5, 2: 3}, 0, max_error=8)
     assert math.isnan(m.compute_loglikelihood(float("nan"), 0.05))
@@ -335,6 +446,81 @@ def test_edge_cases(hip_lib, oracle):
     # a non-zero bin with p_j == 0 -> -inf
     m = BasicModel(21, 100, {5000: 1, 1: 10}, 0, max_error=8)
     assert m.compute_loglikelihood(1.0, 0.01) == -math.inf
+
+
+def test_subnormal_pj_goes_to_the_strict_kernel(hip_lib, oracle):
+    """A key that was observed 6000 times and to which the model gives a SUBNORMAL probability (1e-323 ... 1e-309:
+    one or a few steps of the 4.9e-324 grid): the reference's value there hangs on the rounding of every single
+    term (c_src/covest_poissonmodule.c:32, covest/models.py:93).  The recurrence kernels detect it and hand the
+    point to the term-by-term kernel -- in the arg-min pass for grids, in covest_eval_points for lists -- so
+    every kernel name must deliver the plain 1e-9 (round 1 excused this case with a slack)."""
+    from covest_amd import BasicModel, DenseGrid, RepeatsModel
+    hist = {1: 1000, 2: 500, 150: 6000}
+    cs = np.linspace(0.55, 0.80, 51)
+    om = oracle.OracleModel("basic", 21, 100, hist, 0, max_error=8)
+    pts = np.array([(c, 0.01) for c in cs])
+    ref = om.compute_loglikelihood_many(pts, n_threads=16)
+    sub = [0.0 < om.compute_probabilities(*p)[150] < 2.2250738585072014e-308 for p in pts]
+    assert sum(sub) >= 20 and sum(1 for v in ref if v == -math.inf) >= 5 and not all(sub)
+    m = BasicModel(21, 100, hist, 0, max_error=8)
+    for kernel in ("direct", "recur"):
+        _check(m.loglikelihood_points(pts, kernel=kernel), ref, "subnormal basic list " + kernel)
+        grid = DenseGrid(m, [cs, [0.01]])
+        grid.evaluate(kernel=kernel)
+        ll = grid.loglikelihoods()
+        _check(ll, ref, "subnormal basic grid " + kernel)
+        assert grid.argmin()[1] == oracle.first_min(-ref)[0]
+        grid.close()
+    # repeats model: the same key through K-factored (dense grid, point list) and K-direct
+    rm = RepeatsModel(21, 100, hist, 0, max_error=8)
+    orm = oracle.OracleModel("repeats", 21, 100, hist, 0, max_error=8)
+    axes = [np.exp(np.linspace(np.log(0.03), np.log(0.8), 60)), [0.01], [0.7, 0.9], [0.5], [0.6, 0.95, 1.0]]
+    grid = DenseGrid(rm, axes)
+    gp = np.array([grid.point(i) for i in range(grid.total)])
+    gref = orm.compute_loglikelihood_many(gp, n_threads=16)
+    n_sub = sum(0.0 < orm.compute_probabilities(*p)[150] < 2.2250738585072014e-308 for p in gp)
+    assert n_sub >= 20  # (27 of the 360 points when this was written)
+    for kernel in ("direct", "factored"):
+        grid.evaluate(kernel=kernel)
+        _check(grid.loglikelihoods(), gref, "subnormal repeats grid " + kernel)
+        assert grid.argmin()[1] == oracle.first_min(-gref)[0]
+        _check(rm.loglikelihood_points(gp, kernel=kernel), gref, "subnormal repeats list " + kernel)
+    print("subnormal p_j: %d basic points, >= %d repeats points re-evaluated by the strict kernel" % (sum(sub), n_sub))
+
+
+def test_estimator_fix_and_err_scale_on_gpu(hip_lib, oracle):
+    """CoverageEstimator.likelihood_f (covest/covest.py:26-31) with `fix` and `err_scale != 1` -- the "4-D grid =
+    q2 fixed" case of SURVEY discrepancy 1 -- on the GPU: the scalar objective, its batched form negll_grid, and
+    optimize_grid over it, against the oracle evaluated at the model-space points the adapter must produce."""
+    from covest_amd import CoverageEstimator, RepeatsModel, optimize_grid
+    hist = load_hist("sim_c10_e0.05")
+    m = RepeatsModel(21, 100, hist, 0, max_error=8)
+    om = oracle.OracleModel("repeats", 21, 100, hist, 0, max_error=8)
+    fix = [None, None, None, 0.5, None]
+    est = CoverageEstimator(m, err_scale=10, fix=fix)
+    assert est.bounds[1] == (0, 5.0)  # the error-rate bound lives in scaled space (covest/covest.py:22-24)
+    x = [10.0, 0.5, 0.7, 0.123, 0.4]  # optimiser space: error rate x 10, q2 ignored (fixed)
+    want = -om.compute_loglikelihood(10.0, 0.05, 0.7, 0.5, 0.4)
+    assert rel_err(est.likelihood_f(x), want) <= TOL
+    axes = [[9.0, 10.0, 11.0], [0.3, 0.5, 0.8], [0.6, 0.8], [0.123], [0.2, 0.5, 0.7]]
+    got = est.negll_grid(axes)
+    pts = np.array([(c, e / 10, q1, 0.5, q) for c in axes[0] for e in axes[1] for q1 in axes[2] for q in axes[4]])
+    ref = -om.compute_loglikelihood_many(pts, n_threads=16)
+    _check(got, ref, "negll_grid fix + err_scale")
+    # the search itself: every iterate is a grid point, so the end point must reproduce under the oracle, q2 must
+    # still be the fixed value, and no grid point the search saw may beat it
+    guess = [10.0, 0.5, 0.65, 0.5, 0.5]
+    res = optimize_grid(est.likelihood_f, guess, bounds=est.bounds, fix=fix)
+    assert res[3] == 0.5
+    final = optimize_grid.trace[-1]
+    model_pt = (res[0], res[1] / 10, res[2], 0.5, res[4])
+    assert rel_err(final["value"], -om.compute_loglikelihood(*model_pt)) <= TOL
+    assert all(t["grid_size"] <= 6 ** 4 for t in optimize_grid.trace)  # a fixed dimension contributes one value
+    assert final["value"] <= est.likelihood_f(guess)
+    # the same search without err_scale ends at the same model-space point: the scaling is only a reparametrisation
+    plain = CoverageEstimator(m, fix=fix)
+    res1 = optimize_grid(plain.likelihood_f, [10.0, 0.05, 0.65, 0.5, 0.5], bounds=plain.bounds, fix=fix)
+    assert rel_err(plain.likelihood_f(res1), final["value"]) <= 1e-6
 
 
 def test_block_partition_equals_whole_grid(hip_lib):
@@ -412,10 +598,9 @@ def test_fuzz_random_histograms(hip_lib, oracle, seed):
     pts[:4] = [(0.01, 0.0), (0.01, 0.5), (400.0, 0.0), (400.0, 0.5)]
     ref = om.compute_loglikelihood_many(pts, n_threads=16)
     slack = _tail_noise(om, pts, ref, tail)
-    fast_slack = _wider(slack, _subnormal_noise(om, hist, pts, ref))  # the recurrence kernels only
+    _slack_budget("fuzz basic seed %d" % seed, slack)
     for kernel in ("direct", "recur"):
-        _check(m.loglikelihood_points(pts, kernel=kernel), ref, "fuzz basic %s seed %d" % (kernel, seed),
-               slack=slack if kernel == "direct" else fast_slack)
+        _check(m.loglikelihood_points(pts, kernel=kernel), ref, "fuzz basic %s seed %d" % (kernel, seed), slack=slack)
     # --- repeats model: dense grid through direct and factored, point list through direct ---
     rm = RepeatsModel(k, r, hist, tail, max_error=8)
     orm = oracle.OracleModel("repeats", k, r, hist, tail, max_error=8)
@@ -425,12 +610,12 @@ def test_fuzz_random_histograms(hip_lib, oracle, seed):
     gp = np.array([grid.point(i) for i in range(grid.total)])
     gref = orm.compute_loglikelihood_many(gp, n_threads=16)
     gslack = _tail_noise(orm, gp, gref, tail)
-    gfast = _wider(gslack, _subnormal_noise(orm, hist, gp, gref))
+    _slack_budget("fuzz repeats seed %d" % seed, gslack)
     for kernel in ("direct", "factored"):
         grid.evaluate(kernel=kernel)
         ll = grid.loglikelihoods()
-        _check(ll, gref, "fuzz repeats %s seed %d" % (kernel, seed), slack=gslack if kernel == "direct" else gfast)
+        _check(ll, gref, "fuzz repeats %s seed %d" % (kernel, seed), slack=gslack)
         k_ref, _ = oracle.first_min(-gref)
         val, arg = grid.argmin()
         assert arg == k_ref or rel_err(float(ll[arg]), float(gref[k_ref])) <= TOL
-    _check(rm.loglikelihood_points(gp[::7]), gref[::7], "fuzz repeats list seed %d" % seed, slack=gfast[::7])
+    _check(rm.loglikelihood_points(gp[::7]), gref[::7], "fuzz repeats list seed %d" % seed, slack=gslack[::7])
