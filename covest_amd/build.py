@@ -35,16 +35,17 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link the shared library."""
-    if not force and not _stale():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile every HIP source for gfx950 and link the shared library.  `extra_flags` / `out`: an
+    experimental variant (e.g. -DCOVEST_EXP_...) linked somewhere else, for A/B runs via COVEST_AMD_LIB."""
+    if out is None and not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    obj_dir = os.path.join(LIB_DIR, "obj" if out is None else "obj_" + os.path.basename(out))
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     common = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-              "-x", "hip"]
+              "-x", "hip"] + list(extra_flags)
     objs = []
     procs = []
     for src in SOURCES:
@@ -55,15 +56,20 @@ def build(force=False, verbose=False):
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:
-        out, _ = p.communicate()
+        log, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
-        if verbose and out:
-            print(out.decode(errors="replace"))
-    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, log.decode(errors="replace")))
+        if verbose and log:
+            print(log.decode(errors="replace"))
+    target = LIB_PATH if out is None else out
+    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", target] + objs
     subprocess.check_call(link)
-    return LIB_PATH
+    return target
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m covest_amd.build [--force] [--out path.so -DFLAG ...]
+    args = sys.argv[1:]
+    out = args[args.index("--out") + 1] if "--out" in args else None
+    flags = [a for a in args if a.startswith("-D") or a.startswith("-m")]
+    print(build(force="--force" in args, verbose=out is None, extra_flags=flags, out=out))

@@ -8,8 +8,8 @@
 // HBM-bound streaming read of 8 bytes per grid point, two launches: a
 // grid-stride pass of at most 256 workgroups (one per CU) that leaves one
 // candidate per workgroup, then one workgroup over the candidates.  No
-// atomics, so the result is deterministic.  The first pass also re-evaluates
-// the points a recurrence kernel handed back (redo marker, direct_point.h).
+// atomics, so the result is deterministic.  (Also here: ll_fix_list_kernel, the
+// pass that patches the points a recurrence kernel handed back, direct_point.h.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -64,35 +64,15 @@ __device__ __forceinline__ Cand block_best(Cand c)
     return wave_best(r); // valid in wave 0
 }
 
-// First stage, fused with the hand-back of the recurrence kernels: a point whose value is the
-// redo marker (direct_point.h: a key with h_j != 0 has a subnormal p_j there) is evaluated again,
-// term by term, by the whole wave that meets it, and the LL buffer is patched in place.  Such points
-// are rare (a model that gives probability 1e-310 to a key that was observed); without any, the
-// pass costs one compare per point on top of the 8-byte read.
-template <int P>
-__global__ __launch_bounds__(256) void argmin_stage1(const DevModel m, const PointSource src, double *__restrict__ ll,
-                                                     int64_t n, double *__restrict__ pv, int64_t *__restrict__ pi)
+__global__ __launch_bounds__(256) void argmin_stage1(const double *__restrict__ ll, int64_t n,
+                                                     double *__restrict__ pv, int64_t *__restrict__ pi)
 {
     Cand c;
     c.v = INFINITY;
     c.i = INT64_MAX;
-    const int lane = threadIdx.x & (kWave - 1);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // wave-uniform trip count: lanes past the end hold +inf
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane); base < n; base += stride) {
-        const int64_t i = base + lane;
-        double val = i < n ? ll[i] : -INFINITY;
-        uint64_t redo = __ballot(i < n && is_redo_marker(val));
-        while (redo) { // wave-uniform
-            const int who = __builtin_ctzll(redo);
-            redo &= redo - 1;
-            const double again = direct_point_ll<P, false>(m, src, base + who, nullptr);
-            if (lane == who) {
-                val = again;
-                ll[i] = again;
-            }
-        }
-        const double v = -val;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = -ll[i];
         // ascending i within a thread: strict < keeps the first occurrence
         if (v < c.v) {
             c.v = v;
@@ -106,10 +86,142 @@ __global__ __launch_bounds__(256) void argmin_stage1(const DevModel m, const Poi
     }
 }
 
+// The hand-back of the recurrence kernels (direct_point.h): ONE WORKGROUP PER QUEUED POINT corrects the point's value
+// in place.  `fast` (the recurrence kernel's value, in which every p_j below p_clamp counted as p_clamp) gets, for
+// every counted row of the range named in the side word whose STRICT p_j is below p_clamp, h_j (safe_log(p_j) -
+// log(p_clamp)) added, in ascending row order.  The strict p_j: K-direct's expressions, every term rounded to a
+// double on its own (direct_point.h).  Lane r keeps the p_j of row r of a 64-row chunk; the mixture components are
+// prepared 64 at a time (one per lane) and dealt to the workgroup's 4 waves, whose partial p_j are added through
+// LDS -- where it matters (p_j subnormal) every one of these sums is exact, whatever its order.
+// Launched after every K-basic / K-factored launch, before anything reads the values; with an empty queue it costs
+// a launch and one load.  The queued points of a wide grid come in clusters (whole (c, e) rows of it) and the work
+// of one grows with its threshold_o, which is why they are compacted into a queue and spread over the chip instead
+// of being patched by whichever thread meets them.  The queue's counter is reset by whoever runs next on the
+// stream: the arg-min pass (grids) or the host (point lists).
+// NW: waves that share a point (basic model, a single copy number: 1 -- four points per workgroup; repeats model: 4).
+template <int P, int NW>
+__global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
+                                                          const double *__restrict__ tile_dbl,
+                                                          const int32_t *__restrict__ tile_int, const PointSource src,
+                                                          double *__restrict__ ll, const SubList list)
+{
+    constexpr int PPB = 4 / NW; // points per workgroup
+    __shared__ double pj_part[4][kWave];
+    const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int wave = wave_in_block % NW; // among the waves of its point
+    const unsigned count = __builtin_amdgcn_readfirstlane(*list.count);
+    const int S = m.n_err;
+    const int OT = kWave / S;
+    const int s = lane % S;
+    const int og = lane / S;
+    const bool lane_in_tile = og < OT;
+    const bool pow2 = (S & (S - 1)) == 0; // then the groups of S lanes are aligned and reduce by butterflies
+    const double comb_s = m.comb[s];
+    for (unsigned at0 = blockIdx.x * PPB; at0 < count; at0 += gridDim.x * PPB) { // workgroup-uniform
+        const unsigned at = at0 + wave_in_block / NW;
+        if (NW == 1 && at >= count)
+            continue; // (wave-uniform; with NW == 1 nothing below synchronises the workgroup)
+        const int64_t pt = list.index[at];
+        const unsigned long long word = list.word[at];
+        double par[kMaxParams];
+        int T;
+        fetch_point<P>(src, pt, par, T);
+        clamp_point<P>(m, par);
+        const bool units16 = sub_units16(word);
+        const int64_t row_first = units16 ? (int64_t)sub_first(word) * 16 : (int64_t)sub_first(word);
+        const int64_t row_last = units16 ? (int64_t)sub_last(word) * 16 + 15 : (int64_t)sub_last(word);
+        const double lam = error_class_rate(m, par[0], par[1], s);
+        double value = ll[pt];
+        for (int64_t chunk = row_first; chunk <= row_last; chunk += kWave) { // workgroup-uniform
+            const int64_t row = chunk + lane;
+            const int bin = (row <= row_last && row < (int64_t)tv.n_tiles * kTileBins) ? tv.row_bin[row] : -1;
+            const double h = bin >= 0 ? m.bins.cnt[bin] : 0.0;
+            const bool counted = bin >= 0 && h != 0.0;
+            const double key = counted ? m.bins.key[bin] : 0.0;
+            const double nlg = counted ? -m.bins.lgam[bin] : 0.0;
+            const uint64_t rows = __ballot(counted);
+            double pj = 0.0; // of this lane's row: this wave's share of the copy numbers
+            for (int o0 = 1 + OT * wave; o0 < T; o0 += OT * NW) {
+                const int o = o0 + og;
+                const bool live = lane_in_tile && o < T;
+                const double x = (double)o * lam;
+                const double n_os = comb_s * (1.0 - exp_neg_rn(x));
+                double tot = 0.0;
+                for (int t = 0; t < S; ++t)
+                    tot += __shfl(n_os, og * S + t, kWave);
+                if (tot == 0.0)
+                    tot = 1.0;
+                double a_os = n_os / tot;
+                const double b_o = (P == 5) ? copy_number_weight(par[2], par[3], par[4], o) : 1.0;
+                double lx = 0.0, nd = -INFINITY;
+                if (live && x > 0.0) {
+                    lx = log(x);
+                    nd = -log_trunc_norm(x, lx);
+                }
+                if (!live)
+                    a_os = 0.0;
+                const int n_o = min(OT, T - o0);
+                uint64_t todo = rows;
+                while (todo) { // wave-uniform: one counted row of the chunk after the other
+                    const int kk = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const double key_k = wave_bcast(key, kk), nlg_k = wave_bcast(nlg, kk);
+                    const double arg = fma(key_k, lx, nd + nlg_k);
+                    // exp(arg) rounds to 0 below ln(2^-1075) = -745.13: where all 64 components of this lot are
+                    // there (the copy numbers far from a deep-tail key: most of them), the row gains nothing
+                    if (!__any(a_os != 0.0 && !(arg < -745.2)))
+                        continue;
+                    const double term = a_os != 0.0 ? a_os * exp(arg) : 0.0;
+                    double add = 0.0;
+                    if (pow2) {
+                        double inner = term; // sum over the S error classes of a copy number (every lane of the group) ...
+                        for (int off = 1; off < S; off <<= 1)
+                            inner += __shfl_xor(inner, off, kWave);
+                        double u = og < n_o ? b_o * inner : 0.0; // ... times its weight, rounded ...
+                        for (int off = S; off < kWave; off <<= 1) // ... summed over the copy numbers: every lane (g, s)
+                            u += __shfl_xor(u, off, kWave);       //     adds the groups' values at its own s
+                        add = u;
+                    } else {
+                        for (int g = 0; g < n_o; ++g) {
+                            double inner = 0.0;
+                            for (int t = 0; t < S; ++t)
+                                inner += __shfl(term, g * S + t, kWave);
+                            add += __shfl(b_o, g * S, kWave) * inner;
+                        }
+                    }
+                    if (lane == kk)
+                        pj += add;
+                }
+            }
+            if (NW > 1) {
+                pj_part[wave][lane] = pj;
+                __syncthreads();
+                pj = ((pj_part[0][lane] + pj_part[1][lane]) + pj_part[2][lane]) + pj_part[3][lane];
+            }
+            const bool fix = counted && pj < list.p_clamp;
+            const double contrib = fix ? h * ((pj <= 0.0 ? -INFINITY : log(pj)) - list.log_p_clamp) : 0.0;
+            uint64_t todo = __ballot(fix);
+            while (todo) { // ascending rows (every wave computes the same)
+                const int kk = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                value += wave_bcast(contrib, kk);
+            }
+            if (NW > 1)
+                __syncthreads(); // pj_part is rewritten by the next chunk
+        }
+        if (lane == 0 && wave == 0)
+            ll[pt] = value;
+    }
+}
+
 __global__ __launch_bounds__(256) void argmin_stage2(const double *__restrict__ pv,
                                                      const int64_t *__restrict__ pi, int n_part, int64_t flat_begin,
-                                                     ArgminResult *__restrict__ result)
+                                                     ArgminResult *__restrict__ result, unsigned *__restrict__ queue_count)
 {
+    if (threadIdx.x == 0 && queue_count)
+        *queue_count = 0; // the hand-back queue of the launch before (drained by ll_fix_list_kernel) starts empty again
     Cand c;
     c.v = INFINITY;
     c.i = INT64_MAX;
@@ -132,18 +244,28 @@ __global__ __launch_bounds__(256) void argmin_stage2(const double *__restrict__ 
 
 } // namespace
 
-hipError_t launch_argmin(const DevModel &m, const PointSource &src, double *ll, int64_t n, int64_t flat_begin,
-                         double *partial_val, int64_t *partial_idx, ArgminResult *result, hipStream_t stream)
+hipError_t launch_ll_fix_list(const DevModel &m, const TileView &tv, const PointSource &src, double *ll,
+                              const SubList &list, hipStream_t stream)
+{
+    // enough workgroups to spread a few thousand queued points over the chip; an empty queue is the common case
+    const dim3 grid(2048), block(256);
+    if (m.kind == 0)
+        hipLaunchKernelGGL((ll_fix_list_kernel<2, 1>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+                           tv.int_base, src, ll, list);
+    else
+        hipLaunchKernelGGL((ll_fix_list_kernel<5, 4>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+                           tv.int_base, src, ll, list);
+    return hipGetLastError();
+}
+
+hipError_t launch_argmin(const double *ll, int64_t n, int64_t flat_begin, double *partial_val, int64_t *partial_idx,
+                         ArgminResult *result, unsigned *queue_count, hipStream_t stream)
 {
     // (a small grid needs no more workgroups than it has waves of points)
     const int blocks = (int)std::min<int64_t>(kArgminBlocks, std::max<int64_t>(1, (n + 255) / 256));
-    if (m.kind == 0)
-        hipLaunchKernelGGL(argmin_stage1<2>, dim3(blocks), dim3(256), 0, stream, m, src, ll, n, partial_val,
-                           partial_idx);
-    else
-        hipLaunchKernelGGL(argmin_stage1<5>, dim3(blocks), dim3(256), 0, stream, m, src, ll, n, partial_val,
-                           partial_idx);
-    hipLaunchKernelGGL(argmin_stage2, dim3(1), dim3(256), 0, stream, partial_val, partial_idx, blocks, flat_begin, result);
+    hipLaunchKernelGGL(argmin_stage1, dim3(blocks), dim3(256), 0, stream, ll, n, partial_val, partial_idx);
+    hipLaunchKernelGGL(argmin_stage2, dim3(1), dim3(256), 0, stream, partial_val, partial_idx, blocks, flat_begin, result,
+                       queue_count);
     return hipGetLastError();
 }
 

@@ -96,6 +96,7 @@ struct covest_model {
     bool has_tiles = false;
     // scratch for covest_eval_points / covest_probabilities
     DevBuf ws_params, ws_t, ws_out, ws_p, ws_plan, ws_plan2, ws_partial, ws_items;
+    DevBuf ws_sub_index, ws_sub_word, ws_sub_ctl; // the queue of handed-back points of a point-list launch (direct_point.h)
     std::mutex lock;
 };
 
@@ -104,7 +105,7 @@ struct covest_grid {
     int64_t len[kMaxParams] = {1, 1, 1, 1, 1};
     int64_t flat_begin = 0, flat_end = 0;
     PointSource src{};
-    DevBuf axes, t_table, ll, partial_val, partial_idx, result, plan_buf;
+    DevBuf axes, t_table, ll, sub_index, sub_word, sub_ctl, partial_val, partial_idx, result, plan_buf;
     FactoredPlan plan{};        // K-factored work description (repeats model, dense grid)
     bool has_plan = false;
     double q_sum_t_minus_1 = 0.0; // sum over the Q weight vectors of (threshold_o - 1)
@@ -284,6 +285,7 @@ constexpr int kMaxFastKey = 16384;
 struct HostBin {
     int key;
     double cnt;
+    int32_t index; // in the evaluated bin view (DevModel::bins)
 };
 
 int build_tiles(covest_model *m, std::vector<HostBin> bins)
@@ -299,6 +301,7 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     };
     std::vector<Tile> tiles;
     std::vector<double> scal, cnt;
+    std::vector<int32_t> row_bin;
     size_t i = 0;
     while (i < bins.size()) {
         // one run: keys bins[i..j) with gaps <= kGapFill
@@ -313,12 +316,14 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
             long double sc = ldexpl(1.0L, -kScaleBits);
             for (int b = 0; b < kTileBins; ++b) {
                 double sv = 0.0, cv = 0.0;
+                int32_t which = -1;
                 if (b < nb) {
                     const int key = k0 + b;
                     sc /= (long double)key;
                     if (cur < j && bins[cur].key == key) {
                         sv = (double)sc;
                         cv = bins[cur].cnt;
+                        which = bins[cur].index;
                         ++cur;
                     } // else a FILLER key (a gap of the histogram the recurrence walks through): scale 0, so
                       // that its p_j is exactly 0 -- it is no key of the reference's p_j dict, and must add
@@ -326,6 +331,7 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
                 }
                 scal.push_back(sv);
                 cnt.push_back(cv);
+                row_bin.push_back(which);
             }
         }
         i = j;
@@ -346,8 +352,42 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
         ints[t] = tl.nb;
         ints[nt + t] = tl.run_start;
     }
-    const size_t n_dbl = 4 * nt + 2 * nt * kTileBins;
-    const size_t bytes = n_dbl * sizeof(double) + 2 * nt * sizeof(int32_t);
+    // items (tiles.h): runs of all-zero-count tiles (they exist only with a tail) are grouped, up to 32 per item
+    std::vector<int32_t> item_first, item_ntiles, item_sum;
+    std::vector<double> item_cnt;
+    for (size_t t = 0; t < nt;) {
+        auto all_zero = [&](size_t tt) {
+            for (int b = 0; b < kTileBins; ++b)
+                if (cnt[tt * kTileBins + (size_t)b] != 0.0)
+                    return false;
+            return true;
+        };
+        if (!all_zero(t)) {
+            item_first.push_back((int32_t)t);
+            item_ntiles.push_back(1);
+            item_sum.push_back(0);
+            item_cnt.insert(item_cnt.end(), cnt.begin() + (std::ptrdiff_t)(t * kTileBins),
+                            cnt.begin() + (std::ptrdiff_t)((t + 1) * kTileBins));
+            ++t;
+            continue;
+        }
+        size_t e = t + 1;
+        while (e < nt && e - t < (size_t)kTileBins && all_zero(e))
+            ++e;
+        item_first.push_back((int32_t)t);
+        item_ntiles.push_back((int32_t)(e - t));
+        item_sum.push_back(1);
+        item_cnt.insert(item_cnt.end(), (size_t)kTileBins, 0.0);
+        t = e;
+    }
+    const size_t ni = item_first.size();
+    const size_t n_dbl = 4 * nt + 2 * nt * kTileBins + ni * kTileBins;
+    std::vector<int32_t> tile_zero(nt, 0);
+    for (size_t i2 = 0; i2 < ni; ++i2)
+        if (item_sum[i2])
+            for (int32_t r = 0; r < item_ntiles[i2]; ++r)
+                tile_zero[(size_t)(item_first[i2] + r)] = 1;
+    const size_t bytes = n_dbl * sizeof(double) + (3 * nt + 3 * ni + nt * kTileBins) * sizeof(int32_t);
     HIP_TRY(m->tiles_buf.reserve(bytes));
     double *base = m->tiles_buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(base + n_dbl);
@@ -360,11 +400,23 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     put(dbl.data(), 4 * nt * sizeof(double));
     put(scal.data(), nt * kTileBins * sizeof(double));
     put(cnt.data(), nt * kTileBins * sizeof(double));
+    put(item_cnt.data(), ni * kTileBins * sizeof(double));
     put(ints.data(), 2 * nt * sizeof(int32_t));
+    put(tile_zero.data(), nt * sizeof(int32_t));
+    put(item_first.data(), ni * sizeof(int32_t));
+    put(item_ntiles.data(), ni * sizeof(int32_t));
+    put(item_sum.data(), ni * sizeof(int32_t));
+    put(row_bin.data(), nt * kTileBins * sizeof(int32_t));
     HIP_TRY(hipMemcpy(base, stage.data(), bytes, hipMemcpyHostToDevice));
-    m->tv = tile_view_from((int32_t)nt, base, ibase);
+    m->tv = tile_view_from((int32_t)nt, (int32_t)ni, base, ibase);
     m->has_tiles = true;
     return COVEST_OK;
+}
+
+// p_clamp of direct_point.h for a launch whose largest threshold_o is t_max.
+double clamp_for(const covest_model *m, int t_max)
+{
+    return (double)(m->dm.n_err + std::max(t_max, 2)) * kClampPerTerm;
 }
 
 // RepeatsModel.get_b_o, covest/models.py:193-208, with libm pow as CPython's float ** int.
@@ -423,7 +475,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         nfull[(size_t)n_qtiles - 1] = 0; // padding columns (T = 0) are cut off from the first step
     // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
     const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 1024 <= 160 * 1024 ? 2 : 1;
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 7680 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const int n_units = 2 * n_qtiles;
     const int nt = (t_max - 1 <= 256 && n_units <= 4 * kMaxUnits) ? 256 : 512;
     const int hu = kHalfUnits; // (768 threads with 2 slots per half, 3 waves/SIMD, was measured: +1 %)
@@ -580,6 +632,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     pl.flat_begin = g->flat_begin;
     pl.flat_end = g->flat_end;
     pl.list_mode = 0;
+    pl.p_clamp = clamp_for(m, t_max);
     pl.n_seg = 1;
     pl.item_obase = nullptr;
     pl.partial = nullptr;
@@ -615,7 +668,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     for (int64_t i = 0; i < n; ++i)
         t_max = std::max(t_max, std::min(513, (int)t_list[(size_t)i] - o_base_of(i)));
     const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 1024 <= 160 * 1024 ? 2 : 1;
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 7680 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
     std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 2 * 64, 0.0);
     std::vector<int32_t> q_t(n_slots, 0), q_orig(n_slots, -1), unit_tile(n_unit, -1), unit_half(n_unit, 0),
@@ -710,7 +763,9 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     pl.flat_begin = 0;
     pl.flat_end = n;
     pl.list_mode = 1;
-    pl.n_seg = std::max(1, std::min(kListSegments, (int)m->tv.n_tiles)); // a function of the histogram alone
+    // (one value for every point list, whatever it holds: a point's value must not depend on its company)
+    pl.p_clamp = clamp_for(m, 513);
+    pl.n_seg = std::max(1, std::min(kListSegments, (int)m->tv.n_items)); // a function of the histogram alone
     pl.item_obase = nullptr;
     pl.partial = nullptr;
     pl.diag = nullptr;
@@ -805,7 +860,7 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
             key_e.push_back(kd);
             lg_e.push_back(lg);
             cnt_e.push_back(h);
-            eval_bins.push_back({j, h});
+            eval_bins.push_back({j, h, (int32_t)key_e.size() - 1});
         }
     }
     m->hist_max = d->n_keys > 0 ? hist_max : 0;
@@ -852,6 +907,9 @@ void covest_model_destroy(covest_model *m)
     m->ws_plan2.release();
     m->ws_partial.release();
     m->ws_items.release();
+    m->ws_sub_index.release();
+    m->ws_sub_word.release();
+    m->ws_sub_ctl.release();
     delete m;
 }
 
@@ -942,72 +1000,98 @@ static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_gr
     }
 }
 
+static SubList sub_list_of(const covest_model *m, int t_max, const DevBuf &index, const DevBuf &word, const DevBuf &ctl)
+{
+    SubList l{};
+    l.p_clamp = clamp_for(m, t_max);
+    l.log_p_clamp = std::log(l.p_clamp);
+    l.count = ctl.as<unsigned>();
+    l.index = index.as<int64_t>();
+    l.word = word.as<unsigned long long>();
+    l.index_offset = 0;
+    return l;
+}
+
+// `sub`: the queue the recurrence kernels append the points they hand back to (direct_point.h) -- drained right
+// behind them by the fix pass; K-direct has nothing to hand back.  The queue must be empty (counter 0) on entry.
 static hipError_t launch_ll(const covest_model *m, int kernel, const PointSource &src, int64_t n,
-                            double *out, hipStream_t st, const char **name,
+                            double *out, const SubList &sub, hipStream_t st, const char **name,
                             const covest_grid *g = nullptr)
 {
     if (kernel == COVEST_KERNEL_FACTORED) {
         if (name)
             *name = "ll_factored";
-        return launch_ll_factored(m->dm, m->tv, g->plan, out, st);
+        hipError_t e = launch_ll_factored(m->dm, m->tv, g->plan, out, sub, st);
+        return e != hipSuccess ? e : launch_ll_fix_list(m->dm, m->tv, src, out, sub, st);
     }
     if (kernel == COVEST_KERNEL_RECUR) {
         if (name)
             *name = "ll_basic";
-        return launch_ll_basic(m->dm, m->tv, src, n, out, st);
+        hipError_t e = launch_ll_basic(m->dm, m->tv, src, n, out, sub, st);
+        return e != hipSuccess ? e : launch_ll_fix_list(m->dm, m->tv, src, out, sub, st);
     }
     if (name)
         *name = "ll_direct";
     return launch_ll_direct(m->dm, src, n, out, nullptr, st);
 }
 
-static bool is_redo_marker_host(double v)
+// Workspace of a point-list launch's queue (direct_point.h): room for n entries, counters zeroed on first use.
+static int reserve_point_queue(covest_model *m, int64_t n)
 {
-    unsigned long long bits;
-    std::memcpy(&bits, &v, sizeof bits);
-    return bits == kRedoBits;
+    HIP_TRY(m->ws_sub_index.reserve((size_t)n * sizeof(int64_t)));
+    HIP_TRY(m->ws_sub_word.reserve((size_t)n * sizeof(unsigned long long)));
+    HIP_TRY(m->ws_sub_ctl.reserve(sizeof(unsigned)));
+    HIP_TRY(hipMemset(m->ws_sub_ctl.ptr, 0, sizeof(unsigned))); // the queue starts empty (every point-list call)
+    return COVEST_OK;
 }
 
-static double redo_marker_host()
-{
-    const unsigned long long bits = kRedoBits;
-    double v;
-    std::memcpy(&v, &bits, sizeof v);
-    return v;
-}
-
-// Point lists: the points a recurrence kernel handed back (redo marker in out_ll, direct_point.h: a key with
-// h_j != 0 has a subnormal p_j there) are evaluated by K-direct and patched.  Called with the model locked.
-static int redo_points_direct(covest_model *m, int64_t n, const double *params, double *out_ll)
+// Point lists through K-factored's list mode: add the strict evaluation of the rows the kernel handed back
+// (words[i] != 0, direct_point.h) to out_ll[i].  Called with the model locked.
+static int fix_points_host(covest_model *m, int64_t n, const double *params, double *out_ll,
+                           const std::vector<unsigned long long> &words)
 {
     std::vector<int64_t> again;
     for (int64_t i = 0; i < n; ++i)
-        if (is_redo_marker_host(out_ll[i]))
+        if (words[(size_t)i] != 0 && std::isfinite(out_ll[i]))
             again.push_back(i);
     if (again.empty())
         return COVEST_OK;
     const int P = m->n_par;
-    std::vector<double> sub_par(again.size() * (size_t)P);
-    std::vector<int32_t> sub_t(again.size(), 2);
-    for (size_t k = 0; k < again.size(); ++k) {
+    const size_t na = again.size();
+    std::vector<double> sub_par(na * (size_t)P), sub_ll(na);
+    std::vector<int32_t> sub_t(na, 2);
+    std::vector<unsigned long long> sub_w(na);
+    std::vector<int64_t> sub_i(na);
+    for (size_t k = 0; k < na; ++k) {
         std::memcpy(&sub_par[k * (size_t)P], params + again[k] * P, (size_t)P * sizeof(double));
         if (P == 5)
             sub_t[k] = threshold_for_point(m, params + again[k] * P);
+        sub_ll[k] = out_ll[again[k]];
+        sub_w[k] = words[(size_t)again[k]];
+        sub_i[k] = (int64_t)k;
     }
+    int rc = reserve_point_queue(m, (int64_t)na);
+    if (rc != COVEST_OK)
+        return rc;
     HIP_TRY(m->ws_params.reserve(sub_par.size() * sizeof(double)));
-    HIP_TRY(m->ws_t.reserve(sub_t.size() * sizeof(int32_t)));
-    HIP_TRY(m->ws_out.reserve(again.size() * sizeof(double)));
+    HIP_TRY(m->ws_t.reserve(na * sizeof(int32_t)));
+    HIP_TRY(m->ws_out.reserve(na * sizeof(double)));
     HIP_TRY(hipMemcpy(m->ws_params.ptr, sub_par.data(), sub_par.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->ws_t.ptr, sub_t.data(), sub_t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->ws_t.ptr, sub_t.data(), na * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->ws_out.ptr, sub_ll.data(), na * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->ws_sub_index.ptr, sub_i.data(), na * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->ws_sub_word.ptr, sub_w.data(), na * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    const unsigned count = (unsigned)na;
+    HIP_TRY(hipMemcpy(m->ws_sub_ctl.ptr, &count, sizeof count, hipMemcpyHostToDevice));
     PointSource src{};
     src.is_grid = 0;
     src.params = m->ws_params.as<double>();
     src.t_list = P == 5 ? m->ws_t.as<int32_t>() : nullptr;
-    HIP_TRY(launch_ll_direct(m->dm, src, (int64_t)again.size(), m->ws_out.as<double>(), nullptr, nullptr));
-    std::vector<double> got(again.size());
-    HIP_TRY(hipMemcpy(got.data(), m->ws_out.ptr, got.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < again.size(); ++k)
-        out_ll[again[k]] = got[k];
+    HIP_TRY(launch_ll_fix_list(m->dm, m->tv, src, m->ws_out.as<double>(),
+                               sub_list_of(m, m->n_par == 5 ? 513 : 2, m->ws_sub_index, m->ws_sub_word, m->ws_sub_ctl), nullptr));
+    HIP_TRY(hipMemcpy(sub_ll.data(), m->ws_out.ptr, na * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < na; ++k)
+        out_ll[again[k]] = sub_ll[k];
     return COVEST_OK;
 }
 
@@ -1035,6 +1119,12 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
     HIP_TRY(m->ws_params.reserve((size_t)n * P * sizeof(double)));
     HIP_TRY(m->ws_out.reserve((size_t)n * sizeof(double)));
     HIP_TRY(m->ws_t.reserve((size_t)n * sizeof(int32_t)));
+    {
+        const int qrc = reserve_point_queue(m, n);
+        if (qrc != COVEST_OK)
+            return qrc;
+    }
+    const SubList queue = sub_list_of(m, m->n_par == 5 ? 513 : 2, m->ws_sub_index, m->ws_sub_word, m->ws_sub_ctl);
     PointSource src{};
     src.is_grid = 0;
     src.params = m->ws_params.as<double>();
@@ -1057,6 +1147,7 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         // sum) goes to K-direct.
         std::vector<int32_t> t((size_t)n);
         std::vector<int64_t> fits, big, rest;
+        std::vector<unsigned long long> words((size_t)n, 0ull); // keys handed back per point (direct_point.h)
         for (int64_t i = 0; i < n; ++i) {
             t[(size_t)i] = threshold_for_point(m, params + i * P);
             const int o_max = t[(size_t)i] - 1;
@@ -1073,22 +1164,27 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
             rc = build_list_plan(m, (int64_t)fits.size(), sub_par.data(), sub_t, nullptr, m->ws_plan, pl);
             if (rc != COVEST_OK)
                 return rc;
-            // {LL part, sp_j part (hi, lo)} per (point, key segment); the segments are added here, in order
+            // {LL part, sp_j part (hi, lo), side word} per (point, key segment); the segments are added here, in order
             const size_t n_parts = fits.size() * (size_t)pl.n_seg;
-            HIP_TRY(m->ws_partial.reserve(n_parts * 3 * sizeof(double)));
+            HIP_TRY(m->ws_partial.reserve(n_parts * 4 * sizeof(double)));
             pl.partial = m->ws_partial.as<double>();
-            HIP_TRY(launch_ll_factored(m->dm, m->tv, pl, m->ws_out.as<double>(), nullptr));
-            std::vector<double> got(n_parts * 3);
+            HIP_TRY(launch_ll_factored(m->dm, m->tv, pl, m->ws_out.as<double>(), queue, nullptr));
+            std::vector<double> got(n_parts * 4);
             HIP_TRY(hipMemcpy(got.data(), m->ws_partial.ptr, got.size() * sizeof(double), hipMemcpyDeviceToHost));
             for (size_t k = 0; k < fits.size(); ++k) {
                 double ll = 0.0, hi = 0.0, lo = 0.0;
-                bool redo = false; // a segment met a subnormal p_j with weight (ll_factored.hip, phase C)
+                unsigned u_first = 0xFFFFFFFFu, u_last = 0; // the segments' handed-back units, merged
+                bool any_unit = false;
                 for (int sg = 0; sg < pl.n_seg; ++sg) {
-                    const double *o = &got[(k * (size_t)pl.n_seg + (size_t)sg) * 3];
-                    if (is_redo_marker_host(o[0]))
-                        redo = true;
-                    else
-                        ll += o[0];
+                    const double *o = &got[(k * (size_t)pl.n_seg + (size_t)sg) * 4];
+                    ll += o[0];
+                    unsigned long long w;
+                    std::memcpy(&w, &o[3], sizeof w);
+                    if (w != 0) {
+                        any_unit = true;
+                        u_first = std::min(u_first, sub_first(w));
+                        u_last = std::max(u_last, sub_last(w));
+                    }
                     const double sum = hi + o[1], bb = sum - hi; // two-sum, as the kernels' CompSum
                     lo += ((hi - (sum - bb)) + (o[1] - bb)) + o[2];
                     hi = sum;
@@ -1101,17 +1197,17 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
                     if (sp < 1.0)
                         tail_term = m->dm.tail * std::log(1.0 - sp);
                 }
-                const double v = ll + tail_term;
-                out_ll[fits[k]] = redo && std::isfinite(v) ? redo_marker_host() : v;
+                out_ll[fits[k]] = ll + tail_term;
+                words[(size_t)fits[k]] = any_unit ? sub_word(u_first, u_last, true) : 0ull;
             }
         }
         if (!big.empty()) {
-            std::vector<double> item_par, point_ce(2 * big.size());
-            std::vector<int32_t> item_t, item_ob, first_item(big.size() + 1, 0);
+            std::vector<double> item_par, point_par(5 * big.size());
+            std::vector<int32_t> item_t, item_ob, first_item(big.size() + 1, 0), point_t(big.size());
             for (size_t k = 0; k < big.size(); ++k) {
                 const double *par = params + big[k] * 5;
-                point_ce[2 * k] = par[0];
-                point_ce[2 * k + 1] = par[1];
+                std::memcpy(&point_par[5 * k], par, 5 * sizeof(double));
+                point_t[k] = t[(size_t)big[k]];
                 for (int ob = 0; ob < t[(size_t)big[k]] - 1; ob += 512) {
                     item_par.insert(item_par.end(), par, par + 5);
                     item_t.push_back(t[(size_t)big[k]]);
@@ -1120,26 +1216,33 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
                 first_item[k + 1] = (int32_t)item_t.size();
             }
             const int64_t n_items = (int64_t)item_t.size();
-            const size_t n_keys = (size_t)m->tv.n_tiles * kTileBins;
+            const size_t n_keys = (size_t)m->tv.n_items * kTileBins; // rows of the items (tiles.h)
             FactoredPlan pl;
             rc = build_list_plan(m, n_items, item_par.data(), item_t, &item_ob, m->ws_plan2, pl);
             if (rc != COVEST_OK)
                 return rc;
             HIP_TRY(m->ws_partial.reserve((size_t)n_items * n_keys * sizeof(double)));
             const size_t items_bytes = (size_t)n_items * sizeof(int32_t), first_bytes = first_item.size() * sizeof(int32_t);
-            const size_t int_bytes = ((items_bytes + first_bytes + 7) / 8) * 8;
-            HIP_TRY(m->ws_items.reserve(int_bytes + point_ce.size() * sizeof(double)));
+            const size_t pt_bytes = point_t.size() * sizeof(int32_t);
+            const size_t int_bytes = ((items_bytes + first_bytes + pt_bytes + 7) / 8) * 8;
+            HIP_TRY(m->ws_items.reserve(int_bytes + point_par.size() * sizeof(double)));
             char *ib = m->ws_items.as<char>();
-            HIP_TRY(hipMemcpy(ib, item_ob.data(), items_bytes, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(ib + items_bytes, first_item.data(), first_bytes, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(ib + int_bytes, point_ce.data(), point_ce.size() * sizeof(double), hipMemcpyHostToDevice));
+            {
+                std::vector<char> stage(int_bytes + point_par.size() * sizeof(double)); // one copy
+                std::memcpy(stage.data(), item_ob.data(), items_bytes);
+                std::memcpy(stage.data() + items_bytes, first_item.data(), first_bytes);
+                std::memcpy(stage.data() + items_bytes + first_bytes, point_t.data(), pt_bytes);
+                std::memcpy(stage.data() + int_bytes, point_par.data(), point_par.size() * sizeof(double));
+                HIP_TRY(hipMemcpy(ib, stage.data(), stage.size(), hipMemcpyHostToDevice));
+            }
             pl.list_mode = 2;
             pl.item_obase = reinterpret_cast<const int32_t *>(ib);
             pl.partial = m->ws_partial.as<double>();
-            HIP_TRY(launch_ll_factored(m->dm, m->tv, pl, m->ws_out.as<double>(), nullptr));
+            HIP_TRY(launch_ll_factored(m->dm, m->tv, pl, m->ws_out.as<double>(), queue, nullptr));
             HIP_TRY(launch_ll_finish_partials(m->dm, m->tv, pl.partial, reinterpret_cast<const int32_t *>(ib + items_bytes),
-                                              reinterpret_cast<const double *>(ib + int_bytes), (int64_t)big.size(),
-                                              m->ws_out.as<double>(), nullptr));
+                                              reinterpret_cast<const double *>(ib + int_bytes),
+                                              reinterpret_cast<const int32_t *>(ib + items_bytes + first_bytes),
+                                              (int64_t)big.size(), m->ws_out.as<double>(), nullptr));
             std::vector<double> got(big.size());
             HIP_TRY(hipMemcpy(got.data(), m->ws_out.ptr, big.size() * sizeof(double), hipMemcpyDeviceToHost));
             for (size_t k = 0; k < big.size(); ++k)
@@ -1154,18 +1257,17 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
             }
             HIP_TRY(hipMemcpy(m->ws_params.ptr, sub_par.data(), sub_par.size() * sizeof(double), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(m->ws_t.ptr, sub_t.data(), sub_t.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            HIP_TRY(launch_ll(m, COVEST_KERNEL_DIRECT, src, (int64_t)rest.size(), m->ws_out.as<double>(), nullptr, nullptr));
+            HIP_TRY(launch_ll(m, COVEST_KERNEL_DIRECT, src, (int64_t)rest.size(), m->ws_out.as<double>(), queue, nullptr, nullptr));
             std::vector<double> got(rest.size());
             HIP_TRY(hipMemcpy(got.data(), m->ws_out.ptr, rest.size() * sizeof(double), hipMemcpyDeviceToHost));
             for (size_t k = 0; k < rest.size(); ++k)
                 out_ll[rest[k]] = got[k];
         }
-        return redo_points_direct(m, n, params, out_ll);
+        return fix_points_host(m, n, params, out_ll, words);
     }
-    HIP_TRY(launch_ll(m, kern, src, n, m->ws_out.as<double>(), nullptr, nullptr));
+    // (K-basic is followed by the pass that patches the points it handed back: launch_ll)
+    HIP_TRY(launch_ll(m, kern, src, n, m->ws_out.as<double>(), queue, nullptr, nullptr));
     HIP_TRY(hipMemcpy(out_ll, m->ws_out.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    if (kern == COVEST_KERNEL_RECUR)
-        return redo_points_direct(m, n, params, out_ll);
     return COVEST_OK;
 }
 
@@ -1261,6 +1363,9 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
         g->axes.release();
         g->t_table.release();
         g->ll.release();
+        g->sub_index.release();
+        g->sub_word.release();
+        g->sub_ctl.release();
         g->partial_val.release();
         g->partial_idx.release();
         g->result.release();
@@ -1330,6 +1435,11 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
     }
 
     GRID_TRY(g->ll.reserve((size_t)(n > 0 ? n : 1) * sizeof(double)));
+    // the queue of points the recurrence kernels hand back (direct_point.h): as many entries as points, two counters
+    GRID_TRY(g->sub_index.reserve((size_t)(n > 0 ? n : 1) * sizeof(int64_t)));
+    GRID_TRY(g->sub_word.reserve((size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));
+    GRID_TRY(g->sub_ctl.reserve(sizeof(unsigned)));
+    GRID_TRY(hipMemset(g->sub_ctl.ptr, 0, sizeof(unsigned)));
     GRID_TRY(g->partial_val.reserve(kArgminBlocks * sizeof(double)));
     GRID_TRY(g->partial_idx.reserve(kArgminBlocks * sizeof(int64_t)));
     GRID_TRY(g->result.reserve(sizeof(ArgminResult)));
@@ -1346,6 +1456,9 @@ void covest_grid_destroy(covest_grid *g)
     g->axes.release();
     g->t_table.release();
     g->ll.release();
+    g->sub_index.release();
+    g->sub_word.release();
+    g->sub_ctl.release();
     g->partial_val.release();
     g->partial_idx.release();
     g->result.release();
@@ -1417,12 +1530,13 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
         g->ev_used++;
         HIP_TRY(hipEventRecord(e0, st));
     }
-    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), st, &g->last_kernel, g));
+    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), sub_list_of(m, g->has_plan ? g->plan.max_o + 1 : 2, g->sub_index, g->sub_word, g->sub_ctl), st,
+                      &g->last_kernel, g));
     g->last_kernel_id = kern;
     if (e1)
         HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(launch_argmin(m->dm, g->src, g->ll.as<double>(), n, g->flat_begin, g->partial_val.as<double>(),
-                          g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), st));
+    HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->flat_begin, g->partial_val.as<double>(),
+                          g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), g->sub_ctl.as<unsigned>(), st));
     g->last_stream = st;
     g->evaluated = true;
     return COVEST_OK;

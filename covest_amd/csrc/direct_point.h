@@ -1,6 +1,6 @@
 // direct_point.h -- the log-likelihood of ONE grid point computed by ONE wave64, the body of
-// K-direct (ll_direct.hip).  Also called from the arg-min pass (argmin.hip) for the points a fast
-// kernel hands back (kRedoBits): there every wave re-evaluates the flagged points of its 64.
+// K-direct (ll_direct.hip); and, with the same arithmetic, the strict evaluation of single keys for
+// the points a recurrence kernel hands back (strict_pj_wave here; ll_fix_list_kernel in argmin.hip).
 //
 // Every lane owns histogram bins, the (copy number o, error class s) mixture components are
 // prepared lane-parallel and broadcast through the scalar unit, every pmf term costs one fp64
@@ -18,26 +18,108 @@
 
 #include "device_model.h"
 #include "point_fetch.h"
+#include "tiles.h"
 #include "wave.h"
 
 namespace covest {
 
-// "Evaluate this point again with the strict kernel": the value a recurrence kernel (K-basic,
-// K-factored) writes for a point at which some key with h_j != 0 has a SUBNORMAL p_j -- there the
-// reference's result depends on the rounding of every single term onto the 4.9e-324 grid, which
-// only the term-by-term evaluation reproduces.  A quiet NaN with a payload no arithmetic produces;
-// it never leaves the library (argmin.hip / capi.cpp replace it by K-direct's value).
-constexpr unsigned long long kRedoBits = 0x7FF8C0DE5B0A0001ull;
 
-__device__ __forceinline__ double redo_marker() { return __longlong_as_double((long long)kRedoBits); }
-__device__ __forceinline__ bool is_redo_marker(double v)
+// ---- the hand-back of the recurrence kernels: a RANGE of tile rows per point ----
+// Where keys with h_j != 0 have a subnormal p_j -- typically a run of a few dozen keys at one end of the counted
+// keys -- the reference's value hangs on the rounding of every single term onto the 4.9e-324 grid (DESIGN.md
+// section 2), which only the term-by-term evaluation reproduces.  How far the recurrence kernels' own p_j can be
+// off there is bounded.  With g = 4.94e-324: the reference rounds each of the S terms of a copy number twice
+// (<= g each, weighted by b_o, and the b_o sum to <= 1) and each copy number's share once (g / 2); the recurrence
+// kernels round each G[o][j] once and each accumulation step once.  So |p_j - p_j(reference)| <= (S + T) g, which
+// moves the log-likelihood by at most h_j (S + T) g / p_j -- and |LL| >= 708 h_j because of that very key.  So above
+//     p_clamp = (S + T_max) * 7e-317     (T_max: the largest threshold_o of the launch)
+// the recurrence kernels' value is within 1e-10 of the reference's whatever the roundings were, and nothing needs
+// doing.  Below it they take log(max(p_j, p_clamp)) (one v_max per log, everywhere), so what such a key
+// contributed is KNOWN -- h_j log(p_clamp) -- and they name, in a 64-bit side word per point, the first and last
+// tile row (row = 32 * tile + position, tiles.h) at which they met one: single rows (K-basic) or units of 16 rows
+// (K-factored: the half tile of a weight vector).  ll_fix_list_kernel (argmin.hip) then evaluates the counted rows
+// of that range strictly (K-direct's arithmetic) and, where the strict p_j is below p_clamp, replaces the known
+// contribution by h_j safe_log(p_j).
+constexpr unsigned long long kSubFieldMask = 0xFFFFFull; // 20 bits: rows < 2^20 (16384 keys, one tile each, at worst)
+constexpr double kClampPerTerm = 7e-317; // see above
+
+__host__ __device__ inline unsigned long long sub_word(unsigned first, unsigned last, bool units16)
 {
-    return (unsigned long long)__double_as_longlong(v) == kRedoBits;
+    return (1ull << 62) | ((unsigned long long)(units16 ? 1 : 0) << 60) | ((unsigned long long)last << 20) |
+           (unsigned long long)first;
 }
+// The queue of handed-back points of one launch: (local point index, side word) pairs appended with one atomic
+// each by the thread that writes the point's value.  Capacity = the number of points, so it cannot overflow.
+// ll_fix_list_kernel (argmin.hip) drains it, one wave per entry.
+struct SubList {
+    double p_clamp;           // (S + T_max) * kClampPerTerm of this launch, and its log (libm, host)
+    double log_p_clamp;
+    unsigned *count;          // device counter; zero before the launch
+    int64_t *index;           // [capacity] index into the launch's LL buffer
+    unsigned long long *word; // [capacity]
+    int64_t index_offset;     // added by the launcher when it cuts a launch into parts
+#ifdef __HIPCC__
+    __device__ __forceinline__ void push(int64_t idx, unsigned long long w) const
+    {
+        const unsigned at = atomicAdd(count, 1u);
+        index[at] = idx;
+        word[at] = w;
+    }
+#endif
+};
 
-constexpr double kMinNormal = 2.2250738585072014e-308; // DBL_MIN: below it p_j is subnormal (or 0)
+__host__ __device__ inline unsigned sub_first(unsigned long long w) { return (unsigned)(w & kSubFieldMask); }
+__host__ __device__ inline unsigned sub_last(unsigned long long w) { return (unsigned)((w >> 20) & kSubFieldMask); }
+__host__ __device__ inline bool sub_units16(unsigned long long w) { return ((w >> 60) & 1) != 0; }
 
 constexpr int kDirectBinsPerLane = 4; // bins held in registers per lane per pass
+
+// p_j of ONE bin at one point, by the whole wave, with K-direct's arithmetic: the same expressions, the same
+// order of the two sums (error classes inside, copy numbers outside: covest/models.py:92-97, :235-241), every
+// term rounded to a double on its own.  All lanes call it with the same arguments and get the same value.
+// par: the point's parameters AFTER clamp_point; key / neg_lgam: the bin's j and -lgamma(j + 1).
+template <int P>
+__device__ __forceinline__ double strict_pj_wave(const DevModel &m, const double *par, int T, double key, double neg_lgam)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int S = m.n_err;
+    const int OT = kWave / S;
+    const int s = lane % S;
+    const int og = lane / S;
+    const bool lane_in_tile = og < OT;
+    const double lam = error_class_rate(m, par[0], par[1], s);
+    const double comb_s = m.comb[s];
+    double p = 0.0;
+    for (int o0 = 1; o0 < T; o0 += OT) {
+        const int o = o0 + og;
+        const bool live = lane_in_tile && o < T;
+        const double x = (double)o * lam;
+        const double n_os = comb_s * (1.0 - exp_neg_rn(x));
+        double tot = 0.0;
+        for (int t = 0; t < S; ++t)
+            tot += __shfl(n_os, og * S + t, kWave);
+        if (tot == 0.0)
+            tot = 1.0;
+        double a_os = n_os / tot;
+        const double b_o = (P == 5) ? copy_number_weight(par[2], par[3], par[4], o) : 1.0;
+        double lx = 0.0, nd = -INFINITY;
+        if (live && x > 0.0) {
+            lx = log(x);
+            nd = -log_trunc_norm(x, lx);
+        }
+        if (!live)
+            a_os = 0.0;
+        const double term = a_os != 0.0 ? a_os * exp(fma(key, lx, nd + neg_lgam)) : 0.0;
+        const int n_o = min(OT, T - o0);
+        for (int g = 0; g < n_o; ++g) { // wave-uniform; copy numbers in ascending order
+            double inner = 0.0;
+            for (int t = 0; t < S; ++t)
+                inner += __shfl(term, g * S + t, kWave);
+            p += __shfl(b_o, g * S, kWave) * inner;
+        }
+    }
+    return p;
+}
 
 // All 64 lanes of a wave call this with the same point; every lane returns the point's LL.
 template <int P, bool WRITE_P>

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "device_model.h"
+#include "direct_point.h"
 #include "tiles.h"
 
 namespace covest {
@@ -16,19 +17,29 @@ hipError_t launch_ll_direct(const DevModel &m, const PointSource &src, int64_t n
 
 // K-basic: basic model, one lane per grid point, pmf recurrence (ll_basic.hip).
 // Needs n_err == 8 and a tile table (keys in 1..16384).
+// sub_list: the queue of points handed back (direct_point.h); run launch_ll_fix_list after this.
 hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSource &src, int64_t n,
-                           double *out_ll, hipStream_t stream);
+                           double *out_ll, const SubList &sub_list, hipStream_t stream);
 
 // K-factored: repeats model on a dense grid, one workgroup per (c, e)
 // (ll_factored.hip).  out_ll is the block's LL buffer (index flat - plan.flat_begin).
+// sub_list: the queue of points handed back (direct_point.h; dense grids -- list mode 1 hands the side words over
+// in `partial`, list mode 2 leaves the strict evaluation to ll_finish_partials); run launch_ll_fix_list after this.
 hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
-                              double *out_ll, hipStream_t stream);
+                              double *out_ll, const SubList &sub_list, hipStream_t stream);
 
 // Chunked point list (tiles.h FactoredPlan::list_mode 2): combine the chunks' shares of p_j per point and
-// take the logs.  first_item[n_points + 1] delimits each point's chunks; point_ce[2 n_points] = (c, e).
+// take the logs.  first_item[n_points + 1] delimits each point's chunks; point_par[5 n_points] and point_T[n_points]
+// are the points' parameters and threshold_o.
 hipError_t launch_ll_finish_partials(const DevModel &m, const TileView &tv, const double *partial,
-                                     const int32_t *first_item, const double *point_ce, int64_t n_points,
-                                     double *out_ll, hipStream_t stream);
+                                     const int32_t *first_item, const double *point_par, const int32_t *point_T,
+                                     int64_t n_points, double *out_ll, hipStream_t stream);
+
+// The pass after every K-basic / K-factored launch: one wave per point of the queue `list` (direct_point.h) adds
+// the strict evaluation of the rows named in its side word to ll[], in place.  The queue's counter must be zero
+// before the NEXT recurrence launch: launch_argmin resets it (grids), the host does for point lists.
+hipError_t launch_ll_fix_list(const DevModel &m, const TileView &tv, const PointSource &src, double *ll,
+                              const SubList &list, hipStream_t stream);
 
 // (min -LL, lowest index) over ll[n]: two-stage reduction (argmin.hip).
 // partial_val/partial_idx need kArgminBlocks entries; result[0] = {min, bits of idx}.
@@ -38,10 +49,9 @@ struct ArgminResult {
     int64_t index;  // local index, -1 if no value is < +inf
     double pair[2]; // {min_negll, GLOBAL flat index as a double (-1 if none)}: what the ranks exchange
 };
-// The first pass also replaces every redo marker in ll (direct_point.h) by K-direct's value of that point:
-// m / src must be the model and point source the LL kernel ran with.
-hipError_t launch_argmin(const DevModel &m, const PointSource &src, double *ll, int64_t n, int64_t flat_begin,
-                         double *partial_val, int64_t *partial_idx, ArgminResult *result, hipStream_t stream);
+// queue_count: the hand-back queue's counter to reset (nullptr: none).
+hipError_t launch_argmin(const double *ll, int64_t n, int64_t flat_begin, double *partial_val, int64_t *partial_idx,
+                         ArgminResult *result, unsigned *queue_count, hipStream_t stream);
 
 // ---- K-kmer: k-mer abundance histogram (kmer_count.hip), SURVEY 8(f) row F1 ----
 // Open-addressing table in HBM, slots = 2^log2_slots, one 16-byte entry per slot: {key, count}

@@ -31,13 +31,13 @@ namespace covest {
 namespace {
 
 template <int S, bool TAIL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ll_basic_kernel(const DevModel m, const int32_t n_tiles,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ll_basic_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                        const double *__restrict__ tile_dbl,
                                                        const int32_t *__restrict__ tile_int,
                                                        const PointSource src, const int64_t n,
-                                                       double *__restrict__ out_ll)
+                                                       double *__restrict__ out_ll, SubList sub_list)
 {
-    const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
+    const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
     __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
     load_log_table(log_tab);
     __syncthreads();
@@ -63,22 +63,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     double acc_ll = 0.0;
     uint64_t dead = 0; // lanes that met a p_j <= 0 with h_j != 0
-    uint64_t tiny = 0; // lanes that met a p_j below the normal range with h_j != 0 (p_j <= 0 included)
+    unsigned long long subw = 0; // the rows this lane hands back (direct_point.h): first and last
+    const double p_clamp = sub_list.p_clamp;
     CompSum acc_sp = {0.0, 0.0};
 
     // one key's p_j (flushed like the reference's double): into sp_j, and its log (all branches
     // wave-uniform)
-    auto account = [&](double p, double h) {
+    auto account = [&](double p, double h, int row) {
         if (TAIL)
             acc_sp.add(p); // (filler keys have scale 0: p == 0)
         if (h != 0.0) { // filler keys and zero counts: no log (`if h`, covest/models.py:106)
-            // utils.safe_log: p_j <= 0 makes the whole sum -inf.  Remembered as a lane mask in
-            // SGPRs (one compare) instead of a select per key; fast_log(0) is finite.
-            dead |= __ballot(p <= 0.0);
-            // a SUBNORMAL p_j: the reference's value hangs on the rounding of every single term onto the
-            // 4.9e-324 grid -- the point is handed to the term-by-term kernel
-            tiny |= __ballot(p < kMinNormal);
-            acc_ll = fma(h, fast_log(p, log_tab), acc_ll);
+            // log(max(p_j, p_clamp)): what a p_j deep in the subnormal range contributes is then a known constant,
+            // which the strict evaluation of that key replaces later (direct_point.h); p_j <= 0 is remembered below
+            acc_ll = fma(h, fast_log(fmax(p, p_clamp), log_tab), acc_ll);
+            // one compare per key for everything out of the ordinary (lanes already dead have nothing to add)
+            const uint64_t low = __ballot(p < p_clamp) & ~dead;
+            if (__builtin_expect(low != 0, 0)) { // wave-uniform, cold
+                // utils.safe_log: p_j <= 0 makes the whole sum -inf -- remembered as a lane mask in SGPRs
+                dead |= __ballot(p <= 0.0);
+                if (p > 0.0 && p < p_clamp) // deep in the subnormal range: name the row (rows come in ascending order)
+                    subw = subw ? sub_word(sub_first(subw), (unsigned)row, false) : sub_word((unsigned)row, (unsigned)row, false);
+            }
         }
     };
 
@@ -89,7 +94,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                       tv.run_start[t] != 0);
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         const double *cnt = tv.cnt + (int64_t)t * kTileBins;
-        if (nb == kTileBins) {
+        if (TAIL && tv.all_zero[t] != 0) {
+            // a tile without a single count (they exist only with a tail): its keys take no log, only their
+            // p_j enter sp_j (covest/models.py:103) -- add them up plainly (32 terms of one sign) and hand the
+            // compensated accumulator ONE value per tile
+            double tile_sum = 0.0;
+            if (nb == kTileBins) {
+                double xx[S];
+                st.squares(xx);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    double sc[16];
+#pragma unroll
+                    for (int b = 0; b < 16; ++b)
+                        sc[b] = scal[16 * half + b];
+#pragma unroll
+                    for (int b = 0; b < 16; b += 2) {
+                        double g1, g2;
+                        st.step2(xx, g1, g2);
+                        tile_sum = fma(g1, sc[b], tile_sum);
+                        tile_sum = fma(g2, sc[b + 1], tile_sum);
+                    }
+                }
+            } else {
+                for (int b = 0; b < nb; ++b)
+                    tile_sum = fma(st.step(), scal[b], tile_sum);
+            }
+            acc_sp.add(tile_sum);
+        } else if (nb == kTileBins) {
             double xx[S]; // squared rates, recomputed per tile (S multiplies) rather than held in 2 S registers
             st.squares(xx);
             // full tile: two straight-line halves of 16 keys, their scales and counts fetched
@@ -107,13 +139,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int b = 0; b < 16; b += 2) {
                     double g1, g2;
                     st.step2(xx, g1, g2);
-                    account(g1 * sc[b], hc[b]);
-                    account(g2 * sc[b + 1], hc[b + 1]);
+                    account(g1 * sc[b], hc[b], t * kTileBins + 16 * half + b);
+                    account(g2 * sc[b + 1], hc[b + 1], t * kTileBins + 16 * half + b + 1);
                 }
             }
         } else {
             for (int b = 0; b < nb; ++b)
-                account(st.step() * scal[b], cnt[b]);
+                account(st.step() * scal[b], cnt[b], t * kTileBins + b);
         }
         st.leave_tile(tv.renorm[t]);
     }
@@ -129,18 +161,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if ((dead >> (threadIdx.x & (kWave - 1))) & 1)
         acc_ll = isnan(acc_ll) ? acc_ll : -INFINITY; // h * -inf summed with finite terms
     double ll = acc_ll + tail_term;
-    if (((tiny & ~dead) >> (threadIdx.x & (kWave - 1))) & 1)
-        ll = isfinite(ll) ? redo_marker() : ll; // replaced by K-direct's value before anyone sees it
-    if (!finite)
+    if (!finite) {
         ll = NAN; // a NaN parameter poisons every p_j in the reference
-    if (live)
+        subw = 0;
+    }
+    if (!isfinite(ll))
+        subw = 0; // -inf (or NaN) whatever the handed-back keys are worth
+    if (live) {
         out_ll[pt] = ll;
+        if (subw != 0) // (rare) queue the point for ll_fix_list_kernel
+            sub_list.push(pt + sub_list.index_offset, subw);
+    }
 }
 
 } // namespace
 
 hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSource &src, int64_t n,
-                           double *out_ll, hipStream_t stream)
+                           double *out_ll, const SubList &sub_list, hipStream_t stream)
 {
     if (n <= 0)
         return hipSuccess;
@@ -153,16 +190,18 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
         const int64_t cnt = n - first < per_launch ? n - first : per_launch;
         const dim3 grid((unsigned)((cnt + 255) / 256));
         PointSource part = src;
+        SubList sl = sub_list;
+        sl.index_offset = first;
         if (src.is_grid)
             part.flat_begin = src.flat_begin + first;
         else
             part.params = src.params + first * 2;
         if (m.tail != 0.0)
-            hipLaunchKernelGGL((ll_basic_kernel<8, true>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base,
-                               tv.int_base, part, cnt, out_ll + first);
+            hipLaunchKernelGGL((ll_basic_kernel<8, true>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+                               tv.int_base, part, cnt, out_ll + first, sl);
         else
-            hipLaunchKernelGGL((ll_basic_kernel<8, false>), grid, block, 0, stream, m, tv.n_tiles, tv.dbl_base,
-                               tv.int_base, part, cnt, out_ll + first);
+            hipLaunchKernelGGL((ll_basic_kernel<8, false>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+                               tv.int_base, part, cnt, out_ll + first, sl);
     }
     return hipGetLastError();
 }

@@ -53,6 +53,7 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+
 // One MFMA step of the first N accumulator slots of a wave (they are sorted by length, so the active
 // slots are always a prefix): all A fragments first -- N independent LDS reads in flight -- then per
 // slot the weight b_o (advanced by (1-q)^4, cut off at o >= T: models.py:198-206,239) and the MFMA.
@@ -74,13 +75,13 @@ __device__ __forceinline__ void contract_step(int i, const double *cur, const in
 }
 
 template <int NT, int HU, bool TAIL>
-__global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const int32_t n_tiles,
+__global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                          const double *__restrict__ tile_dbl,
                                                          const int32_t *__restrict__ tile_int,
                                                          const FactoredPlan plan,
-                                                         double *__restrict__ out_ll)
+                                                         double *__restrict__ out_ll, const SubList sub_list)
 {
-    const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
+    const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
     constexpr int NW = NT / kWave;
     constexpr int MU = 2 * HU; // accumulator slots per wave (6: the specialised step loops below assume it)
     static_assert(MU == 6, "contract loops are written for 6 slots");
@@ -88,10 +89,18 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
     __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
     load_log_table(log_tab);
+    // rows handed back (direct_point.h), per accumulator slot and weight vector: first unit, last unit + 1 (0: none;
+    // a unit = the 16 rows of a half tile: index 2 * tile + half).  One writer per entry: the lane with kq == 0.
+    __shared__ unsigned sub_rec[NW * MU * 16 * 2];
+    for (int i = threadIdx.x; i < NW * MU * 16; i += NT) {
+        sub_rec[2 * i] = 0xFFFFFFFFu;
+        sub_rec[2 * i + 1] = 0;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const double p_clamp = plan.p_clamp; // direct_point.h
 
     // ---- the (c, e) of this workgroup ----
     // list mode: workgroup = (unit, key segment); a unit is a point or a chunk of a point's copy numbers, the
@@ -99,8 +108,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int n_seg = plan.list_mode ? plan.n_seg : 1;
     const int unit = plan.list_mode ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
     const int seg = plan.list_mode ? (int)blockIdx.x - unit * n_seg : 0;
-    const int seg_tiles = (n_tiles + n_seg - 1) / n_seg;
-    const int t_begin = seg * seg_tiles, t_end = min(n_tiles, t_begin + seg_tiles);
+    // (the loop below walks ITEMS, tiles.h: a plain tile, or up to 32 all-zero-count tiles summed -- the latter
+    // only exist with a tail; without one item i is tile i)
+    const int seg_items = (n_items + n_seg - 1) / n_seg;
+    const int t_begin = seg * seg_items, t_end = min(n_items, t_begin + seg_items);
     const int64_t ce = plan.ce_begin + unit;
     // (list mode: workgroup i takes point i of a point list -- its own (c, e) AND its own single weight
     // vector, see tiles.h FactoredPlan::list_mode)
@@ -139,7 +150,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU];
     double r4[MU], llacc[MU];
     uint64_t dead[MU]; // lanes that met a p_j <= 0 with h_j != 0
-    uint64_t tiny[MU]; // lanes that met a p_j below the normal range (<= 0 included) with h_j != 0
     CompSum spacc[MU];
     // wave w's block of MU slots in the unit tables
     auto wave_block = [&](int w) -> int {
@@ -166,7 +176,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         r4[k] = plan.q_r4[slot];
         llacc[k] = 0.0;
         dead[k] = 0;
-        tiny[k] = 0;
         spacc[k].hi = 0.0;
         spacc[k].lo = 0.0;
     }
@@ -186,13 +195,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     load_weights();
 
     // ================= phase A: G[key][o] of key tile t into `dst` =================
-    auto build_tile = [&](int t, double *dst) {
+    auto build_tile = [&](int t, bool seg_start, double *dst) __attribute__((always_inline)) {
         if (plan.skip_phases & 1)
             return;
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
         st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                      tv.run_start[t] != 0 || t == t_begin); // (a key segment starts like a run: every stream anchored)
+                      tv.run_start[t] != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         double *colp = dst + (lane_in_row ? tid : 0);
         if (nb == kTileBins) { // the common case: straight-line code, scales in SGPRs
@@ -226,9 +235,60 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         }
         st.leave_tile(tv.renorm[t]);
     };
+    // The same walk over a tile WITHOUT counts (tail != 0 only): sum_j G[o][j] over its keys stays in a register
+    // -- 32 terms of one sign added plainly, the compensated accumulator of phase C gets their contraction --
+    // and is returned instead of 32 stores.
+    auto build_tile_sum = [&](int t, bool seg_start) __attribute__((always_inline)) -> double {
+        const double k0 = tv.first_key[t];
+        const int nb = tv.n_bins[t];
+        st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t], tv.run_start[t] != 0 || seg_start);
+        const double *scal = tv.scal + (int64_t)t * kTileBins;
+        double gsum = 0.0;
+        if (nb == kTileBins) {
+            double xx[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                double xs = st.x[s];
+                asm volatile("" : "+v"(xs));
+                xx[s] = xs * xs;
+            }
+#pragma unroll
+            for (int b = 0; b < kTileBins; b += 2) {
+                double g1, g2;
+                st.step2(xx, g1, g2);
+                gsum = fma(g1, scal[b], gsum);
+                gsum = fma(g2, scal[b + 1], gsum);
+            }
+        } else {
+            for (int b = 0; b < nb; ++b)
+                gsum = fma(st.step(), scal[b], gsum);
+        }
+        st.leave_tile(tv.renorm[t]);
+        return gsum;
+    };
+    // One item into `dst`: a plain tile, or (TAIL) the per-tile sums of up to 32 count-less tiles as its rows.
+    auto build_item = [&](int it, double *dst) __attribute__((always_inline)) {
+        const int first = TAIL ? __builtin_amdgcn_readfirstlane(tv.item_first[it]) : it;
+        if (TAIL && tv.item_sum[it] != 0) {
+            if (plan.skip_phases & 1)
+                return;
+            const int n = __builtin_amdgcn_readfirstlane(tv.item_ntiles[it]);
+            double *colp = dst + (lane_in_row ? tid : 0);
+            for (int r = 0; r < n; ++r) {
+                const double gsum = build_tile_sum(first + r, it == t_begin && r == 0);
+                if (lane_in_row)
+                    colp[r * LD] = gsum;
+            }
+            for (int r = n; r < kTileBins; ++r)
+                if (lane_in_row)
+                    colp[r * LD] = 0.0;
+        } else {
+            build_tile(first, it == t_begin, dst);
+        }
+    };
 
     // in-kernel stamps (diagnostic runs only): cycles per wave in build / contract / log / barrier
-    long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0;
+    long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0, dg_cold = 0, dg_units = 0;
     const bool diag = plan.diag != nullptr;
 #define STAMP(acc)                                    \
     if (diag) {                                       \
@@ -244,17 +304,17 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const bool dbuf = plan.n_buf == 2;
     if (dbuf && t_begin < t_end) {
         if (wave_builds)
-            build_tile(t_begin, Gs + (t_begin & 1) * kTileBins * LD);
+            build_item(t_begin, Gs + (t_begin & 1) * kTileBins * LD);
         __syncthreads();
     }
     for (int t = t_begin; t < t_end; ++t) {
         const double *cur = Gs + (dbuf ? (t & 1) * kTileBins * LD : 0);
         if (!dbuf) {
             if (wave_builds)
-                build_tile(t, Gs);
+                build_item(t, Gs);
             __syncthreads();
         } else if (wave_builds && t + 1 < t_end) {
-            build_tile(t + 1, Gs + ((t + 1) & 1) * kTileBins * LD);
+            build_item(t + 1, Gs + ((t + 1) & 1) * kTileBins * LD);
         }
         STAMP(dg_a)
 
@@ -266,7 +326,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int bin = 16 * u + kq + 4 * r;
-                hrow[u][r] = tv.cnt[(int64_t)t * kTileBins + bin];
+                hrow[u][r] = tv.item_cnt[(int64_t)t * kTileBins + bin];
             }
         d4 acc[MU];
         // the piece's first step (weights wfirst/wrun were fetched during the previous tile's logs)
@@ -304,6 +364,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 
         STAMP(dg_b)
         // ================= phase C: h_j * log p_j from the accumulators =================
+        const bool item_is_sum = TAIL && tv.item_sum[t] != 0; // wave-uniform
         // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
@@ -311,27 +372,67 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 if (qslot[k] >= 0 && !cont[k] && col == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        plan.partial[(ce * tv.n_tiles + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] =
+                        plan.partial[(ce * tv.n_items + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] =
                             acc[k][r];
                 }
                 continue;
             }
+            if (TAIL && item_is_sum) { // rows are sums over count-less tiles: they only enter sp_j
+                if (qslot[k] >= 0 && !cont[k]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        spacc[k].add(acc[k][r]);
+                }
+                continue;
+            }
             if (qslot[k] >= 0 && !cont[k] && !(plan.skip_phases & 4)) { // wave-uniform: first slot of a unit
+                // Everything out of the ordinary -- p_j <= 0, or deep in the subnormal range (below p_clamp,
+                // direct_point.h), at a key with h_j != 0 -- is caught by ONE compare per row, made BEFORE the logs
+                // (the accumulators are not kept alive for it), and sorted out in a branch the wave takes for one
+                // unit in twenty.  Filler and padding keys have h == 0 (`if h`, covest/models.py:106) and add
+                // 0 * log below.
+                uint64_t any_low = 0;
+                if (diag)
+                    dg_units += 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
+                    any_low |= __ballot(acc[k][r] < p_clamp && h != 0.0);
+                }
+                if (__builtin_expect((any_low & ~dead[k]) != 0, 0)) { // wave-uniform, cold (a lane that is dead already
+                                                                      // has nothing more to report)
+                    uint64_t subm = 0;
+                    if (diag)
+                        dg_cold += 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
+                        const double p = acc[k][r];
+                        // utils.safe_log: p_j <= 0 with h_j != 0 makes the sum -inf; kept as a lane mask in SGPRs
+                        dead[k] |= __ballot(p <= 0.0 && h != 0.0);
+                        subm |= __ballot(p > 0.0 && p < p_clamp && h != 0.0);
+                    }
+                    // p_j DEEP IN THE SUBNORMAL RANGE: the unit (this half tile) is recorded for every weight vector
+                    // (column) concerned -- first and last unit met; one writer per entry, the lane of row group 0.
+                    // The strict evaluation of its counted rows follows in ll_fix_list_kernel (argmin.hip)
+                    const uint64_t cm = (subm | (subm >> 16) | (subm >> 32) | (subm >> 48)) & 0xFFFFull;
+                    if (kq == 0 && ((cm >> col) & 1)) {
+                        const unsigned u = 2u * (unsigned)(TAIL ? tv.item_first[t] : t) + (unsigned)uhalf[k];
+                        unsigned *rec = &sub_rec[((wave * MU + k) * 16 + col) * 2];
+                        rec[0] = min(rec[0], u);
+                        rec[1] = max(rec[1], u + 1);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
                     const double p = acc[k][r];
                     if (TAIL)
                         spacc[k].add(p); // (filler and padding keys: p == 0)
-                    // No branch on h (it differs between the lanes' rows): the four logs of a unit are
-                    // straight-line code and interleave.  Filler and padding keys have h == 0 (`if h`,
-                    // covest/models.py:106) and add 0 * log p -- fast_log(0) is finite.  utils.safe_log:
-                    // p_j <= 0 with h_j != 0 makes the sum -inf; kept as a lane mask in SGPRs.
-                    dead[k] |= __ballot(p <= 0.0 && h != 0.0);
-                    // a SUBNORMAL p_j: the reference's value hangs on the rounding of every single term onto
-                    // the 4.9e-324 grid -- such a point is handed to the strict kernel
-                    tiny[k] |= __ballot(p < kMinNormal && h != 0.0);
-                    llacc[k] = fma(h, fast_log(p, log_tab), llacc[k]);
+                    // no branch on h (it differs between the lanes' rows): the four logs of a unit are straight-line
+                    // code and interleave.  log(max(p_j, p_clamp)): what a p_j deep in the subnormal range contributes
+                    // is then a known constant, which the strict evaluation of that key replaces (direct_point.h)
+                    llacc[k] = fma(h, fast_log(fmax(p, p_clamp), log_tab), llacc[k]);
                 }
                 __builtin_amdgcn_sched_barrier(0); // ... one unit at a time: registers
             }
@@ -348,6 +449,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         d[2] = dg_c;
         d[3] = dg_w;
         d[4] = dg_b0;
+        d[5] = dg_cold;
+        d[6] = dg_units;
     }
 #undef STAMP
     if (plan.list_mode == 2)
@@ -357,7 +460,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     double *part_ll = Gs;                               // [NW][MU][16]
     double *part_hi = Gs + (size_t)NW * MU * 16; // compensated sp_j parts
     double *part_lo = part_hi + (size_t)NW * MU * 16;
-    double *part_sub = part_lo + (size_t)NW * MU * 16; // > 0: a subnormal p_j with weight was met (and no p_j <= 0)
 #pragma unroll
     for (int k = 0; k < MU; ++k) {
         double ll = llacc[k];
@@ -365,9 +467,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             ll = isnan(ll) ? ll : -INFINITY; // h * -inf summed with finite terms
         ll += __shfl_xor(ll, 16, kWave);
         ll += __shfl_xor(ll, 32, kWave);
-        double sub = ((tiny[k] & ~dead[k]) >> lane) & 1 ? 1.0 : 0.0;
-        sub += __shfl_xor(sub, 16, kWave);
-        sub += __shfl_xor(sub, 32, kWave);
         CompSum sp = spacc[k];
         if (TAIL) {
 #pragma unroll
@@ -382,7 +481,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         if (lane < 16) {
             const int at = (wave * MU + k) * 16 + lane;
             part_ll[at] = ll;
-            part_sub[at] = sub;
             if (TAIL) {
                 part_hi[at] = sp.hi;
                 part_lo[at] = sp.lo;
@@ -407,7 +505,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
             }
         const double ll = part_ll[e] + (pe >= 0 ? part_ll[pe] : 0.0);
-        const bool sub = part_sub[e] + (pe >= 0 ? part_sub[pe] : 0.0) > 0.0;
+        // the units handed back for this weight vector: this half-0 slot's record and its half-1 partner's
+        unsigned u_first = sub_rec[2 * e], u_end = sub_rec[2 * e + 1];
+        if (pe >= 0) {
+            u_first = min(u_first, sub_rec[2 * pe]);
+            u_end = max(u_end, sub_rec[2 * pe + 1]);
+        }
+        const unsigned long long word = u_end ? sub_word(u_first, u_end - 1, true) : 0ull;
         double tail_term = 0.0;
         double hi = 0.0, lo = 0.0;
         if (TAIL) {
@@ -421,10 +525,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         }
         if (plan.list_mode == 1) { // a key segment of a point: {LL part, sp_j part (hi, lo)}; the host adds the segments
             if (plan.q_orig[qt * 16 + c] >= 0) {
-                double *o = plan.partial + ((int64_t)ce * n_seg + seg) * 3;
-                o[0] = !finite ? NAN : (sub && isfinite(ll)) ? redo_marker() : ll;
+                double *o = plan.partial + ((int64_t)ce * n_seg + seg) * 4;
+                o[0] = finite ? ll : NAN;
                 o[1] = hi;
                 o[2] = lo;
+                o[3] = __longlong_as_double((long long)(finite ? word : 0ull)); // (bits; the host merges the segments' words)
             }
             continue;
         }
@@ -439,41 +544,62 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         if (qo >= 0) {
             const int64_t flat = ce * plan.n_q + qo;
             if (flat >= plan.flat_begin && flat < plan.flat_end) {
-                double v = ll + tail_term;
-                if (sub && isfinite(v))
-                    v = redo_marker(); // replaced by K-direct's value in the arg-min pass (argmin.hip)
-                out_ll[flat - plan.flat_begin] = finite ? v : NAN;
+                const double v = finite ? ll + tail_term : NAN;
+                out_ll[flat - plan.flat_begin] = v;
+                if (word != 0 && isfinite(v)) // (rare; -inf stays -inf whatever the keys are worth)
+                    sub_list.push(flat - plan.flat_begin, word);
             }
         }
     }
 }
 
 // Chunked point list (tiles.h list_mode 2): one wave per point adds the chunks' shares of p_j in chunk order
-// and takes the logs.  LL = sum_j h_j log p_j + tail log(1 - sp), covest/models.py:100-107.
-__global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, const int32_t n_tiles,
+// and takes the logs.  LL = sum_j h_j log p_j + tail log(1 - sp), covest/models.py:100-107.  A subnormal p_j at a
+// key with h_j != 0 is replaced on the spot by its strict evaluation (direct_point.h: the whole wave, K-direct's
+// arithmetic).  point_par[5 n_points], point_T[n_points]: the points' parameters and threshold_o.
+__global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                            const double *__restrict__ tile_dbl,
                                                            const int32_t *__restrict__ tile_int,
                                                            const double *__restrict__ partial,
                                                            const int32_t *__restrict__ first_item,
-                                                           const double *__restrict__ point_ce, double *__restrict__ out_ll)
+                                                           const double *__restrict__ point_par,
+                                                           const int32_t *__restrict__ point_T, double *__restrict__ out_ll)
 {
-    const TileView tv = tile_view_from(n_tiles, tile_dbl, tile_int);
+    const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
     const int p = blockIdx.x, lane = threadIdx.x;
     const int c0 = first_item[p], c1 = first_item[p + 1];
-    const int64_t n_keys = (int64_t)n_tiles * kTileBins;
+    const int64_t n_keys = (int64_t)n_items * kTileBins; // rows of the items: keys, or per-tile sums (tiles.h)
+    double par[kMaxParams];
+#pragma unroll
+    for (int d = 0; d < kMaxParams; ++d)
+        par[d] = point_par[(int64_t)p * kMaxParams + d];
+    clamp_point<5>(m, par);
+    const int T = point_T[p];
     double ll = 0.0;
-    bool dead = false, sub = false, poisoned = false;
+    bool dead = false, poisoned = false;
     CompSum sp = {0.0, 0.0};
-    for (int64_t key = lane; key < n_keys; key += kWave) {
+    for (int64_t base = 0; base < n_keys; base += kWave) { // wave-uniform trip count
+        const int64_t key = base + lane;
+        const bool valid = key < n_keys;
         double pj = 0.0;
         for (int c = c0; c < c1; ++c)
-            pj += partial[(int64_t)c * n_keys + key];
-        const double h = tv.cnt[key];
+            pj += valid ? partial[(int64_t)c * n_keys + key] : 0.0;
+        const double h = valid ? tv.item_cnt[key] : 0.0;
+        uint64_t sub = __ballot(h != 0.0 && pj > 0.0 && pj < 2.2250738585072014e-308); // a subnormal p_j
+        while (sub) { // wave-uniform, rare
+            const int who = __builtin_ctzll(sub);
+            sub &= sub - 1;
+            const int64_t row = base + who;
+            const int item = (int)(row / kTileBins);
+            const int bin = tv.row_bin[(int64_t)tv.item_first[item] * kTileBins + (row - (int64_t)item * kTileBins)];
+            const double strict = strict_pj_wave<5>(m, par, T, m.bins.key[bin], -m.bins.lgam[bin]);
+            if (lane == who)
+                pj = strict;
+        }
         if (m.tail != 0.0)
             sp.add(pj);
         if (h != 0.0) {
             dead |= pj <= 0.0; // utils.safe_log
-            sub |= pj > 0.0 && pj < kMinNormal; // see ll_factored_kernel, phase C
             poisoned |= pj != pj; // a NaN parameter: NaN, as in the reference (math.log(nan))
             ll = fma(h, log(pj > 0.0 ? pj : 1.0), ll);
         }
@@ -489,11 +615,7 @@ __global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, co
     }
     if (__ballot(dead))
         ll = isnan(ll) ? ll : -INFINITY;
-    double par[kMaxParams] = {point_ce[2 * p], point_ce[2 * p + 1], 0, 0, 0};
-    clamp_point<2>(m, par);
     double v = ll + tail_term;
-    if (__ballot(sub) && isfinite(v))
-        v = redo_marker();
     if (__ballot(poisoned) || !(isfinite(par[0]) && isfinite(par[1])))
         v = NAN;
     if (lane == 0)
@@ -502,12 +624,12 @@ __global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, co
 
 template <int NT, int HU, bool TAIL>
 hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
-                          double *out_ll, hipStream_t stream)
+                          double *out_ll, const SubList &sub_list, hipStream_t stream)
 {
     // + 64 zeroed doubles: the last piece of a unit may run a few (masked, weight 0) steps past the end
     // of a G row; what it reads there must be finite
-    // (the per-q combine at the end reuses the buffer for four [waves][slots][16] arrays)
-    const size_t lds = std::max((size_t)plan.n_buf * kTileBins * plan.ld + 64, (size_t)4 * (NT / kWave) * 2 * HU * 16) *
+    // (the per-q combine at the end reuses the buffer for three [waves][slots][16] arrays)
+    const size_t lds = std::max((size_t)plan.n_buf * kTileBins * plan.ld + 64, (size_t)3 * (NT / kWave) * 2 * HU * 16) *
                        sizeof(double);
     // the dynamic-LDS ceiling is a per-device attribute of the kernel: raise it once per device
     static size_t configured[64] = {0};
@@ -531,44 +653,44 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
         part.ce_end = std::min(plan.ce_end, first + per_launch);
         const dim3 grid((unsigned)((part.ce_end - part.ce_begin) * (plan.list_mode ? plan.n_seg : 1)),
                         (unsigned)plan.n_qblocks);
-        hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles,
-                           tv.dbl_base, tv.int_base, part, out_ll);
+        hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.n_items,
+                           tv.dbl_base, tv.int_base, part, out_ll, sub_list);
     }
     return hipGetLastError();
 }
 
 template <int NT, int HU>
 hipError_t launch_nt(const DevModel &m, const TileView &tv, const FactoredPlan &plan, double *out_ll,
-                     hipStream_t stream)
+                     const SubList &sub_list, hipStream_t stream)
 {
-    return m.tail != 0.0 ? launch_nt_tail<NT, HU, true>(m, tv, plan, out_ll, stream)
-                         : launch_nt_tail<NT, HU, false>(m, tv, plan, out_ll, stream);
+    return m.tail != 0.0 ? launch_nt_tail<NT, HU, true>(m, tv, plan, out_ll, sub_list, stream)
+                         : launch_nt_tail<NT, HU, false>(m, tv, plan, out_ll, sub_list, stream);
 }
 
 } // namespace
 
 hipError_t launch_ll_finish_partials(const DevModel &m, const TileView &tv, const double *partial,
-                                     const int32_t *first_item, const double *point_ce, int64_t n_points,
-                                     double *out_ll, hipStream_t stream)
+                                     const int32_t *first_item, const double *point_par, const int32_t *point_T,
+                                     int64_t n_points, double *out_ll, hipStream_t stream)
 {
     if (n_points <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(ll_finish_partials, dim3((unsigned)n_points), dim3(kWave), 0, stream, m, tv.n_tiles, tv.dbl_base,
-                       tv.int_base, partial, first_item, point_ce, out_ll);
+    hipLaunchKernelGGL(ll_finish_partials, dim3((unsigned)n_points), dim3(kWave), 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+                       tv.int_base, partial, first_item, point_par, point_T, out_ll);
     return hipGetLastError();
 }
 
 hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
-                              double *out_ll, hipStream_t stream)
+                              double *out_ll, const SubList &sub_list, hipStream_t stream)
 {
     if (plan.ce_end <= plan.ce_begin)
         return hipSuccess;
     if (m.n_err != 8 || m.kind != 1 || plan.max_o > plan.n_threads)
         return hipErrorInvalidValue;
     if (plan.n_threads == 256 && plan.half_units == 3)
-        return launch_nt<256, 3>(m, tv, plan, out_ll, stream);
+        return launch_nt<256, 3>(m, tv, plan, out_ll, sub_list, stream);
     if (plan.n_threads == 512 && plan.half_units == 3)
-        return launch_nt<512, 3>(m, tv, plan, out_ll, stream);
+        return launch_nt<512, 3>(m, tv, plan, out_ll, sub_list, stream);
     return hipErrorInvalidValue;
 }
 

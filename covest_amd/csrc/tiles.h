@@ -14,9 +14,17 @@ constexpr double kWindowLn = -760.0; // terms below e^-760 are 0 in double
 // Tiles of <= 32 consecutive keys over the evaluated bins (built on the host,
 // capi.cpp: build_tiles).  All arrays live in one device buffer; everything
 // indexed by tile is wave-uniform and read through the scalar cache.
+//
+// ITEMS: what a kernel walks is a list of items, each one LDS buffer's worth of K-factored's phases B/C.  A
+// "plain" item is one tile.  A "sum" item stands for up to 32 consecutive tiles whose counts are ALL zero
+// (they exist only when tail != 0: then every key enters sp_j, covest/models.py:103, and a trimmed histogram
+// is mostly such keys): none of their keys takes a log, only the sum of their p_j is needed, and
+// sum_j sum_o b_o G[o][j] = sum_o b_o (sum_j G[o][j]) -- so the builders add G over a tile's keys in registers
+// and the item's 32 rows are those per-tile sums: one contraction and no log for 1024 keys.
 struct TileView {
     int32_t n_tiles;
-    // raw buffers behind the views below: [4*nt + 2*nt*32] doubles, [2*nt] int32.  The fast
+    int32_t n_items;
+    // raw buffers behind the views below: [4*nt + 2*nt*32 + ni*32] doubles, [3*nt + 3*ni + 32*nt] int32.  The fast
     // kernels take these two as separate `const __restrict__` kernel arguments and rebuild the
     // view from them (tile_view_from): only then does hipcc know the table is read-only and
     // never aliased, and fetches the wave-uniform entries with s_load into SGPRs.
@@ -25,19 +33,27 @@ struct TileView {
     const double *first_key;   // [n_tiles] k0 as a double
     const int32_t *n_bins;     // [n_tiles] keys in the tile (1..32)
     const int32_t *run_start;  // [n_tiles] 1: keys are not contiguous with the previous tile -> re-anchor
+    const int32_t *all_zero;   // [n_tiles] 1: every count of the tile is 0 (its keys only enter sp_j: tail != 0)
     const double *lgam_prev;   // [n_tiles] lgamma(k0)       = ln (k0-1)!
     const double *lgam_last;   // [n_tiles] lgamma(k0 + nb)  = ln (k0+nb-1)!
     const double *renorm;      // [n_tiles] (k0-1)! / (k0+nb-1)!   carries v into the next tile
     const double *scal;        // [n_tiles][32] 2^-SC (k0-1)!/(k0+b)!; 0 for filler keys (gaps of the histogram the
                                //   recurrence walks through) and padding: their p_j is exactly 0, so they add nothing to sp_j
     const double *cnt;         // [n_tiles][32] h_j (0 for padding and filler keys)
+    const double *item_cnt;    // [n_items][32] the counts of an item's 32 rows: its tile's for a plain item, 0 for a sum item
+    const int32_t *item_first; // [n_items] first tile of the item
+    const int32_t *item_ntiles; // [n_items] 1 for a plain item, 1..32 (rows in use) for a sum item
+    const int32_t *item_sum;   // [n_items] 1 = sum item
+    const int32_t *row_bin;    // [n_tiles][32] index of the row's key in DevModel::bins (-1: filler / padding): how a
+                               //   recurrence kernel names a key it hands back (direct_point.h)
 };
 
 // The layout of capi.cpp: build_tiles.
-inline __host__ __device__ TileView tile_view_from(int32_t nt, const double *dbl, const int32_t *ints)
+inline __host__ __device__ TileView tile_view_from(int32_t nt, int32_t ni, const double *dbl, const int32_t *ints)
 {
     TileView tv;
     tv.n_tiles = nt;
+    tv.n_items = ni;
     tv.dbl_base = dbl;
     tv.int_base = ints;
     tv.first_key = dbl;
@@ -46,8 +62,14 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, const double *dbl
     tv.renorm = dbl + 3 * (int64_t)nt;
     tv.scal = dbl + 4 * (int64_t)nt;
     tv.cnt = tv.scal + (int64_t)nt * kTileBins;
+    tv.item_cnt = tv.cnt + (int64_t)nt * kTileBins;
     tv.n_bins = ints;
     tv.run_start = ints + nt;
+    tv.all_zero = ints + 2 * (int64_t)nt;
+    tv.item_first = ints + 3 * (int64_t)nt;
+    tv.item_ntiles = tv.item_first + ni;
+    tv.item_sum = tv.item_ntiles + ni;
+    tv.row_bin = tv.item_sum + ni;
     return tv;
 }
 
@@ -106,6 +128,7 @@ struct FactoredPlan {
                                    //   point's copy numbers, o = item_obase[i] + 1 .. + 512 (threshold_o beyond one
                                    //   workgroup's lanes); the workgroup stores its share of p_j to `partial` and
                                    //   ll_finish_partials adds the chunks and takes the logs
+    double p_clamp;                // (S + max threshold_o) * 7e-317: below it a p_j is handed back (direct_point.h)
     int32_t n_seg;                 // list modes: key tiles are cut into n_seg contiguous segments, workgroup
                                    //   blockIdx.x = unit * n_seg + segment (unit = point or chunk); a segment starts
                                    //   like a run (streams anchored).  list_mode 1 then writes {LL part, sp part hi, lo}

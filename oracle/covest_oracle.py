@@ -19,7 +19,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libcovest_oracle.so")
+# COVEST_ORACLE_LIB: another build of the same source, e.g. the sanitizer build `make -C oracle
+# libcovest_oracle_asan.so` (tests/test_oracle_sanitizers.py); it is loaded as is, never rebuilt here
+_LIB_PATH = os.environ.get("COVEST_ORACLE_LIB") or os.path.join(_HERE, "libcovest_oracle.so")
 _MAX_PARAMS = 5
 
 
@@ -44,6 +46,8 @@ class _OracleModelStruct(ctypes.Structure):
 def build(force=False):
     """Compile the C restatement (gcc, seconds).  Building the checker is not using it."""
     src = os.path.join(_HERE, "covest_oracle.c")
+    if os.environ.get("COVEST_ORACLE_LIB"):
+        return _LIB_PATH
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
         return _LIB_PATH

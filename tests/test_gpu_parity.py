@@ -523,6 +523,33 @@ def test_estimator_fix_and_err_scale_on_gpu(hip_lib, oracle):
     assert rel_err(plain.likelihood_f(res1), final["value"]) <= 1e-6
 
 
+def test_reference_overflow_is_flagged(hip_lib, oracle):
+    """The documented divergence: beyond ln(l^i / i!) = 11356.5 the reference's long-double
+    pmf product is inf before it is scaled (c_src/covest_poissonmodule.c:19-24) and its likelihood +inf or NaN; the
+    kernels return the finite value.  covest_reference_overflow must mark exactly the points where the faithful
+    oracle -- bit-equal to the reference's extension, tests/test_oracle_vs_ref.py -- stops being finite that way."""
+    from covest_amd import BasicModel, RepeatsModel
+    hist = {1: 5, 2: 3, 10000: 2}
+    m = BasicModel(21, 100, hist, 0, max_error=8)
+    om = oracle.OracleModel("basic", 21, 100, hist, 0, max_error=8)
+    pts = np.array([(c, 0.001) for c in np.linspace(14300.0, 14900.0, 25)])
+    ref = om.compute_loglikelihood_many(pts, n_threads=16)
+    want = np.array([v == math.inf or v != v for v in ref])
+    assert want.any() and not want.all()
+    assert np.array_equal(m.reference_overflows(pts), want)
+    got = m.loglikelihood_points(pts)
+    assert np.all(np.isfinite(got[want]))  # the finite value the formula defines
+    _check(got[~want], ref[~want], "below the overflow boundary")
+    # repeats model: the copy number multiplies the rate, so the boundary moves with threshold_o
+    rm = RepeatsModel(21, 100, hist, 0, max_error=8)
+    orm = oracle.OracleModel("repeats", 21, 100, hist, 0, max_error=8)
+    rp = np.array([(c, 0.001, 0.5, 0.5, q) for c in (300.0, 700.0, 1500.0) for q in (0.9, 0.5, 0.3, 0.2)])
+    rref = orm.compute_loglikelihood_many(rp, n_threads=16)
+    rwant = np.array([v == math.inf or v != v for v in rref])
+    assert rwant.any() and not rwant.all()
+    assert np.array_equal(rm.reference_overflows(rp), rwant)
+
+
 def test_block_partition_equals_whole_grid(hip_lib):
     """Multi-GPU block partition on one device: evaluating the
     blocks of a partition separately gives the same values and the same winner."""

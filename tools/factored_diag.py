@@ -22,7 +22,11 @@ n = L.covest_grid_diag(g._handle, None, 0)
 buf = np.zeros(n, dtype=np.int64)
 L.covest_grid_diag(g._handle, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n)
 d = buf.reshape(-1, 8, 8)[:, :, :4].astype(np.float64)  # [wg][wave][build, contract, log, barrier]
-print("workgroups", d.shape[0])
+extra = buf.reshape(-1, 8, 8)
+print("workgroups", d.shape[0], "units logged per wave %.1f, of which through the cold branch %.1f" % (
+    extra[:, :, 6].mean(), extra[:, :, 5].mean()))
+for w in range(8):
+    print("  wave %d: units %.1f cold %.1f" % (w, extra[:, w, 6].mean(), extra[:, w, 5].mean()))
 tot = d.sum(axis=2)
 print("mean cycles per wave (s_memtime ticks): total %.0f" % tot.mean())
 for w in range(8):
