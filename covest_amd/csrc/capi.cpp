@@ -355,6 +355,7 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     // items (tiles.h): runs of all-zero-count tiles (they exist only with a tail) are grouped, up to 32 per item
     std::vector<int32_t> item_first, item_ntiles, item_sum;
     std::vector<double> item_cnt;
+    const bool no_sum_items = std::getenv("COVEST_NO_SUM_ITEMS") != nullptr; // diagnostic: every tile a plain item
     for (size_t t = 0; t < nt;) {
         auto all_zero = [&](size_t tt) {
             for (int b = 0; b < kTileBins; ++b)
@@ -362,7 +363,7 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
                     return false;
             return true;
         };
-        if (!all_zero(t)) {
+        if (!all_zero(t) || no_sum_items) {
             item_first.push_back((int32_t)t);
             item_ntiles.push_back(1);
             item_sum.push_back(0);

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     };
 
     // in-kernel stamps (diagnostic runs only): cycles per wave in build / contract / log / barrier
-    long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0, dg_cold = 0, dg_units = 0;
+    long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0;
     const bool diag = plan.diag != nullptr;
 #define STAMP(acc)                                    \
     if (diag) {                                       \
@@ -391,27 +391,29 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 // (the accumulators are not kept alive for it), and sorted out in a branch the wave takes for one
                 // unit in twenty.  Filler and padding keys have h == 0 (`if h`, covest/models.py:106) and add
                 // 0 * log below.
-                uint64_t any_low = 0;
-                if (diag)
-                    dg_units += 1;
+                uint64_t low[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
-                    any_low |= __ballot(acc[k][r] < p_clamp && h != 0.0);
+                    low[r] = __ballot(acc[k][r] < p_clamp && h != 0.0);
                 }
-                if (__builtin_expect((any_low & ~dead[k]) != 0, 0)) { // wave-uniform, cold (a lane that is dead already
-                                                                      // has nothing more to report)
-                    uint64_t subm = 0;
-                    if (diag)
-                        dg_cold += 1;
+                if (__builtin_expect(((low[0] | low[1] | low[2] | low[3]) & ~dead[k]) != 0, 0)) {
+                    // wave-uniform, cold (a lane that is dead already has nothing more to report).  Kept SHORT: a
+                    // wave in here holds up its whole workgroup at the tile's barrier, and each of its vector
+                    // instructions queues behind the partner wave's MFMAs
+                    __builtin_amdgcn_s_setprio(3);
+                    uint64_t subm = 0, zero = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
-                        const double p = acc[k][r];
-                        // utils.safe_log: p_j <= 0 with h_j != 0 makes the sum -inf; kept as a lane mask in SGPRs
-                        dead[k] |= __ballot(p <= 0.0 && h != 0.0);
-                        subm |= __ballot(p > 0.0 && p < p_clamp && h != 0.0);
+                        const uint64_t z = __ballot(acc[k][r] <= 0.0) & low[r];
+                        zero |= z;
+                        subm |= low[r] & ~z;
                     }
+                    // utils.safe_log: p_j <= 0 with h_j != 0 makes the sum -inf; kept as a lane mask in SGPRs -- for
+                    // all four row groups of the weight vector (column) at once: its sum is -inf whichever of them
+                    // met the zero, and the other three need not come through here for it
+                    const uint64_t zc = (zero | (zero >> 16) | (zero >> 32) | (zero >> 48)) & 0xFFFFull;
+                    dead[k] |= zc * 0x0001000100010001ull;
                     // p_j DEEP IN THE SUBNORMAL RANGE: the unit (this half tile) is recorded for every weight vector
                     // (column) concerned -- first and last unit met; one writer per entry, the lane of row group 0.
                     // The strict evaluation of its counted rows follows in ll_fix_list_kernel (argmin.hip)
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                         rec[0] = min(rec[0], u);
                         rec[1] = max(rec[1], u + 1);
                     }
+                    __builtin_amdgcn_s_setprio(0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -449,8 +452,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         d[2] = dg_c;
         d[3] = dg_w;
         d[4] = dg_b0;
-        d[5] = dg_cold;
-        d[6] = dg_units;
     }
 #undef STAMP
     if (plan.list_mode == 2)

@@ -107,7 +107,15 @@ struct StreamSet {
             const double lx = an.lx(s), c = an.c(s);
             const double a0 = fma(km1, lx, c - lgam_prev);
             const double a1 = fma(klast, lx, c - lgam_last);
-            const bool need = run_start ? true : (v[s] == 0.0 && fmax(a0, a1) > kWindowLn);
+            // A stream is on only inside the window.  (At a run start every stream used to be anchored whatever a0
+            // was: for a0 + ln 2^SC in (-745, -708) -- o * lambda_s between about 1083 and 1119 at key 0 -- the
+            // anchor was a SUBNORMAL double, a handful of significant bits carried along by every later multiply;
+            // below -745 it was 0 and the stream re-entered correctly.  Found by the C3 fixture with a tail:
+            // sp_j off by 2e-10 where those streams have their mass.)
+            const bool in_window = fmax(a0, a1) > kWindowLn;
+            const bool need = run_start ? in_window : (v[s] == 0.0 && in_window);
+            if (run_start)
+                v[s] = 0.0; // what is left of the run before means nothing here
             if (__any(need)) {
                 // 2^SC is applied exactly (v_ldexp_f64) wherever exp(a0) itself is a normal
                 // double: folding ln 2^SC = 374.3 into the argument would cost its ulp

@@ -448,6 +448,45 @@ def test_edge_cases(hip_lib, oracle):
     assert m.compute_loglikelihood(1.0, 0.01) == -math.inf
 
 
+def test_streams_that_start_below_the_window(hip_lib, oracle):
+    """Regression (found by the C3 fixture with a tail): a stream whose rate o * lambda_s is about 1083 ... 1119 starts
+    a run of keys with a term of e^-1100 -- outside the recurrence's window.  Round 1 anchored it there all the same,
+    as a SUBNORMAL double (a handful of significant bits) that every later key inherited: p_j wrong by up to a per
+    cent exactly where such a stream has its mass.  A histogram counted around key 1100 and rates swept through that
+    band, basic model (the stream IS the likelihood) and repeats model, against the oracle."""
+    from covest_amd import BasicModel, DenseGrid, RepeatsModel
+    rng = np.random.default_rng(11)
+    hist = {j: int(v) for j, v in zip(range(1, 1301), np.zeros(1300))}
+    for j in range(950, 1251):
+        hist[j] = int(1000 * math.exp(-0.5 * ((j - 1100) / 33.0) ** 2) * 40) + int(rng.integers(0, 3))
+    hist = {j: v for j, v in hist.items() if v or j % 7 == 0}  # (some zero-count keys stay: they matter with a tail)
+    # lambda_0 = c * 0.8 * (1 - e)^21: c such that it sweeps 1070 ... 1130 at e = 0.01
+    cs = np.linspace(1070.0, 1130.0, 41) / (0.8 * 0.99 ** 21)
+    for tail in (0, 500):
+        m = BasicModel(21, 100, hist, tail, max_error=8)
+        om = oracle.OracleModel("basic", 21, 100, hist, tail, max_error=8)
+        pts = np.array([(c, 0.01) for c in cs])
+        ref = om.compute_loglikelihood_many(pts, n_threads=16)
+        assert np.all(np.isfinite(ref))
+        slack = _tail_noise(om, pts, ref, tail)
+        _slack_budget("window start basic tail=%d" % tail, slack)
+        for kernel in ("direct", "recur"):
+            _check(m.loglikelihood_points(pts, kernel=kernel), ref, "window start basic %s tail=%d" % (kernel, tail),
+                   slack=slack)
+        # repeats: copy numbers 1 .. 8 of a rate eight times smaller put o * lambda_0 = 1100 at o = 8
+        rm = RepeatsModel(21, 100, hist, tail, max_error=8)
+        orm = oracle.OracleModel("repeats", 21, 100, hist, tail, max_error=8)
+        axes = [cs[::4] / 8.0, [0.01], [0.4], [0.3], [0.05, 0.3]]
+        grid = DenseGrid(rm, axes)
+        gp = np.array([grid.point(i) for i in range(grid.total)])
+        gref = orm.compute_loglikelihood_many(gp, n_threads=16)
+        gslack = _tail_noise(orm, gp, gref, tail)
+        _slack_budget("window start repeats tail=%d" % tail, gslack)
+        for kernel in ("direct", "factored"):
+            grid.evaluate(kernel=kernel)
+            _check(grid.loglikelihoods(), gref, "window start repeats %s tail=%d" % (kernel, tail), slack=gslack)
+
+
 def test_subnormal_pj_goes_to_the_strict_kernel(hip_lib, oracle):
     """A key that was observed 6000 times and to which the model gives a SUBNORMAL probability (1e-323 ... 1e-309:
     one or a few steps of the 4.9e-324 grid): the reference's value there hangs on the rounding of every single
