@@ -20,9 +20,14 @@ quoted on (repeat model, 10k-bin histogram):
   c5  (next row F1) canonical 21-mer histogram of synthetic reads, --kmer-gbp gigabases
   f2  (next row F2) the `-sp 20` L-BFGS-B multi-start refinement of the repeats model on H10k_rep
   f3  (next row F3) histogram down-sampling (K-thin) of H10k_rep by a factor of 2
-Weak scaling: with N ranks the c axis has N times as many values over the same
+Weak scaling (default): with N ranks the c axis has N times as many values over the same
 range and the flat index range is block-partitioned, one contiguous block of the
-single-GPU size per rank.
+single-GPU size per rank.  --scaling strong: ONE fixed grid, c3 refined to c128 x e128 x q1 16 x q 16 =
+4.2 M points (~20 ms on one GPU), cut into N contiguous blocks balanced by sum(T - 1)
+(SURVEY.md 8(e)); the line then carries the ranks' kernel times (imbalance) and the cost of
+the exchange.  With N > 1 over RCCL the ranks' (min, index) pairs never visit the host: the
+arg-min kernel's 16 bytes in HBM go into one all-gather, are scanned where they land, and 16
+bytes are copied back.
 
 Before the W warm-up steps a fixed, uncounted spin-up of 25 steps lets the device's clocks settle.
 Rank 0 prints ONE JSON line.
@@ -55,8 +60,14 @@ def load_hist(name):
     return hist
 
 
-def workload(name, n_ranks):
+def workload(name, n_ranks, scaling="weak"):
     """(model kind, histogram name, axes) -- SURVEY.md 8(d)."""
+    if scaling == "strong":
+        if name != "c3":
+            raise SystemExit("--scaling strong is defined for the c3 workload")
+        axes = [np.linspace(15.0, 30.0, 128), np.linspace(0.005, 0.08, 128),
+                np.linspace(0.3, 0.95, 16), np.array([0.5]), np.linspace(0.05, 0.95, 16)]
+        return "repeats", "H10k_rep", axes
     if name == "c3":
         axes = [np.linspace(15.0, 30.0, 32 * n_ranks), np.linspace(0.005, 0.08, 32),
                 np.linspace(0.3, 0.95, 16), np.array([0.5]), np.linspace(0.05, 0.95, 16)]
@@ -382,6 +393,44 @@ def bench_refine(args):
     print(json.dumps(out), flush=True)
 
 
+def tail_variant(cls, hist, axes, args, device, stream):
+    """The same grid on the same histogram with a tail (tail = 1000): what a trimmed real histogram has
+    (covest/histogram.py:125-134).  Then EVERY one of the 10 000 keys enters sp_j (covest/models.py:103-104), not
+    only the 981 counted ones.  Same step, same timing rules as the headline number."""
+    from covest_amd import DenseGrid
+    model = cls(21, 100, hist, 1000, max_error=8, device=device)
+    grid = DenseGrid(model, axes)
+
+    def step():
+        grid.evaluate(kernel=args.kernel, stream=stream)
+        return grid.argmin()
+
+    for _ in range(5 + args.warmup):
+        step()
+    import torch
+    grid.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gmin, gidx = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = grid.kernel_ms()
+    terms, flops, kernel_name = grid.work()
+    avg_kernel_s = 1e-3 * kernel_ms / max(launches, 1)
+    total = len(grid)
+    out = {"what": "same grid, same histogram, tail = 1000: all %d keys evaluated" % model.bins_evaluated,
+           "value": total * args.steps / elapsed, "unit": "evals/s", "ms_per_step": 1e3 * elapsed / args.steps,
+           "argmin": {"min_negll": gmin, "flat_index": gidx},
+           "roofline": {"bound": "mfma", "achieved": flops / avg_kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": flops / avg_kernel_s / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
+                        "kernel": kernel_name, "kernel_ms_avg": 1e3 * avg_kernel_s, "launches": launches,
+                        "algorithmic_flops_per_launch": flops, "pmf_terms_per_launch": terms}}
+    grid.close()
+    model.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -390,6 +439,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5", "f2", "f3"])
     ap.add_argument("--kmer-gbp", type=float, default=1.0, help="c5: gigabases of synthetic reads")
     ap.add_argument("--kernel", default="auto")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="strong: one fixed 4.2 M-point c3 grid cut into N blocks balanced by sum(T - 1)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl == RCCL; gloo only to rehearse N > 1 on one GPU)")
@@ -406,7 +457,7 @@ def main():
     import torch
     import torch.distributed as dist
     from covest_amd import BasicModel, DenseGrid, RepeatsModel
-    from covest_amd.grid import distributed_argmin
+    from covest_amd.grid import distributed_argmin, partition_flat_range, repeats_cost_weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -425,9 +476,10 @@ def main():
             dist.init_process_group("gloo")
     xdev = device if args.backend == "nccl" else None  # where the 16-byte exchange lives
 
-    kind, hist_name, axes = workload(args.workload, world)
+    kind, hist_name, axes = workload(args.workload, world, args.scaling)
     hist = load_hist(hist_name)
     cls = BasicModel if kind == "basic" else RepeatsModel
+    on_device = world > 1 and args.backend == "nccl"  # the exchange consumes the arg-min kernel's output in HBM
 
     # ---- time-to-argmin: host axes + histogram -> global (min, index) on the host ----
     torch.cuda.synchronize()
@@ -435,19 +487,26 @@ def main():
     model = cls(21, 100, hist, 0, max_error=8, device=local_rank)
     shape = [len(a) for a in axes]
     total = int(np.prod(shape))
-    per_rank = total // world
-    block = (rank * per_rank, (rank + 1) * per_rank if rank < world - 1 else total)
+    # contiguous flat-index blocks, one per rank, balanced by sum(T - 1) for the repeats model (covest_amd.grid):
+    # T depends on the (q1, q2, q) sub-index only, so the weights are known on the host up front
+    weights = repeats_cost_weights(model, axes) if kind == "repeats" and world > 1 else None
+    bounds = partition_flat_range(total, world, weights)
+    block = (bounds[rank], bounds[rank + 1])
     grid = DenseGrid(model, axes, block)
     stream = torch.cuda.current_stream().cuda_stream
-    grid.evaluate(kernel=args.kernel, stream=stream)
-    lmin, lidx = grid.argmin()
-    gmin, gidx = distributed_argmin(lmin, lidx, device=xdev)
-    time_to_argmin_first = time.perf_counter() - t0   # includes HIP module load on first use
+
+    def exchange():
+        if on_device:
+            return distributed_argmin(None, None, pair=grid.argmin_pair_tensor(local_rank))
+        lm, li = grid.argmin()
+        return distributed_argmin(lm, li, device=xdev)
 
     def step():
         grid.evaluate(kernel=args.kernel, stream=stream)
-        lm, li = grid.argmin()
-        return distributed_argmin(lm, li, device=xdev)
+        return exchange()
+
+    gmin, gidx = step()
+    time_to_argmin_first = time.perf_counter() - t0   # includes HIP module load on first use
 
     # W untimed warm-up steps as asked, preceded by a fixed spin-up that is not counted either: the device
     # needs a few milliseconds of work before its clocks settle (at --warmup 1 the first timed steps ran 13 %
@@ -460,8 +519,11 @@ def main():
     model2 = cls(21, 100, hist, 0, max_error=8, device=local_rank)
     grid2 = DenseGrid(model2, axes, block)
     grid2.evaluate(kernel=args.kernel, stream=stream)
-    lm, li = grid2.argmin()
-    distributed_argmin(lm, li, device=xdev)
+    if on_device:
+        distributed_argmin(None, None, pair=grid2.argmin_pair_tensor(local_rank))
+    else:
+        lm, li = grid2.argmin()
+        distributed_argmin(lm, li, device=xdev)
     time_to_argmin_warm = time.perf_counter() - t0
     grid2.close()
     model2.close()
@@ -484,6 +546,23 @@ def main():
     kernel_ms, launches = grid.kernel_ms()
     grid.profile(False)
     terms, flops, kernel_name = grid.work()
+    # N > 1: every rank's likelihood-kernel time (imbalance of the partition) and the price of the exchange alone
+    per_rank_kernel_ms, exchange_us = None, None
+    if world > 1:
+        mine = torch.tensor([kernel_ms / max(launches, 1)], dtype=torch.float64, device=xdev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_kernel_ms = [float(t.item()) for t in every]
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            exchange()  # (the pairs of the last step are still in place)
+        torch.cuda.synchronize()
+        exchange_us = 1e6 * (time.perf_counter() - t1) / 20
+    variants = None
+    if rank == 0 and world == 1 and args.workload == "c3" and args.scaling == "weak":
+        variants = {"tail": tail_variant(cls, hist, axes, args, local_rank, stream)}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -506,21 +585,24 @@ def main():
                       if args.workload == "c3" else "grid-point log-likelihood evals/s (%s)" % args.workload,
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": {"c3": "C3: RepeatsModel k=21 r=100 S=8, H10k_rep.hist (10000 keys, %d evaluated: tail=0), "
-                                   "grid c%dxe32xq1 16xq2 1xq 16" % (model.bins_evaluated, shape[0]),
+                                   "grid c%dxe%dxq1 16xq2 1xq 16" % (model.bins_evaluated, shape[0], shape[1]),
                              "c2": "C2: BasicModel k=21 r=100 S=8, H10k_basic.hist (10000 keys, %d evaluated: tail=0), "
                                    "grid c%dxe1000" % (model.bins_evaluated, shape[0]),
                              "c1": "C1: BasicModel k=21 r=100 S=8, H256.hist, grid c%dxe50" % shape[0]}[args.workload],
                 "grid_points": total, "points_per_gpu": n_local, "kernel": kernel_name,
-                "partition": "contiguous flat-index block per GPU, one RCCL all-gather of 16-byte (min, index) pairs per step",
+                "partition": "contiguous flat-index block per GPU balanced by sum(T-1), one RCCL all-gather of 16-byte "
+                             "(min, index) pairs per step (taken from the arg-min kernel's output in HBM, scanned on the "
+                             "device, 16 bytes copied back)",
             },
             "argmin": {"min_negll": gmin, "flat_index": gidx},
             "time_to_argmin_ms": {"first_call_incl_module_load": 1e3 * time_to_argmin_first,
                                   "warm": 1e3 * time_to_argmin_warm},
             "roofline": {
-                "bound": "mfma", "pipe": "fp64 VALU; 78.6 TFLOP/s is both the fp64 vector and the dense fp64 MFMA peak of MI355X",
+                "bound": "mfma", "pipe": "fp64 VALU + fp64 MFMA: ONE shared fp64 datapath (tools/microbench_mix.hip); "
+                                         "78.6 TFLOP/s is both the fp64 vector and the dense fp64 MFMA peak of MI355X",
                 "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
                 "kernel": kernel_name, "kernel_ms_avg": 1e3 * avg_kernel_s, "launches": launches,
@@ -530,6 +612,14 @@ def main():
                         "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
+        if per_rank_kernel_ms is not None:
+            out["multi_gpu"] = {"per_rank_kernel_ms": per_rank_kernel_ms,
+                                "kernel_imbalance": max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / world),
+                                "exchange_us": exchange_us, "block_bounds": [int(b) for b in bounds],
+                                "exchange": "device-resident pair -> all-gather -> device scan -> 16-byte copy"
+                                            if on_device else "host pair -> all-gather (%s) -> scan" % args.backend}
+        if variants is not None:
+            out["variants"] = variants
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(kind, hist, axes, args.cpu_budget)
         print(json.dumps(out), flush=True)

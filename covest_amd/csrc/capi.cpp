@@ -86,6 +86,10 @@ struct covest_model {
     int64_t n_keys = 0;
     int hist_max = 0;    // max(self.hist)
     int64_t key_max = 0; // the largest key the reference evaluates a pmf term for (0 if none is positive)
+    // work accounting of K-factored over the item table (tiles.h): rows that are contracted (32 per item: a sum item
+    // stands for up to 1024 keys) and keys that take a log
+    double rows_contracted = 0.0, keys_logged = 0.0;
+    bool tail_is_zero = true;
     double threshold = 0.0;
     bool has_threshold = true;
     // device storage of the two bin views
@@ -382,6 +386,10 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
         t = e;
     }
     const size_t ni = item_first.size();
+    m->rows_contracted = (double)ni * kTileBins;
+    m->keys_logged = 0.0;
+    for (double c : cnt)
+        m->keys_logged += c != 0.0 ? 1.0 : 0.0;
     const size_t n_dbl = 4 * nt + 2 * nt * kTileBins + ni * kTileBins;
     std::vector<int32_t> tile_zero(nt, 0);
     for (size_t i2 = 0; i2 < ni; ++i2)
@@ -865,6 +873,7 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
         }
     }
     m->hist_max = d->n_keys > 0 ? hist_max : 0;
+    m->tail_is_zero = d->tail == 0.0;
     m->key_max = hist_max > 0 ? hist_max : 0;
 
     DeviceGuard dev_guard(m->device);
@@ -1926,12 +1935,15 @@ int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, con
     if (flops) {
         if (g->last_kernel_id == COVEST_KERNEL_FACTORED) {
             // algorithmic minimum of the factored formulation (ll_factored.hip header):
-            // per (c,e): G build 2 flop per (key, o, s), contraction 2 flop per (key, q, o < T_q),
-            // one log (25 flop) per (key, q), prologue exps 25 per (o, s)
+            // per (c,e): G build 2 flop per (key, o, s), contraction 2 flop per (row, q, o < T_q) -- a row is a key,
+            // or the sum of a whole count-less tile (tail != 0, tiles.h) --, one log (25 flop) per
+            // (counted key, q), prologue exps 25 per (o, s)
             const double n_ce = (double)(g->plan.ce_end - g->plan.ce_begin);
             const double max_o = (double)g->plan.max_o;
-            *flops = n_ce * (bins * S * max_o * 2.0 + bins * g->q_sum_t_minus_1 * 2.0 +
-                             bins * (double)g->plan.n_q * 25.0 + 25.0 * S * max_o);
+            const double rows = m->tail_is_zero ? bins : m->rows_contracted;
+            const double logged = m->tail_is_zero ? bins : m->keys_logged;
+            *flops = n_ce * (bins * S * max_o * 2.0 + rows * g->q_sum_t_minus_1 * 2.0 +
+                             logged * (double)g->plan.n_q * 25.0 + 25.0 * S * max_o);
         } else {
             // 4 flop per pmf term + 25 per log + 25 per exp of the prologue
             *flops = 4.0 * terms + 25.0 * bins * n + 25.0 * S * g->sum_t_minus_1;

@@ -589,6 +589,61 @@ def test_reference_overflow_is_flagged(hip_lib, oracle):
     assert np.array_equal(rm.reference_overflows(rp), rwant)
 
 
+_PAIR_SCRIPT = r'''
+import os, sys
+import torch                      # FIRST: one HIP runtime per process -- the one torch ships; the library binds to it
+torch.cuda.init()
+sys.path.insert(0, os.environ["COVEST_REPO"]); sys.path.insert(0, os.path.join(os.environ["COVEST_REPO"], "tests"))
+import numpy as np
+from conftest import load_hist
+from covest_amd import DenseGrid, RepeatsModel
+from covest_amd.grid import _scan_pairs_tensor, distributed_argmin
+m = RepeatsModel(21, 100, load_hist("sim_c10_e0.05"), 0, max_error=8)
+axes = [np.linspace(8, 12, 5), np.linspace(0.03, 0.07, 4), np.linspace(0.5, 1.0, 3), [0.5], np.linspace(0.05, 0.95, 6)]
+whole = DenseGrid(m, axes)
+pairs = []
+for a, b in ((0, 100), (100, 360)):
+    g = DenseGrid(m, axes, (a, b))
+    g.evaluate(stream=torch.cuda.current_stream().cuda_stream)
+    t = g.argmin_pair_tensor(torch.cuda.current_device())
+    assert t.is_cuda and t.dtype == torch.float64 and tuple(t.shape) == (2,)
+    v, i = g.argmin()
+    assert t.cpu().tolist() == [v, float(i)] and a <= i < b, (t, v, i)
+    assert distributed_argmin(None, None, pair=t) == (v, i)  # no process group: the identity
+    pairs.append(t.clone())
+    g.close()
+whole.evaluate()
+best = whole.argmin()
+got = _scan_pairs_tensor(torch.stack(pairs)).cpu().tolist()
+assert (got[0], int(got[1])) == best, (got, best)
+# the same through a one-rank RCCL group: the all-gather consumes the HBM pair where the arg-min kernel left it
+import torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+g = DenseGrid(m, axes)
+g.evaluate(stream=torch.cuda.current_stream().cuda_stream)
+t = g.argmin_pair_tensor(0)
+out = torch.empty((1, 2), dtype=torch.float64, device="cuda")
+dist.all_gather_into_tensor(out, t)
+assert out.cpu().tolist()[0] == [best[0], float(best[1])]
+dist.destroy_process_group()
+print("pair ok", best)
+'''
+
+
+def test_argmin_pair_in_hbm_feeds_the_exchange(hip_lib):
+    """Multi-GPU exchange without a host round trip (SURVEY 8(e)): the arg-min kernel's (min, GLOBAL index) pair is
+    adopted by torch where it lies in HBM (DenseGrid.argmin_pair_tensor), scanned with the tensor form of the
+    selection rule, and fed to an RCCL all-gather (a one-rank group: the box has one GPU); it must be what
+    covest_grid_argmin copies out, for a block that does not start at 0 too.  In a process of its own: torch has to
+    initialise its HIP runtime before the library's first call (as bench.py does) -- a process has ONE runtime."""
+    import subprocess
+    import sys
+    env = dict(os.environ, COVEST_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    proc = subprocess.run([sys.executable, "-c", _PAIR_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "pair ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
+
+
 def test_block_partition_equals_whole_grid(hip_lib):
     """Multi-GPU block partition (SURVEY 8(e)) on one device: evaluating the
     blocks of a partition separately gives the same values and the same winner."""
