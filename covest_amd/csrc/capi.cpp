@@ -110,8 +110,20 @@ struct covest_grid {
     int64_t flat_begin = 0, flat_end = 0;
     PointSource src{};
     DevBuf axes, t_table, ll, sub_index, sub_word, sub_ctl, partial_val, partial_idx, result, plan_buf;
-    FactoredPlan plan{};        // K-factored work description (repeats model, dense grid)
+    FactoredPlan plan{};        // K-factored work description (repeats model, dense grid): the weight vectors whose
+                                //   threshold_o fits a workgroup's lanes (build_factored_plan)
     bool has_plan = false;
+    bool has_short_part = false;
+    // the weight vectors beyond that: one part per chunk of copy numbers, p_j summed in HBM, logs by ll_finish_dense
+    struct Part {
+        DevBuf buf;
+        FactoredPlan plan{};
+    };
+    std::vector<Part> long_parts;
+    int32_t n_long_tiles = 0;
+    std::vector<int32_t> long_q_orig_host;
+    DevBuf long_q_orig, long_partial;
+    int t_max = 2; // largest threshold_o of the (q1, q2, q) product
     double q_sum_t_minus_1 = 0.0; // sum over the Q weight vectors of (threshold_o - 1)
     double sum_t_minus_1 = 0.0; // sum over the block's points of (threshold_o - 1)
     const char *last_kernel = "none";
@@ -295,7 +307,7 @@ struct HostBin {
 int build_tiles(covest_model *m, std::vector<HostBin> bins)
 {
     m->has_tiles = false;
-    if (m->dm.n_err != 8 || bins.empty())
+    if (m->dm.n_err > 32 || bins.empty()) // (the recurrence kernels hold max_error <= 32 error classes)
         return COVEST_OK;
     std::sort(bins.begin(), bins.end(), [](const HostBin &a, const HostBin &b) { return a.key < b.key; });
     if (bins.front().key < 1 || bins.back().key > kMaxFastKey)
@@ -438,82 +450,97 @@ double copy_number_weight_host(double q1, double q2, double q, int o)
     return (1 - q1) * (1 - q2) * q * std::pow(1 - q, (double)(o - 3));
 }
 
-// FactoredPlan of tiles.h for the (q1, q2, q) product of a dense repeats grid.
-int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t *axis_len,
-                        const std::vector<int32_t> &t_table)
+// ---- K-factored plans of a dense repeats grid (tiles.h FactoredPlan) ----
+// The Q = |q1| x |q2| x |q| weight vectors are sorted by threshold_o (descending) into slots, 16 per q-tile.  A PART
+// is one launch's work description: a range of q-tiles and a CHUNK of copy numbers o_base + 1 .. o_base + chunk.
+//   * weight vectors whose threshold_o - 1 fits the lanes of a workgroup (`chunk` copy numbers) form ONE part that
+//     writes log-likelihoods (list_mode 0);
+//   * the longer ones (optimize_grid walks q down to 0.01: threshold_o ~ 1500) are the first q-tiles of the sorted
+//     order; they get one part per chunk (list_mode 3) that sums p_j into HBM, and ll_finish_dense takes the logs.
+//     Only those tiles pay for it: the rest of the grid stays on the one-launch path.
+// With more than 8 error classes (max_error = k + 1 = 22 when a model is built directly, covest/models.py:28-31) a
+// copy number's classes are dealt to n_pass = ceil(S / 8) lanes, which the contraction treats as extra columns with
+// the same weight; a chunk then holds 512 / n_pass copy numbers.
+struct QOrder {
+    int64_t n1, n2, n3, nq;
+    std::vector<int32_t> order; // slot -> index in the (q1, q2, q) product, by descending threshold_o
+    int32_t n_qtiles;
+    int t_max;
+};
+
+// One part: q-tiles [tile_lo, tile_hi) of the sorted order, copy numbers o_base + 1 .. o_base + chunk.
+int build_plan_part(covest_grid *g, const double *const *axes, const std::vector<int32_t> &t_table, const QOrder &qo,
+                    int32_t tile_lo, int32_t tile_hi, int o_base, int chunk, int n_pass, int list_mode, DevBuf &buf,
+                    FactoredPlan &pl, std::vector<int32_t> *q_orig_out)
 {
     covest_model *m = g->model;
-    g->has_plan = false;
-    if (!m->has_tiles || m->n_par != 5)
-        return COVEST_OK;
-    const int64_t n1 = axis_len[2], n2 = axis_len[3], n3 = axis_len[4];
-    const int64_t nq = n1 * n2 * n3;
-    if (nq > (int64_t)1 << 24)
-        return COVEST_OK;
-    int t_max = 1;
-    for (int64_t i = 0; i < nq; ++i)
-        t_max = std::max(t_max, (int)t_table[(size_t)i]);
-    if (t_max - 1 > 512)
-        return COVEST_OK; // more copy-number classes than a workgroup has lanes: direct kernel
-    std::vector<int32_t> order((size_t)nq);
-    for (int64_t i = 0; i < nq; ++i)
-        order[(size_t)i] = (int32_t)i;
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int32_t a, int32_t b) { return t_table[(size_t)a] > t_table[(size_t)b]; });
-    const int32_t n_qtiles = (int32_t)((nq + 15) / 16);
+    const int64_t n2 = qo.n2, n3 = qo.n3, nq = qo.nq;
+    const int32_t n_qtiles = tile_hi - tile_lo;
     const size_t n_slots = (size_t)n_qtiles * 16;
-    std::vector<int32_t> nsteps((size_t)n_qtiles, 0), nfull((size_t)n_qtiles, 1 << 30), q_t(n_slots, 0), q_orig(n_slots, -1);
-    std::vector<double> first8(8 * n_slots, 0.0), r4(n_slots, 0.0);
-    for (size_t slot = 0; slot < (size_t)nq; ++slot) {
-        const int64_t qi = order[slot];
+    std::vector<int32_t> nsteps((size_t)n_qtiles, 0), q_t(n_slots, 0), q_orig(n_slots, -1);
+    std::vector<double> r4(n_slots, 0.0);
+    int t_loc_max = 1; // largest LOCAL threshold: copy numbers of the chunk are o_base + 1 .. o_base + t_local - 1
+    auto weights_of = [&](size_t slot_global, double &q1, double &q2, double &q) {
+        const int64_t qi = qo.order[slot_global];
         const int64_t a = qi / (n2 * n3), b = (qi / n3) % n2, c = qi % n3;
-        const double q1 = clamp_one(m->dm, 2, axes[2][a]);
-        const double q2 = clamp_one(m->dm, 3, axes[3][b]);
-        const double q = clamp_one(m->dm, 4, axes[4][c]);
-        const int t = t_table[(size_t)qi];
-        q_t[slot] = t;
-        q_orig[slot] = (int32_t)qi;
-        for (int o = 1; o <= 8; ++o)
-            first8[(size_t)(o - 1) * n_slots + slot] = copy_number_weight_host(q1, q2, q, o);
-        r4[slot] = std::pow(1 - q, 4.0);
-        const int steps = t > 1 ? (t - 1 + 3) / 4 : 0;
-        nsteps[slot / 16] = std::max(nsteps[slot / 16], steps);
-        nfull[slot / 16] = std::min(nfull[slot / 16], t > 1 ? (t - 1) / 4 : 0);
+        q1 = clamp_one(m->dm, 2, axes[2][a]);
+        q2 = clamp_one(m->dm, 3, axes[3][b]);
+        q = clamp_one(m->dm, 4, axes[4][c]);
+    };
+    for (size_t ls = 0; ls < n_slots; ++ls) {
+        const size_t gs = (size_t)tile_lo * 16 + ls;
+        if (gs >= (size_t)nq)
+            continue; // padding column
+        const int64_t qi = qo.order[gs];
+        const int t_loc = std::min(chunk + 1, std::max(0, (int)t_table[(size_t)qi] - o_base));
+        q_t[ls] = t_loc;
+        q_orig[ls] = (int32_t)qi;
+        double q1, q2, q;
+        weights_of(gs, q1, q2, q);
+        r4[ls] = std::pow(1 - q, 4.0);
+        const int steps = t_loc > 1 ? (t_loc - 1 + 3) / 4 : 0;
+        nsteps[ls / 16] = std::max(nsteps[ls / 16], steps);
+        t_loc_max = std::max(t_loc_max, t_loc);
     }
-    if (nq % 16 != 0)
-        nfull[(size_t)n_qtiles - 1] = 0; // padding columns (T = 0) are cut off from the first step
+    if (q_orig_out)
+        *q_orig_out = q_orig;
+    const int max_o = t_loc_max - 1;
+    const int pass_stride = ((max_o + 3) / 4) * 4; // a pass begins on an MFMA step
+    const int n_columns = n_pass == 1 ? max_o : n_pass * pass_stride;
     // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
-    const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
+    const int ld = ((n_columns + 31) / 32) * 32 + 2;
     const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 7680 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const int n_units = 2 * n_qtiles;
-    const int nt = (t_max - 1 <= 256 && n_units <= 4 * kMaxUnits) ? 256 : 512;
     const int hu = kHalfUnits; // (768 threads with 2 slots per half, 3 waves/SIMD, was measured: +1 %)
     const int mu = 2 * hu;
+    // a unit needs at least one piece per pass: fewer units fit a wave's slots
+    const int units_per_wave = std::max(1, mu / n_pass);
+    const int nt = (n_columns <= 256 && n_units <= 4 * units_per_wave) ? 256 : 512;
     const int nw = nt / 64;
-    const int cap_block = nw * mu;
-    const int n_qblocks = (n_units + cap_block - 1) / cap_block;
-    // cost model of the assignment, in MFMA steps: a unit costs its steps plus its share of the
+    const int cap_block = nw * units_per_wave;
+    const int n_qblocks = std::max(1, (n_units + cap_block - 1) / cap_block);
+    // cost model of the assignment, in MFMA steps: a unit costs its steps (in every pass) plus its share of the
     // logs; a builder wave starts with the cost of phase A (tuned on C3 with the in-kernel stamps)
     const int unit_overhead = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD") ? std::atoi(std::getenv("COVEST_FACTORED_UNIT_OVERHEAD")) : kUnitOverhead;
     const int build_cost = std::getenv("COVEST_FACTORED_BUILD_COST") ? std::atoi(std::getenv("COVEST_FACTORED_BUILD_COST")) : kBuildCost;
-    const size_t n_unit = (size_t)n_qblocks * cap_block;
-    std::vector<int32_t> unit_tile(n_unit, -1), unit_half(n_unit, 0), unit_s0(n_unit, 0), unit_len(n_unit, 0),
-        unit_cont(n_unit, 0);
+    const size_t n_unit = (size_t)n_qblocks * nw * mu;
+    std::vector<int32_t> unit_tile(n_unit, -1), unit_half(n_unit, 0), unit_s0(n_unit, 0), unit_o0(n_unit, 1),
+        unit_len(n_unit, 0), unit_cont(n_unit, 0);
     for (int blk = 0; blk < n_qblocks; ++blk) {
         struct Unit {
-            int tile, half, cost, pieces;
+            int tile, half, cost, pieces; // pieces: per pass
         };
         std::vector<Unit> units;
         for (int qt = blk; qt < n_qtiles; qt += n_qblocks) // tiles are sorted by T: interleave over blocks
             for (int h = 0; h < 2; ++h)
-                units.push_back({qt, h, std::max(1, (int)nsteps[(size_t)qt]) + unit_overhead, 1});
+                units.push_back({qt, h, n_pass * std::max(1, (int)nsteps[(size_t)qt]) + unit_overhead, 1});
         std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.cost > b.cost; });
-        // longest first into the lightest SIMD (waves w and w + 4 share one) that still has a free
-        // slot, then into the lighter of that SIMD's waves with one
+        // longest first into the lightest SIMD (waves w and w + 4 share one) that still has room,
+        // then into the lighter of that SIMD's waves with room
         const int n_bins = std::min(4, nw);
         std::vector<long> bin_load((size_t)n_bins, 0), wave_load((size_t)nw, 0);
         if (n_buf == 2) // builders contract less: they fill the next key tile in the same interval
-            for (int w = 0; w < nw && w * 64 < t_max - 1; ++w) {
+            for (int w = 0; w < nw && w * 64 < n_columns; ++w) {
                 bin_load[(size_t)(w % n_bins)] += build_cost;
                 wave_load[(size_t)w] += build_cost;
             }
@@ -521,7 +548,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         for (const Unit &u : units) {
             int best_wave = -1;
             for (int w = 0; w < nw; ++w) {
-                if ((int)held[(size_t)w].size() >= mu)
+                if ((int)held[(size_t)w].size() >= units_per_wave)
                     continue;
                 if (best_wave < 0) {
                     best_wave = w;
@@ -537,10 +564,10 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         }
         for (int w = 0; w < nw; ++w) {
             std::vector<Unit> &mine = held[(size_t)w];
-            // cut the unit with the longest pieces once more while slots are free (tiles.h)
+            // cut the unit with the longest pieces once more (in every pass) while slots are free (tiles.h)
             auto piece_len = [&](const Unit &u) { return ((int)nsteps[(size_t)u.tile] + u.pieces - 1) / u.pieces; };
-            int used = (int)mine.size();
-            while (used < mu && !mine.empty()) {
+            int used = (int)mine.size() * n_pass;
+            while (used + n_pass <= mu && !mine.empty()) {
                 size_t longest = 0;
                 for (size_t i = 1; i < mine.size(); ++i)
                     if (piece_len(mine[i]) > piece_len(mine[longest]))
@@ -550,21 +577,26 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
                 if (piece_len(trial) < kMinPieceSteps)
                     break;
                 mine[longest].pieces += 1;
-                ++used;
+                used += n_pass;
             }
             // slots sorted by piece length (descending), the pieces of a unit adjacent
             std::stable_sort(mine.begin(), mine.end(),
                              [&](const Unit &a, const Unit &b) { return piece_len(a) > piece_len(b); });
             size_t k = 0;
-            for (const Unit &u : mine)
-                for (int p = 0; p < u.pieces; ++p, ++k) {
-                    const size_t at = ((size_t)blk * nw + w) * mu + k;
-                    unit_tile[at] = u.tile;
-                    unit_half[at] = u.half;
-                    unit_s0[at] = p * piece_len(u);
-                    unit_len[at] = piece_len(u); // equal lengths: steps past the unit's end are cut off by T
-                    unit_cont[at] = p > 0;
-                }
+            for (const Unit &u : mine) {
+                bool first = true;
+                for (int pass = 0; pass < n_pass; ++pass)
+                    for (int p = 0; p < u.pieces; ++p, ++k) {
+                        const size_t at = ((size_t)blk * nw + w) * mu + k;
+                        unit_tile[at] = u.tile;
+                        unit_half[at] = u.half;
+                        unit_s0[at] = pass * (pass_stride / 4) + p * piece_len(u);
+                        unit_o0[at] = 1 + 4 * p * piece_len(u);
+                        unit_len[at] = piece_len(u); // equal lengths: steps past the unit's end are cut off by T
+                        unit_cont[at] = first ? 0 : 1;
+                        first = false;
+                    }
+            }
         }
     }
     // weights of every slot's first two MFMA steps, per lane (lane = 16 * (o mod 4) + column)
@@ -575,81 +607,85 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
             continue;
         for (int which = 0; which < 2; ++which)
             for (int lane = 0; lane < 64; ++lane) {
-                const size_t slot = (size_t)qt * 16 + (size_t)(lane & 15);
-                if (slot >= (size_t)nq)
+                const size_t gs = ((size_t)tile_lo + (size_t)qt) * 16 + (size_t)(lane & 15);
+                if (gs >= (size_t)nq)
                     continue; // padding column
-                const int64_t qi = order[slot];
-                const int64_t a = qi / (n2 * n3), b = (qi / n3) % n2, c = qi % n3;
-                const int o = 1 + 4 * (unit_s0[at] + which) + (lane >> 4);
-                piece_w[(at * 2 + (size_t)which) * 64 + (size_t)lane] = copy_number_weight_host(
-                    clamp_one(m->dm, 2, axes[2][a]), clamp_one(m->dm, 3, axes[3][b]), clamp_one(m->dm, 4, axes[4][c]), o);
+                double q1, q2, q;
+                weights_of(gs, q1, q2, q);
+                const int o = o_base + unit_o0[at] + 4 * which + (lane >> 4);
+                piece_w[(at * 2 + (size_t)which) * 64 + (size_t)lane] = copy_number_weight_host(q1, q2, q, o);
             }
     }
-    // one buffer: doubles first (first8 | r4), then int32 (nsteps | q_T | q_orig | unit_tile | nfull)
-    const size_t n_dbl = 9 * n_slots + piece_w.size();
-    const size_t n_int = 2 * (size_t)n_qtiles + 2 * n_slots + 5 * n_unit;
-    HIP_TRY(g->plan_buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
-    double *dbase = g->plan_buf.as<double>();
+    // one buffer: doubles first (r4 | piece_w), then int32 (q_T | q_orig | unit tables)
+    const size_t n_dbl = n_slots + piece_w.size();
+    const size_t n_int = 2 * n_slots + 6 * n_unit;
+    HIP_TRY(buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
+    double *dbase = buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
-    int32_t *piece_base = ibase + 2 * n_qtiles + 2 * n_slots + n_unit;
     {
         // staged on the host in the device layout, ONE copy (a dozen small copies cost ~150 us of the plan build)
         std::vector<char> stage(n_dbl * sizeof(double) + n_int * sizeof(int32_t));
         double *sd = reinterpret_cast<double *>(stage.data());
         int32_t *si = reinterpret_cast<int32_t *>(sd + n_dbl);
-        std::copy(first8.begin(), first8.end(), sd);
-        std::copy(r4.begin(), r4.end(), sd + 8 * n_slots);
-        std::copy(piece_w.begin(), piece_w.end(), sd + 9 * n_slots);
-        std::copy(nsteps.begin(), nsteps.end(), si);
-        std::copy(q_t.begin(), q_t.end(), si + n_qtiles);
-        std::copy(q_orig.begin(), q_orig.end(), si + n_qtiles + n_slots);
-        std::copy(unit_tile.begin(), unit_tile.end(), si + n_qtiles + 2 * n_slots);
-        std::copy(nfull.begin(), nfull.end(), si + n_qtiles + 2 * n_slots + n_unit);
-        int32_t *sp = si + 2 * n_qtiles + 2 * n_slots + n_unit;
-        std::copy(unit_half.begin(), unit_half.end(), sp);
-        std::copy(unit_s0.begin(), unit_s0.end(), sp + n_unit);
-        std::copy(unit_len.begin(), unit_len.end(), sp + 2 * n_unit);
-        std::copy(unit_cont.begin(), unit_cont.end(), sp + 3 * n_unit);
-        HIP_TRY(hipMemcpy(g->plan_buf.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice));
+        std::copy(r4.begin(), r4.end(), sd);
+        std::copy(piece_w.begin(), piece_w.end(), sd + n_slots);
+        std::copy(q_t.begin(), q_t.end(), si);
+        std::copy(q_orig.begin(), q_orig.end(), si + n_slots);
+        int32_t *sp = si + 2 * n_slots;
+        std::copy(unit_tile.begin(), unit_tile.end(), sp);
+        std::copy(unit_half.begin(), unit_half.end(), sp + n_unit);
+        std::copy(unit_s0.begin(), unit_s0.end(), sp + 2 * n_unit);
+        std::copy(unit_o0.begin(), unit_o0.end(), sp + 3 * n_unit);
+        std::copy(unit_len.begin(), unit_len.end(), sp + 4 * n_unit);
+        std::copy(unit_cont.begin(), unit_cont.end(), sp + 5 * n_unit);
+        HIP_TRY(hipMemcpy(buf.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice));
     }
-    FactoredPlan &pl = g->plan;
+    pl = FactoredPlan{};
     pl.c_axis = g->src.axis[0];
     pl.e_axis = g->src.axis[1];
-    pl.n_e = axis_len[1];
+    pl.n_e = g->len[1];
     pl.n_q = nq;
     pl.ce_begin = g->flat_begin / nq;
     pl.ce_end = (g->flat_end + nq - 1) / nq;
     pl.n_qtiles = n_qtiles;
-    pl.max_o = t_max - 1;
+    pl.max_o = max_o;
+    pl.n_pass = n_pass;
+    pl.pass_stride = pass_stride;
+    pl.n_columns = n_columns;
+    pl.o_base = o_base;
     pl.n_threads = nt;
     pl.half_units = hu;
     pl.n_qblocks = n_qblocks;
     pl.ld = ld;
     pl.n_buf = std::getenv("COVEST_FACTORED_NBUF") ? std::atoi(std::getenv("COVEST_FACTORED_NBUF")) : n_buf;
-    pl.unit_tile = ibase + n_qtiles + 2 * n_slots;
-    pl.qtile_nfull = ibase + n_qtiles + 2 * n_slots + n_unit;
-    pl.unit_half = piece_base;
-    pl.unit_s0 = piece_base + n_unit;
-    pl.unit_len = piece_base + 2 * n_unit;
-    pl.unit_cont = piece_base + 3 * n_unit;
-    pl.piece_w = dbase + 9 * n_slots;
-    pl.q_first8 = dbase;
-    pl.q_r4 = dbase + 8 * n_slots;
-    pl.qtile_nsteps = ibase;
-    pl.q_T = ibase + n_qtiles;
-    pl.q_orig = ibase + n_qtiles + n_slots;
+    int32_t *ub = ibase + 2 * n_slots;
+    pl.unit_tile = ub;
+    pl.unit_half = ub + n_unit;
+    pl.unit_s0 = ub + 2 * n_unit;
+    pl.unit_o0 = ub + 3 * n_unit;
+    pl.unit_len = ub + 4 * n_unit;
+    pl.unit_cont = ub + 5 * n_unit;
+    pl.piece_w = dbase + n_slots;
+    pl.q_first8 = nullptr;
+    pl.q_r4 = dbase;
+    pl.qtile_nsteps = nullptr;
+    pl.qtile_nfull = nullptr;
+    pl.q_T = ibase;
+    pl.q_orig = ibase + n_slots;
     pl.flat_begin = g->flat_begin;
     pl.flat_end = g->flat_end;
-    pl.list_mode = 0;
-    pl.p_clamp = clamp_for(m, t_max);
+    pl.list_mode = list_mode;
+    pl.p_clamp = clamp_for(m, qo.t_max);
     pl.n_seg = 1;
     pl.item_obase = nullptr;
     pl.partial = nullptr;
+    pl.ce_first = pl.ce_begin;
+    pl.n_cols_partial = (int64_t)n_slots;
     {
         const char *skip = std::getenv("COVEST_FACTORED_SKIP"); // profiling aid, see tiles.h
         pl.skip_phases = skip ? std::atoi(skip) : 0;
         pl.diag = nullptr;
-        if (std::getenv("COVEST_FACTORED_DIAG")) { // profiling aid: leaked on purpose, diagnostic runs only
+        if (list_mode == 0 && std::getenv("COVEST_FACTORED_DIAG")) { // profiling aid: leaked on purpose, diagnostic runs only
             void *dp = nullptr;
             const size_t bytes = (size_t)(pl.ce_end - pl.ce_begin) * n_qblocks * nw * 8 * sizeof(long long);
             if (hipMalloc(&dp, bytes) == hipSuccess && hipMemset(dp, 0, bytes) == hipSuccess) {
@@ -658,7 +694,83 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
             }
         }
     }
-    g->has_plan = pl.max_o >= 1;
+    return COVEST_OK;
+}
+
+// All the parts of a dense repeats grid (see above).  g->has_plan stays false where K-factored does not apply:
+// no tile table (keys beyond 16384 ...), more than 32 error classes, or more weight vectors than 2^24.
+int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t *axis_len,
+                        const std::vector<int32_t> &t_table)
+{
+    covest_model *m = g->model;
+    g->has_plan = false;
+    g->long_parts.clear();
+    g->n_long_tiles = 0;
+    if (!m->has_tiles || m->n_par != 5 || m->dm.n_err > 32)
+        return COVEST_OK;
+    QOrder qo;
+    qo.n1 = axis_len[2];
+    qo.n2 = axis_len[3];
+    qo.n3 = axis_len[4];
+    qo.nq = qo.n1 * qo.n2 * qo.n3;
+    if (qo.nq > (int64_t)1 << 24)
+        return COVEST_OK;
+    qo.t_max = 1;
+    for (int64_t i = 0; i < qo.nq; ++i)
+        qo.t_max = std::max(qo.t_max, (int)t_table[(size_t)i]);
+    qo.order.resize((size_t)qo.nq);
+    for (int64_t i = 0; i < qo.nq; ++i)
+        qo.order[(size_t)i] = (int32_t)i;
+    std::stable_sort(qo.order.begin(), qo.order.end(),
+                     [&](int32_t a, int32_t b) { return t_table[(size_t)a] > t_table[(size_t)b]; });
+    qo.n_qtiles = (int32_t)((qo.nq + 15) / 16);
+    const int n_pass = (m->dm.n_err + 7) / 8;
+    const int chunk = ((512 / n_pass) / 4) * 4; // copy numbers one workgroup's lanes hold
+    g->t_max = qo.t_max;
+    // the long weight vectors are the first slots of the sorted order
+    int64_t n_long = 0;
+    while (n_long < qo.nq && (int)t_table[(size_t)qo.order[(size_t)n_long]] - 1 > chunk)
+        ++n_long;
+    const int32_t n_long_tiles = (int32_t)((n_long + 15) / 16);
+    if (n_long_tiles > 0) {
+        const int n_chunks = (qo.t_max - 1 + chunk - 1) / chunk;
+        g->long_parts.resize((size_t)n_chunks);
+        for (int c = 0; c < n_chunks; ++c) {
+            // tiles that still have copy numbers in this chunk: a prefix (sorted by threshold_o)
+            int32_t hi = 0;
+            while (hi < n_long_tiles && (int)t_table[(size_t)qo.order[(size_t)hi * 16]] - 1 > c * chunk)
+                ++hi;
+            if (hi == 0) {
+                g->long_parts.resize((size_t)c);
+                break;
+            }
+            covest_grid::Part &part = g->long_parts[(size_t)c];
+            const int rc = build_plan_part(g, axes, t_table, qo, 0, hi, c * chunk, chunk, n_pass, 3, part.buf, part.plan,
+                                           c == 0 ? &g->long_q_orig_host : nullptr);
+            if (rc != COVEST_OK)
+                return rc;
+        }
+        g->n_long_tiles = n_long_tiles;
+        // q_orig of the long slots on the device, for ll_finish_dense (padded to whole tiles)
+        g->long_q_orig_host.resize((size_t)n_long_tiles * 16, -1);
+        HIP_TRY(g->long_q_orig.reserve(g->long_q_orig_host.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(g->long_q_orig.ptr, g->long_q_orig_host.data(), g->long_q_orig_host.size() * sizeof(int32_t),
+                          hipMemcpyHostToDevice));
+    }
+    g->has_short_part = n_long_tiles < qo.n_qtiles;
+    if (g->has_short_part) {
+        const int rc = build_plan_part(g, axes, t_table, qo, n_long_tiles, qo.n_qtiles, 0, chunk, n_pass, 0, g->plan_buf,
+                                       g->plan, nullptr);
+        if (rc != COVEST_OK)
+            return rc;
+    } else {
+        g->plan = FactoredPlan{};
+        g->plan.n_q = qo.nq;
+        g->plan.ce_begin = g->flat_begin / qo.nq;
+        g->plan.ce_end = (g->flat_end + qo.nq - 1) / qo.nq;
+        g->plan.max_o = 0;
+    }
+    g->has_plan = qo.t_max >= 2;
     return COVEST_OK;
 }
 
@@ -681,7 +793,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
     std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 2 * 64, 0.0);
     std::vector<int32_t> q_t(n_slots, 0), q_orig(n_slots, -1), unit_tile(n_unit, -1), unit_half(n_unit, 0),
-        unit_s0(n_unit, 0), unit_len(n_unit, 0), unit_cont(n_unit, 0);
+        unit_s0(n_unit, 0), unit_o0(n_unit, 1), unit_len(n_unit, 0), unit_cont(n_unit, 0);
     for (int64_t p = 0; p < n; ++p) {
         const double *par = params + p * 5;
         axes[(size_t)p] = par[0];
@@ -704,6 +816,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
                 unit_tile[at] = (int32_t)p;
                 unit_half[at] = h;
                 unit_s0[at] = k * piece_len;
+                unit_o0[at] = 1 + 4 * k * piece_len;
                 unit_len[at] = piece_len;
                 unit_cont[at] = k > 0;
                 for (int which = 0; which < 2; ++which)
@@ -717,7 +830,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     std::vector<std::pair<const void *, size_t>> iparts = {
         {q_t.data(), q_t.size()},             {q_orig.data(), q_orig.size()},       {unit_tile.data(), unit_tile.size()},
         {unit_half.data(), unit_half.size()}, {unit_s0.data(), unit_s0.size()},     {unit_len.data(), unit_len.size()},
-        {unit_cont.data(), unit_cont.size()}};
+        {unit_cont.data(), unit_cont.size()}, {unit_o0.data(), unit_o0.size()}};
     size_t n_dbl = 0, n_int = 0;
     for (auto &pr : dparts)
         n_dbl += pr.second;
@@ -752,6 +865,10 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     pl.n_q = 1;
     pl.n_qtiles = (int32_t)n;
     pl.max_o = t_max - 1;
+    pl.n_pass = 1;
+    pl.pass_stride = ((t_max - 1 + 3) / 4) * 4;
+    pl.n_columns = t_max - 1;
+    pl.o_base = 0;
     pl.n_threads = NW * 64;
     pl.half_units = kHalfUnits;
     pl.n_qblocks = 1;
@@ -766,6 +883,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     pl.unit_s0 = iptr[4];
     pl.unit_len = iptr[5];
     pl.unit_cont = iptr[6];
+    pl.unit_o0 = iptr[7];
     pl.qtile_nsteps = nullptr;
     pl.qtile_nfull = nullptr;
     pl.q_first8 = nullptr;
@@ -991,7 +1109,7 @@ static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_gr
         // a repeats-model point list: one workgroup per (point, key segment) (list mode) instead of one wave --
         // the latency path of refinements.  Long lists are throughput work and go to K-direct (and the list
         // mode's per-point tables, 13 KB each, stay small): see covest_eval_points.
-        if (!g && m->has_tiles && m->dm.kind == COVEST_MODEL_REPEATS)
+        if (!g && m->has_tiles && m->dm.kind == COVEST_MODEL_REPEATS && m->dm.n_err <= 8)
             return COVEST_KERNEL_FACTORED;
         return COVEST_KERNEL_DIRECT;
     case COVEST_KERNEL_DIRECT:
@@ -999,15 +1117,59 @@ static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_gr
     case COVEST_KERNEL_RECUR:
         if (basic_fast)
             return COVEST_KERNEL_RECUR;
-        return fail(COVEST_E_INVALID, "recurrence kernel needs the basic model, max_error 8 and keys in 1..16384");
+        return fail(COVEST_E_INVALID, "recurrence kernel needs the basic model, max_error <= 32 and keys in 1..16384");
     case COVEST_KERNEL_FACTORED:
-        if (factored_ok || (!g && m->has_tiles && m->dm.kind == COVEST_MODEL_REPEATS))
+        if (factored_ok || (!g && m->has_tiles && m->dm.kind == COVEST_MODEL_REPEATS && m->dm.n_err <= 8))
             return COVEST_KERNEL_FACTORED;
-        return fail(COVEST_E_INVALID, "factored kernel needs a dense repeats-model grid, max_error 8, keys in "
-                                      "1..16384 and threshold_o <= 513");
+        return fail(COVEST_E_INVALID, "factored kernel needs the repeats model, keys in 1..16384 and max_error <= 32 "
+                                      "(<= 8 for a point list)");
     default:
         return fail(COVEST_E_INVALID, "unknown kernel");
     }
+}
+
+// K-factored on a dense grid: the part whose weight vectors fit a workgroup's lanes writes log-likelihoods (and is
+// followed by the pass that patches what it handed back); the long weight vectors go chunk by chunk of copy numbers
+// into an HBM buffer of p_j, one batch of (c, e) rows at a time, and ll_finish_dense takes their logs.
+static hipError_t launch_factored_grid(covest_grid *g, double *out, const SubList &sub, hipStream_t st)
+{
+    const covest_model *m = g->model;
+    if (g->has_short_part) {
+        hipError_t e = launch_ll_factored(m->dm, m->tv, g->plan, out, sub, st);
+        if (e != hipSuccess)
+            return e;
+        e = launch_ll_fix_list(m->dm, m->tv, g->src, out, sub, st);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (g->n_long_tiles > 0) {
+        const int64_t n_cols = (int64_t)g->n_long_tiles * 16, n_rows = (int64_t)m->tv.n_items * kTileBins;
+        const int64_t ce_begin = g->plan.ce_begin, ce_end = g->plan.ce_end;
+        const int64_t per_ce = n_cols * n_rows * (int64_t)sizeof(double);
+        const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(ce_end - ce_begin, ((int64_t)1 << 30) / per_ce));
+        hipError_t e = g->long_partial.reserve((size_t)(batch * per_ce));
+        if (e != hipSuccess)
+            return e;
+        for (int64_t first = ce_begin; first < ce_end; first += batch) {
+            const int64_t last = std::min(ce_end, first + batch);
+            for (covest_grid::Part &part : g->long_parts) {
+                FactoredPlan pl = part.plan;
+                pl.ce_begin = first;
+                pl.ce_end = last;
+                pl.ce_first = first;
+                pl.n_cols_partial = n_cols;
+                pl.partial = g->long_partial.as<double>();
+                e = launch_ll_factored(m->dm, m->tv, pl, out, sub, st);
+                if (e != hipSuccess)
+                    return e;
+            }
+            e = launch_ll_finish_dense(m->dm, m->tv, g->src, g->long_partial.as<double>(), first, last - first, n_cols,
+                                       g->long_q_orig.as<int32_t>(), g->plan.n_q, g->flat_end, out, st);
+            if (e != hipSuccess)
+                return e;
+        }
+    }
+    return hipSuccess;
 }
 
 static SubList sub_list_of(const covest_model *m, int t_max, const DevBuf &index, const DevBuf &word, const DevBuf &ctl)
@@ -1031,8 +1193,7 @@ static hipError_t launch_ll(const covest_model *m, int kernel, const PointSource
     if (kernel == COVEST_KERNEL_FACTORED) {
         if (name)
             *name = "ll_factored";
-        hipError_t e = launch_ll_factored(m->dm, m->tv, g->plan, out, sub, st);
-        return e != hipSuccess ? e : launch_ll_fix_list(m->dm, m->tv, src, out, sub, st);
+        return launch_factored_grid(const_cast<covest_grid *>(g), out, sub, st);
     }
     if (kernel == COVEST_KERNEL_RECUR) {
         if (name)
@@ -1380,6 +1541,10 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
         g->partial_idx.release();
         g->result.release();
         g->plan_buf.release();
+        for (covest_grid::Part &part : g->long_parts)
+            part.buf.release();
+        g->long_q_orig.release();
+        g->long_partial.release();
         delete g;
         return code;
     };
@@ -1473,6 +1638,10 @@ void covest_grid_destroy(covest_grid *g)
     g->partial_idx.release();
     g->result.release();
     g->plan_buf.release();
+    for (covest_grid::Part &part : g->long_parts)
+        part.buf.release();
+    g->long_q_orig.release();
+    g->long_partial.release();
     for (hipEvent_t e : g->ev_begin)
         (void)hipEventDestroy(e);
     for (hipEvent_t e : g->ev_end)
@@ -1540,7 +1709,7 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
         g->ev_used++;
         HIP_TRY(hipEventRecord(e0, st));
     }
-    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), sub_list_of(m, g->has_plan ? g->plan.max_o + 1 : 2, g->sub_index, g->sub_word, g->sub_ctl), st,
+    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), sub_list_of(m, g->has_plan ? g->t_max : 2, g->sub_index, g->sub_word, g->sub_ctl), st,
                       &g->last_kernel, g));
     g->last_kernel_id = kern;
     if (e1)
@@ -1939,7 +2108,7 @@ int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, con
             // or the sum of a whole count-less tile (tail != 0, tiles.h) --, one log (25 flop) per
             // (counted key, q), prologue exps 25 per (o, s)
             const double n_ce = (double)(g->plan.ce_end - g->plan.ce_begin);
-            const double max_o = (double)g->plan.max_o;
+            const double max_o = (double)(g->t_max - 1);
             const double rows = m->tail_is_zero ? bins : m->rows_contracted;
             const double logged = m->tail_is_zero ? bins : m->keys_logged;
             *flops = n_ce * (bins * S * max_o * 2.0 + rows * g->q_sum_t_minus_1 * 2.0 +

@@ -35,6 +35,13 @@ hipError_t launch_ll_finish_partials(const DevModel &m, const TileView &tv, cons
                                      const int32_t *first_item, const double *point_par, const int32_t *point_T,
                                      int64_t n_points, double *out_ll, hipStream_t stream);
 
+// Dense grids, long weight vectors (tiles.h FactoredPlan::list_mode 3): take the logs of the p_j that the chunk
+// launches summed into `partial` ([n_ce][n_cols][n_items * 32], first row = (c, e) number ce_first); q_orig[n_cols] maps
+// a slot to its index in the (q1, q2, q) product (-1: padding); values go to out_ll[flat - src.flat_begin].
+hipError_t launch_ll_finish_dense(const DevModel &m, const TileView &tv, const PointSource &src, const double *partial,
+                                  int64_t ce_first, int64_t n_ce, int64_t n_cols, const int32_t *q_orig, int64_t n_q,
+                                  int64_t flat_end, double *out_ll, hipStream_t stream);
+
 // The pass after every K-basic / K-factored launch: one wave per point of the queue `list` (direct_point.h) adds
 // the strict evaluation of the rows named in its side word to ll[], in place.  The queue's counter must be zero
 // before the NEXT recurrence launch: launch_argmin resets it (grids), the host does for point lists.

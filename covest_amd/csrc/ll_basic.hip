@@ -30,12 +30,13 @@ namespace covest {
 
 namespace {
 
-template <int S, bool TAIL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ll_basic_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
-                                                       const double *__restrict__ tile_dbl,
-                                                       const int32_t *__restrict__ tile_int,
-                                                       const PointSource src, const int64_t n,
-                                                       double *__restrict__ out_ll, SubList sub_list)
+// S: error classes, padded to a multiple of 8 (comb = 0 beyond the model's: such a class weighs exactly 0); BD: threads
+// per workgroup.  The per-lane anchors of the recurrence live in dynamic LDS: 16 S BD bytes.
+template <int S, bool TAIL, int BD>
+__device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n_tiles, const int32_t n_items,
+                                              const double *__restrict__ tile_dbl, const int32_t *__restrict__ tile_int,
+                                              const PointSource &src, const int64_t n, double *__restrict__ out_ll,
+                                              const SubList &sub_list)
 {
     const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
     __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
@@ -55,10 +56,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int s = 0; s < S; ++s)
         lam[s] = error_class_rate(m, par[0], par[1], s);
-    __shared__ double anchors[2 * S * 256]; // [2S][lane of the workgroup]: conflict-free columns
+    extern __shared__ double anchors[]; // [2S][lane of the workgroup]: conflict-free columns
     StreamSet<S, LdsAnchors<S>> st;
     st.an.mine = anchors + threadIdx.x;
-    st.an.stride = 256;
+    st.an.stride = BD;
     st.init(m, lam, 1, finite, log_tab, log_tab);
 
     double acc_ll = 0.0;
@@ -174,6 +175,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// The case the reference's `main` builds (max_error = 8): 4 waves per SIMD at 128 registers.
+template <bool TAIL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ll_basic_kernel(
+    const DevModel m, const int32_t n_tiles, const int32_t n_items, const double *__restrict__ tile_dbl,
+    const int32_t *__restrict__ tile_int, const PointSource src, const int64_t n, double *__restrict__ out_ll,
+    SubList sub_list)
+{
+    ll_basic_body<8, TAIL, 256>(m, n_tiles, n_items, tile_dbl, tile_int, src, n, out_ll, sub_list);
+}
+
+// More error classes (max_error = k + 1 = 22 when a model is built directly, covest/models.py:28-31): the same walk
+// with 16, 24 or 32 streams per lane -- more registers, one wave per workgroup.
+template <int S, bool TAIL>
+__global__ __launch_bounds__(64) void ll_basic_wide_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
+                                                           const double *__restrict__ tile_dbl,
+                                                           const int32_t *__restrict__ tile_int, const PointSource src,
+                                                           const int64_t n, double *__restrict__ out_ll, SubList sub_list)
+{
+    ll_basic_body<S, TAIL, 64>(m, n_tiles, n_items, tile_dbl, tile_int, src, n, out_ll, sub_list);
+}
+
+template <int S>
+void launch_wide(bool tail, dim3 grid, hipStream_t stream, const DevModel &m, const TileView &tv, const PointSource &part,
+                 int64_t cnt, double *out, const SubList &sl)
+{
+    const size_t lds = (size_t)2 * S * 64 * sizeof(double);
+    if (tail)
+        hipLaunchKernelGGL((ll_basic_wide_kernel<S, true>), grid, dim3(64), lds, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+                           tv.int_base, part, cnt, out, sl);
+    else
+        hipLaunchKernelGGL((ll_basic_wide_kernel<S, false>), grid, dim3(64), lds, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+                           tv.int_base, part, cnt, out, sl);
+}
+
 } // namespace
 
 hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSource &src, int64_t n,
@@ -181,14 +216,16 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
 {
     if (n <= 0)
         return hipSuccess;
-    if (m.n_err != 8 || m.kind != 0)
+    if (m.n_err > 32 || m.kind != 0)
         return hipErrorInvalidValue;
+    const int s_pad = ((m.n_err + 7) / 8) * 8;
+    const int bd = s_pad == 8 ? 256 : 64;
     // HIP wraps a grid of more than 2^32 threads silently: at most 2^23 workgroups per launch
-    const dim3 block(256);
-    const int64_t per_launch = (int64_t)256 << 23;
+    const dim3 block(bd);
+    const int64_t per_launch = (int64_t)bd << 23;
     for (int64_t first = 0; first < n; first += per_launch) {
         const int64_t cnt = n - first < per_launch ? n - first : per_launch;
-        const dim3 grid((unsigned)((cnt + 255) / 256));
+        const dim3 grid((unsigned)((cnt + bd - 1) / bd));
         PointSource part = src;
         SubList sl = sub_list;
         sl.index_offset = first;
@@ -196,11 +233,18 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
             part.flat_begin = src.flat_begin + first;
         else
             part.params = src.params + first * 2;
-        if (m.tail != 0.0)
-            hipLaunchKernelGGL((ll_basic_kernel<8, true>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+        const size_t lds8 = (size_t)2 * 8 * 256 * sizeof(double);
+        if (s_pad == 16)
+            launch_wide<16>(m.tail != 0.0, grid, stream, m, tv, part, cnt, out_ll + first, sl);
+        else if (s_pad == 24)
+            launch_wide<24>(m.tail != 0.0, grid, stream, m, tv, part, cnt, out_ll + first, sl);
+        else if (s_pad == 32)
+            launch_wide<32>(m.tail != 0.0, grid, stream, m, tv, part, cnt, out_ll + first, sl);
+        else if (m.tail != 0.0)
+            hipLaunchKernelGGL((ll_basic_kernel<true>), grid, block, lds8, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
                                tv.int_base, part, cnt, out_ll + first, sl);
         else
-            hipLaunchKernelGGL((ll_basic_kernel<8, false>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+            hipLaunchKernelGGL((ll_basic_kernel<false>), grid, block, lds8, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
                                tv.int_base, part, cnt, out_ll + first, sl);
     }
     return hipGetLastError();

@@ -115,26 +115,41 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int64_t ce = plan.ce_begin + unit;
     // (list mode: workgroup i takes point i of a point list -- its own (c, e) AND its own single weight
     // vector, see tiles.h FactoredPlan::list_mode)
-    const bool list = plan.list_mode != 0;
+    const bool list = plan.list_mode == 1 || plan.list_mode == 2; // (3 is a dense grid's chunk: addressed like mode 0)
     const int64_t ic = list ? ce : ce / plan.n_e;
     const int64_t ie = list ? ce : ce - ic * plan.n_e;
     double par[kMaxParams] = {plan.c_axis[ic], plan.e_axis[ie], 0, 0, 0};
     clamp_point<2>(m, par);
     const bool finite = isfinite(par[0]) && isfinite(par[1]);
-    if (tid < 8)
+    // the rates of ALL error classes (padded to a multiple of 8; comb = 0 beyond the model's: such a class weighs 0)
+    const int n_pass = plan.n_pass; // lanes per copy number: one per 8 error classes (1 when max_error <= 8)
+    if (tid < 8 * n_pass)
         Gs[tid] = error_class_rate(m, par[0], par[1], tid);
     __syncthreads();
+
+    // ---- phase-A state: lane = (pass, copy number): column pass * pass_stride + (o - o_base - 1) of G ----
+    // With more than 8 error classes a copy number's classes are dealt to n_pass lanes, 8 each, whose columns the
+    // contraction treats as extra copy numbers with the same weight: sum_s a_os TP = sum over the passes' partial sums.
+    const int my_pass = n_pass == 1 ? 0 : tid / plan.pass_stride;
+    const int o_local = n_pass == 1 ? tid : tid - my_pass * plan.pass_stride; // 0-based inside the chunk
+    const bool wave_builds = wave * kWave < plan.n_columns; // wave-uniform
+    // chunked point list (list_mode 2): copy numbers before the chunk per item; dense chunks (3): one for the launch
+    const int o_base = plan.list_mode == 2 ? plan.item_obase[ce] : plan.o_base;
+    const int o_mine = o_base + o_local + 1;
     double lam[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s)
-        lam[s] = Gs[s];
+        lam[s] = Gs[8 * my_pass + s];
+    double n_total = -1.0;
+    if (n_pass > 1) { // the mixture weights a_os are normalised over ALL classes: covest/models.py:225-233
+        n_total = 0.0;
+        for (int s = 0; s < 8 * n_pass; ++s)
+            n_total += m.comb[s] * (1.0 - exp_neg_rn((double)o_mine * Gs[s]));
+    }
     __syncthreads();
-
-    // ---- phase-A state: lane = copy number o = tid + 1 ----
-    const bool wave_builds = wave * kWave < plan.max_o; // wave-uniform
     StreamSet<8> st;
-    const int o_base = plan.list_mode == 2 ? plan.item_obase[ce] : 0; // chunked point list: tiles.h
-    st.init(m, lam, o_base + tid + 1, finite && wave_builds && (tid + 1) <= plan.max_o, log_tab);
+    st.init(m, lam, o_mine, finite && wave_builds && my_pass < n_pass && o_local < plan.max_o, log_tab, nullptr,
+            8 * my_pass, n_total);
     const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
     if (tid < 64)
         Gs[(size_t)plan.n_buf * kTileBins * LD + tid] = 0.0; // the slack behind the buffers (see launch)
@@ -170,9 +185,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         cont[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_cont[at] : 0);
         uhalf[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_half[at] : 0);
         a_off[k] = (16 * uhalf[k] + col) * LD + kq + 4 * first_step; // this lane's A fragment inside a G buffer
-        // iterations of the piece during which this lane's o = 1 + 4 (first_step + i) + kq is below T
+        // iterations of the piece during which this lane's copy number o0 + 4 i + kq (o0: the piece's first one,
+        // counted from the chunk's start) is below T (the chunk's local one)
         const int t_lane = on ? plan.q_T[slot] : 0;
-        cut[k] = (t_lane - (1 + 4 * first_step + kq) + 3) >> 2;
+        const int o0 = __builtin_amdgcn_readfirstlane(on ? plan.unit_o0[at] : 1);
+        cut[k] = (t_lane - (o0 + kq) + 3) >> 2;
         r4[k] = plan.q_r4[slot];
         llacc[k] = 0.0;
         dead[k] = 0;
@@ -377,6 +394,18 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
                 continue;
             }
+            if (plan.list_mode == 3) { // a chunk of the copy numbers of a dense grid's LONG weight vectors: every
+                                       // column's share of p_j goes to (the first chunk) or is added to the block's
+                                       // buffer in HBM; ll_finish_dense takes the logs.  Each element has one owner.
+                if (qslot[k] >= 0 && !cont[k]) {
+                    double *row = plan.partial + (((ce - plan.ce_first) * plan.n_cols_partial + qslot[k]) * tv.n_items + t) * kTileBins +
+                                  16 * uhalf[k] + kq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        row[4 * r] = plan.o_base == 0 ? acc[k][r] : row[4 * r] + acc[k][r];
+                }
+                continue;
+            }
             if (TAIL && item_is_sum) { // rows are sums over count-less tiles: they only enter sp_j
                 if (qslot[k] >= 0 && !cont[k]) {
 #pragma unroll
@@ -399,9 +428,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
                 if (__builtin_expect(((low[0] | low[1] | low[2] | low[3]) & ~dead[k]) != 0, 0)) {
                     // wave-uniform, cold (a lane that is dead already has nothing more to report).  Kept SHORT: a
-                    // wave in here holds up its whole workgroup at the tile's barrier, and each of its vector
-                    // instructions queues behind the partner wave's MFMAs
-                    __builtin_amdgcn_s_setprio(3);
+                    // wave in here holds up its whole workgroup at the tile's barrier
                     uint64_t subm = 0, zero = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -424,7 +451,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                         rec[0] = min(rec[0], u);
                         rec[1] = max(rec[1], u + 1);
                     }
-                    __builtin_amdgcn_s_setprio(0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -454,8 +480,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         d[4] = dg_b0;
     }
 #undef STAMP
-    if (plan.list_mode == 2)
-        return; // (wave-uniform for the whole workgroup) the chunks are combined by ll_finish_partials
+    if (plan.list_mode >= 2)
+        return; // (wave-uniform for the whole workgroup) the chunks are combined by ll_finish_partials / _dense
     // ---- per-q results: sum the 4 row groups of the accumulator layout, then the two
     //      halves of each q-tile (they may live on different waves) through LDS ----
     double *part_ll = Gs;                               // [NW][MU][16]
@@ -554,45 +580,32 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
 }
 
-// Chunked point list (tiles.h list_mode 2): one wave per point adds the chunks' shares of p_j in chunk order
-// and takes the logs.  LL = sum_j h_j log p_j + tail log(1 - sp), covest/models.py:100-107.  A subnormal p_j at a
-// key with h_j != 0 is replaced on the spot by its strict evaluation (direct_point.h: the whole wave, K-direct's
-// arithmetic).  point_par[5 n_points], point_T[n_points]: the points' parameters and threshold_o.
-__global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, const int32_t n_tiles, const int32_t n_items,
-                                                           const double *__restrict__ tile_dbl,
-                                                           const int32_t *__restrict__ tile_int,
-                                                           const double *__restrict__ partial,
-                                                           const int32_t *__restrict__ first_item,
-                                                           const double *__restrict__ point_par,
-                                                           const int32_t *__restrict__ point_T, double *__restrict__ out_ll)
+// One wave finishes ONE point whose p_j lie in HBM, summed over chunks of copy numbers (tiles.h list modes 2, 3):
+// LL = sum_j h_j log p_j + tail log(1 - sp), covest/models.py:100-107.  read_pj(row): the p_j of row `row` of the
+// items (tiles.h: a key, or the sum over a count-less tile).  A subnormal p_j at a key with h_j != 0 is replaced on
+// the spot by its strict evaluation (direct_point.h: the whole wave, K-direct's arithmetic).  par: the point's
+// parameters, clamped; every lane returns the value.
+template <class ReadPj>
+__device__ __forceinline__ double finish_point(const DevModel &m, const TileView &tv, const double *par, int T,
+                                               ReadPj read_pj)
 {
-    const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
-    const int p = blockIdx.x, lane = threadIdx.x;
-    const int c0 = first_item[p], c1 = first_item[p + 1];
-    const int64_t n_keys = (int64_t)n_items * kTileBins; // rows of the items: keys, or per-tile sums (tiles.h)
-    double par[kMaxParams];
-#pragma unroll
-    for (int d = 0; d < kMaxParams; ++d)
-        par[d] = point_par[(int64_t)p * kMaxParams + d];
-    clamp_point<5>(m, par);
-    const int T = point_T[p];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t n_rows = (int64_t)tv.n_items * kTileBins;
     double ll = 0.0;
     bool dead = false, poisoned = false;
     CompSum sp = {0.0, 0.0};
-    for (int64_t base = 0; base < n_keys; base += kWave) { // wave-uniform trip count
-        const int64_t key = base + lane;
-        const bool valid = key < n_keys;
-        double pj = 0.0;
-        for (int c = c0; c < c1; ++c)
-            pj += valid ? partial[(int64_t)c * n_keys + key] : 0.0;
-        const double h = valid ? tv.item_cnt[key] : 0.0;
+    for (int64_t base = 0; base < n_rows; base += kWave) { // wave-uniform trip count
+        const int64_t row = base + lane;
+        const bool valid = row < n_rows;
+        double pj = valid ? read_pj(row) : 0.0;
+        const double h = valid ? tv.item_cnt[row] : 0.0;
         uint64_t sub = __ballot(h != 0.0 && pj > 0.0 && pj < 2.2250738585072014e-308); // a subnormal p_j
         while (sub) { // wave-uniform, rare
             const int who = __builtin_ctzll(sub);
             sub &= sub - 1;
-            const int64_t row = base + who;
-            const int item = (int)(row / kTileBins);
-            const int bin = tv.row_bin[(int64_t)tv.item_first[item] * kTileBins + (row - (int64_t)item * kTileBins)];
+            const int64_t r = base + who;
+            const int item = (int)(r / kTileBins);
+            const int bin = tv.row_bin[(int64_t)tv.item_first[item] * kTileBins + (r - (int64_t)item * kTileBins)];
             const double strict = strict_pj_wave<5>(m, par, T, m.bins.key[bin], -m.bins.lgam[bin]);
             if (lane == who)
                 pj = strict;
@@ -619,8 +632,65 @@ __global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, co
     double v = ll + tail_term;
     if (__ballot(poisoned) || !(isfinite(par[0]) && isfinite(par[1])))
         v = NAN;
-    if (lane == 0)
+    return v;
+}
+
+// Chunked point list (tiles.h list_mode 2): one wave per point adds the chunks' shares of p_j in chunk order and
+// takes the logs.  point_par[5 n_points], point_T[n_points]: the points' parameters and threshold_o.
+__global__ __launch_bounds__(kWave) void ll_finish_partials(const DevModel m, const int32_t n_tiles, const int32_t n_items,
+                                                           const double *__restrict__ tile_dbl,
+                                                           const int32_t *__restrict__ tile_int,
+                                                           const double *__restrict__ partial,
+                                                           const int32_t *__restrict__ first_item,
+                                                           const double *__restrict__ point_par,
+                                                           const int32_t *__restrict__ point_T, double *__restrict__ out_ll)
+{
+    const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
+    const int p = blockIdx.x;
+    const int c0 = first_item[p], c1 = first_item[p + 1];
+    const int64_t n_rows = (int64_t)n_items * kTileBins;
+    double par[kMaxParams];
+#pragma unroll
+    for (int d = 0; d < kMaxParams; ++d)
+        par[d] = point_par[(int64_t)p * kMaxParams + d];
+    clamp_point<5>(m, par);
+    const double v = finish_point(m, tv, par, point_T[p], [&](int64_t row) {
+        double pj = 0.0;
+        for (int c = c0; c < c1; ++c)
+            pj += partial[(int64_t)c * n_rows + row];
+        return pj;
+    });
+    if (threadIdx.x == 0)
         out_ll[p] = v;
+}
+
+// The long weight vectors of a dense grid (tiles.h list_mode 3: threshold_o beyond a workgroup's lanes): one wave
+// per ((c, e), slot) takes the logs of the p_j the chunk launches summed into `partial`.
+__global__ __launch_bounds__(kWave) void ll_finish_dense(const DevModel m, const int32_t n_tiles, const int32_t n_items,
+                                                        const double *__restrict__ tile_dbl,
+                                                        const int32_t *__restrict__ tile_int, const PointSource src,
+                                                        const double *__restrict__ partial, const int64_t ce_first,
+                                                        const int64_t n_cols, const int32_t *__restrict__ q_orig,
+                                                        const int64_t n_q, const int64_t flat_end,
+                                                        double *__restrict__ out_ll)
+{
+    const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
+    const int64_t ce_local = blockIdx.x / n_cols, slot = blockIdx.x - ce_local * n_cols;
+    const int32_t qo = q_orig[slot];
+    if (qo < 0)
+        return; // padding column
+    const int64_t flat = (ce_first + ce_local) * n_q + qo;
+    if (flat < src.flat_begin || flat >= flat_end)
+        return; // (ragged block ends)
+    double par[kMaxParams];
+    int T;
+    fetch_point<5>(src, flat - src.flat_begin, par, T);
+    clamp_point<5>(m, par);
+    const int64_t n_rows = (int64_t)n_items * kTileBins;
+    const double *mine = partial + (ce_local * n_cols + slot) * n_rows;
+    const double v = finish_point(m, tv, par, T, [&](int64_t row) { return mine[row]; });
+    if (threadIdx.x == 0)
+        out_ll[flat - src.flat_begin] = v;
 }
 
 template <int NT, int HU, bool TAIL>
@@ -681,12 +751,27 @@ hipError_t launch_ll_finish_partials(const DevModel &m, const TileView &tv, cons
     return hipGetLastError();
 }
 
+hipError_t launch_ll_finish_dense(const DevModel &m, const TileView &tv, const PointSource &src, const double *partial,
+                                  int64_t ce_first, int64_t n_ce, int64_t n_cols, const int32_t *q_orig, int64_t n_q,
+                                  int64_t flat_end, double *out_ll, hipStream_t stream)
+{
+    // HIP wraps a grid of more than 2^32 threads silently: at most 2^24 waves per launch
+    const int64_t per_launch = std::max<int64_t>(1, ((int64_t)1 << 24) / n_cols);
+    for (int64_t first = 0; first < n_ce; first += per_launch) {
+        const int64_t cnt = std::min(per_launch, n_ce - first);
+        hipLaunchKernelGGL(ll_finish_dense, dim3((unsigned)(cnt * n_cols)), dim3(kWave), 0, stream, m, tv.n_tiles, tv.n_items,
+                           tv.dbl_base, tv.int_base, src, partial + first * n_cols * (int64_t)tv.n_items * kTileBins,
+                           ce_first + first, n_cols, q_orig, n_q, flat_end, out_ll);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                               double *out_ll, const SubList &sub_list, hipStream_t stream)
 {
     if (plan.ce_end <= plan.ce_begin)
         return hipSuccess;
-    if (m.n_err != 8 || m.kind != 1 || plan.max_o > plan.n_threads)
+    if (m.kind != 1 || plan.n_columns > plan.n_threads || 8 * plan.n_pass < m.n_err)
         return hipErrorInvalidValue;
     if (plan.n_threads == 256 && plan.half_units == 3)
         return launch_nt<256, 3>(m, tv, plan, out_ll, sub_list, stream);

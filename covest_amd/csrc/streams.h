@@ -69,17 +69,22 @@ struct StreamSet {
     // device library's cost -- the prologue is 8 streams x (2 logs + exp + the normaliser) per lane.
     // `norm_tab`: the same table for the two logs inside the normaliser, or nullptr for the device library's
     // (K-factored: the shorter code there costs it more in register allocation than it saves -- measured).
+    // `s0`, `total`: this set holds the error classes s0 .. s0 + S - 1 of a model with MORE than S of them (the
+    // classes of one copy number are then dealt to several lanes, ll_factored.hip); `total` is the sum of n_os over
+    // ALL the model's classes, in s order -- a negative value means: the S classes here are all there are.
     __device__ __forceinline__ void init(const DevModel &m, const double *lam, int o, bool live, const double *log_tab,
-                                         const double *norm_tab = nullptr)
+                                         const double *norm_tab = nullptr, int s0 = 0, double total = -1.0)
     {
         double n_os[S];
         double tot = 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             x[s] = (double)o * lam[s];
-            n_os[s] = m.comb[s] * (1.0 - exp_neg_rn(x[s]));
+            n_os[s] = m.comb[s0 + s] * (1.0 - exp_neg_rn(x[s]));
             tot += n_os[s]; // naive sum in s order
         }
+        if (total >= 0.0)
+            tot = total;
         if (tot == 0.0)
             tot = 1.0; // fix_zero
 #pragma unroll

@@ -98,7 +98,11 @@ struct FactoredPlan {
     int64_t ce_begin, ce_end;      // (c, e) pairs this block covers
     int64_t n_q;                   // Q
     int32_t n_qtiles;              // ceil(Q / 16)
-    int32_t max_o;                 // max threshold_o - 1: copy numbers to build
+    int32_t max_o;                 // copy numbers to build (of this chunk): max LOCAL threshold_o - 1
+    int32_t n_pass;                // lanes per copy number: ceil(max_error / 8); each takes 8 error classes
+    int32_t pass_stride;           // columns of G per pass (max_o rounded up to a multiple of 4)
+    int32_t n_columns;             // n_pass * pass_stride (n_pass == 1: max_o): columns of G that are built
+    int32_t o_base;                // list_mode 3: copy numbers before this launch's chunk
     int32_t n_threads;             // workgroup size the unit tables were built for (256, 512 or 768)
     int32_t half_units;            // unit slots per wave and half (kHalfUnits, or 2 with 768 threads)
     int32_t n_qblocks;             // workgroups per (c, e) (gridDim.y); each rebuilds G
@@ -107,7 +111,8 @@ struct FactoredPlan {
     // per accumulator slot, [n_qblocks][n_threads/64][kMaxUnits], sorted by length within a wave:
     const int32_t *unit_tile;      // q-tile of the slot, -1 = none
     const int32_t *unit_half;      // 0 = keys 0..15 of the key tile, 1 = keys 16..31
-    const int32_t *unit_s0;        // first MFMA step of the slot's piece
+    const int32_t *unit_s0;        // first MFMA step of the slot's piece (a step = 4 columns of G)
+    const int32_t *unit_o0;        // the copy number (1-based inside the chunk) of that step's first column
     const int32_t *unit_len;       // steps of the piece (equal for all pieces of a unit; steps past the
                                    //   unit's end are masked by the T cut-off)
     const int32_t *unit_cont;      // 1 = this slot continues the unit of the slot before it
@@ -120,7 +125,8 @@ struct FactoredPlan {
     const double *q_first8;        // [8][n_qtiles*16] b_o, o = 1..8   (covest/models.py:193-208)
     const double *q_r4;            // [n_qtiles*16] (1 - q)^4
     int64_t flat_begin, flat_end;  // flat indices whose LL is written (ragged block ends)
-    int32_t list_mode;             // 1, 2: a POINT LIST, not a grid: workgroup i (gridDim.y == 1) evaluates ITEM i =
+    int32_t list_mode;             // 3: a dense grid's long weight vectors, one chunk of copy numbers (see partial).
+                                   // 1, 2: a POINT LIST, not a grid: workgroup i (gridDim.y == 1) evaluates ITEM i =
                                    //   (c_axis[i], e_axis[i]) with the single weight vector of q-tile i (slot 16 i;
                                    //   n_q == 1).  The unit tables then hold one empty wave block followed by two
                                    //   blocks per item, for the workgroup's last two waves (ll_factored.hip).
@@ -134,8 +140,12 @@ struct FactoredPlan {
                                    //   like a run (streams anchored).  list_mode 1 then writes {LL part, sp part hi, lo}
                                    //   per (point, segment) to `partial` and the host adds the segments in order
     const int32_t *item_obase;     // [units] list_mode 2: copy numbers before this chunk (multiple of 512); else NULL
-    double *partial;               // list_mode 2: [units][n_tiles * 32] sum over the chunk's o of b_o G[o][key];
-                                   //   list_mode 1: [points][n_seg][3]
+    double *partial;               // list_mode 2: [units][n_items * 32] sum over the chunk's o of b_o G[o][key];
+                                   //   list_mode 1: [points][n_seg][4]
+                                   //   list_mode 3: [ce - ce_first][n_cols_partial][n_items * 32] p_j of the grid's long
+                                   //   weight vectors (threshold_o beyond a workgroup's lanes), summed chunk by chunk
+    int64_t ce_first;              // list_mode 3: the (c, e) of partial's first row
+    int64_t n_cols_partial;        // list_mode 3: weight-vector slots per (c, e) in partial
     long long *diag;               // PROFILING ONLY (env COVEST_FACTORED_DIAG): per-wave s_memtime sums [wg][wave][8]
     int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
 };

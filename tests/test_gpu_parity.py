@@ -115,7 +115,7 @@ def test_golden_loglikelihood(hip_lib, oracle, kind, fname):
         n_slack += _slack_budget("golden %s #%d" % (kind, g["cases"].index(case)), slack)
         worst = max(worst, _check(got, case["ll"], "%s %s tail=%s S=%s" % (
             kind, case["hist"], case["tail"], case["max_error"]), slack=slack))
-        if kind == "basic" and case["max_error"] == 8:  # the recurrence kernel (K-basic) on the same points
+        if kind == "basic":  # the recurrence kernel (K-basic) on the same points: 8, 22 (= k + 1) and 5 error classes
             fast = m.loglikelihood_points(np.array(case["points"]), kernel="recur")
             worst = max(worst, _check(fast, case["ll"], "recur %s tail=%s" % (case["hist"], case["tail"]),
                                       slack=slack))
@@ -376,12 +376,36 @@ def test_factored_plan_shapes(hip_lib, oracle):
         # few vectors, small T: the 256-thread workgroup
         ("256 threads", 0, [np.array([5.0, 9.0]), np.array([0.03]), np.linspace(0.4, 0.9, 4),
                             np.array([0.5]), np.linspace(0.3, 0.9, 8)]),
+        # what optimize_grid walks into (covest/grid.py:23-26: q down to 0.01): threshold_o up to ~1500, far beyond a
+        # workgroup's 512 lanes -- the long weight vectors go chunk by chunk of copy numbers, the short ones
+        # (q = 0.2, 0.6) stay on the one-launch path, in the same grid
+        ("chunks of copy numbers", 3, [np.array([0.8, 1.5]), np.array([0.02]), np.array([0.5, 0.9]),
+                                       np.array([0.3]), np.array([0.0105, 0.012, 0.02, 0.05, 0.2, 0.6])]),
+        # ... and a grid of long vectors only
+        ("long vectors only", 0, [np.array([1.1]), np.array([0.01, 0.04]), np.array([0.6]), np.array([0.5]),
+                                  np.array([0.0103, 0.0107, 0.011])]),
+        # max_error = k + 1 = 22, the default of a model built directly (covest/models.py:28-31): a copy number's
+        # error classes are dealt to three lanes
+        ("22 error classes", 7, [np.array([8.0, 20.0]), np.array([0.02, 0.2, 0.45]), np.linspace(0.3, 0.9, 3),
+                                 np.array([0.2, 0.7]), np.array([0.06, 0.2, 0.5, 0.9]), 22]),
+        # ... with long vectors on top (chunks of 168 copy numbers), and 12 classes (two lanes)
+        ("22 classes, chunks", 0, [np.array([1.2]), np.array([0.05]), np.array([0.7]), np.array([0.5]),
+                                   np.array([0.02, 0.03, 0.3]), 22]),
+        ("12 error classes", 0, [np.array([6.0]), np.array([0.1, 0.4]), np.array([0.5, 0.8]), np.array([0.5]),
+                                 np.linspace(0.1, 0.9, 5), 12]),
+        ("5 error classes", 2, [np.array([6.0, 30.0]), np.array([0.1]), np.array([0.5, 0.8]), np.array([0.5]),
+                                np.linspace(0.1, 0.9, 5), 5]),
     ]
-    for name, tail, axes in cases:
-        m = RepeatsModel(21, 100, hist, tail, max_error=8)
-        om = oracle.OracleModel("repeats", 21, 100, hist, tail, max_error=8)
+    for case in cases:
+        name, tail, axes = case[0], case[1], case[2]
+        S = 8
+        if not isinstance(axes[-1], np.ndarray):
+            S, axes = axes[-1], axes[:-1]
+        m = RepeatsModel(21, 100, hist, tail, max_error=S)
+        om = oracle.OracleModel("repeats", 21, 100, hist, tail, max_error=S)
         fac = DenseGrid(m, axes)
         fac.evaluate(kernel="factored")
+        assert fac.work()[2] == "ll_factored"
         ll = fac.loglikelihoods()
         ref = DenseGrid(m, axes)
         ref.evaluate(kernel="direct")
