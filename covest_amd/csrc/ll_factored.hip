@@ -74,7 +74,9 @@ __device__ __forceinline__ void contract_step(int i, const double *cur, const in
     }
 }
 
-template <int NT, int HU, bool TAIL>
+// PLAIN: the shape every dense grid of the reference's own set-up has -- list_mode 0, at most 8 error classes (one
+// lane per copy number) -- compiled on its own so that the other modes' code costs it no registers.
+template <int NT, int HU, bool TAIL, bool PLAIN>
 __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                          const double *__restrict__ tile_dbl,
                                                          const int32_t *__restrict__ tile_int,
@@ -101,13 +103,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const double p_clamp = plan.p_clamp; // direct_point.h
+    const int list_mode = PLAIN ? 0 : plan.list_mode;
 
     // ---- the (c, e) of this workgroup ----
     // list mode: workgroup = (unit, key segment); a unit is a point or a chunk of a point's copy numbers, the
     // key tiles are cut into n_seg contiguous segments so that even ONE point spreads over several CUs
-    const int n_seg = plan.list_mode ? plan.n_seg : 1;
-    const int unit = plan.list_mode ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
-    const int seg = plan.list_mode ? (int)blockIdx.x - unit * n_seg : 0;
+    const int n_seg = list_mode ? plan.n_seg : 1;
+    const int unit = list_mode ? (int)blockIdx.x / n_seg : (int)blockIdx.x;
+    const int seg = list_mode ? (int)blockIdx.x - unit * n_seg : 0;
     // (the loop below walks ITEMS, tiles.h: a plain tile, or up to 32 all-zero-count tiles summed -- the latter
     // only exist with a tail; without one item i is tile i)
     const int seg_items = (n_items + n_seg - 1) / n_seg;
@@ -115,14 +118,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int64_t ce = plan.ce_begin + unit;
     // (list mode: workgroup i takes point i of a point list -- its own (c, e) AND its own single weight
     // vector, see tiles.h FactoredPlan::list_mode)
-    const bool list = plan.list_mode == 1 || plan.list_mode == 2; // (3 is a dense grid's chunk: addressed like mode 0)
+    const bool list = list_mode == 1 || list_mode == 2; // (3 is a dense grid's chunk: addressed like mode 0)
     const int64_t ic = list ? ce : ce / plan.n_e;
     const int64_t ie = list ? ce : ce - ic * plan.n_e;
     double par[kMaxParams] = {plan.c_axis[ic], plan.e_axis[ie], 0, 0, 0};
     clamp_point<2>(m, par);
     const bool finite = isfinite(par[0]) && isfinite(par[1]);
     // the rates of ALL error classes (padded to a multiple of 8; comb = 0 beyond the model's: such a class weighs 0)
-    const int n_pass = plan.n_pass; // lanes per copy number: one per 8 error classes (1 when max_error <= 8)
+    const int n_pass = PLAIN ? 1 : plan.n_pass; // lanes per copy number: one per 8 error classes (1 when max_error <= 8)
     if (tid < 8 * n_pass)
         Gs[tid] = error_class_rate(m, par[0], par[1], tid);
     __syncthreads();
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int o_local = n_pass == 1 ? tid : tid - my_pass * plan.pass_stride; // 0-based inside the chunk
     const bool wave_builds = wave * kWave < plan.n_columns; // wave-uniform
     // chunked point list (list_mode 2): copy numbers before the chunk per item; dense chunks (3): one for the launch
-    const int o_base = plan.list_mode == 2 ? plan.item_obase[ce] : plan.o_base;
+    const int o_base = PLAIN ? 0 : list_mode == 2 ? plan.item_obase[ce] : plan.o_base;
     const int o_mine = o_base + o_local + 1;
     double lam[8];
 #pragma unroll
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
-            if (plan.list_mode == 2) { // a chunk of a point's copy numbers: hand p_j's share on (column 0 only)
+            if (list_mode == 2) { // a chunk of a point's copy numbers: hand p_j's share on (column 0 only)
                 if (qslot[k] >= 0 && !cont[k] && col == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
                 continue;
             }
-            if (plan.list_mode == 3) { // a chunk of the copy numbers of a dense grid's LONG weight vectors: every
+            if (list_mode == 3) { // a chunk of the copy numbers of a dense grid's LONG weight vectors: every
                                        // column's share of p_j goes to (the first chunk) or is added to the block's
                                        // buffer in HBM; ll_finish_dense takes the logs.  Each element has one owner.
                 if (qslot[k] >= 0 && !cont[k]) {
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         d[4] = dg_b0;
     }
 #undef STAMP
-    if (plan.list_mode >= 2)
+    if (list_mode >= 2)
         return; // (wave-uniform for the whole workgroup) the chunks are combined by ll_finish_partials / _dense
     // ---- per-q results: sum the 4 row groups of the accumulator layout, then the two
     //      halves of each q-tile (they may live on different waves) through LDS ----
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 lo += part_lo[pe] + err;
             }
         }
-        if (plan.list_mode == 1) { // a key segment of a point: {LL part, sp_j part (hi, lo)}; the host adds the segments
+        if (list_mode == 1) { // a key segment of a point: {LL part, sp_j part (hi, lo)}; the host adds the segments
             if (plan.q_orig[qt * 16 + c] >= 0) {
                 double *o = plan.partial + ((int64_t)ce * n_seg + seg) * 4;
                 o[0] = finite ? ll : NAN;
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(kWave) void ll_finish_dense(const DevModel m, const
         out_ll[flat - src.flat_begin] = v;
 }
 
-template <int NT, int HU, bool TAIL>
+template <int NT, int HU, bool TAIL, bool PLAIN>
 hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                           double *out_ll, const SubList &sub_list, hipStream_t stream)
 {
@@ -710,7 +713,7 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         dev = 0;
     if (lds > configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ll_factored_kernel<NT, HU, TAIL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ll_factored_kernel<NT, HU, TAIL, PLAIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
@@ -724,7 +727,7 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
         part.ce_end = std::min(plan.ce_end, first + per_launch);
         const dim3 grid((unsigned)((part.ce_end - part.ce_begin) * (plan.list_mode ? plan.n_seg : 1)),
                         (unsigned)plan.n_qblocks);
-        hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.n_items,
+        hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL, PLAIN>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.n_items,
                            tv.dbl_base, tv.int_base, part, out_ll, sub_list);
     }
     return hipGetLastError();
@@ -734,8 +737,12 @@ template <int NT, int HU>
 hipError_t launch_nt(const DevModel &m, const TileView &tv, const FactoredPlan &plan, double *out_ll,
                      const SubList &sub_list, hipStream_t stream)
 {
-    return m.tail != 0.0 ? launch_nt_tail<NT, HU, true>(m, tv, plan, out_ll, sub_list, stream)
-                         : launch_nt_tail<NT, HU, false>(m, tv, plan, out_ll, sub_list, stream);
+    const bool plain = plan.list_mode == 0 && plan.n_pass == 1;
+    if (m.tail != 0.0)
+        return plain ? launch_nt_tail<NT, HU, true, true>(m, tv, plan, out_ll, sub_list, stream)
+                     : launch_nt_tail<NT, HU, true, false>(m, tv, plan, out_ll, sub_list, stream);
+    return plain ? launch_nt_tail<NT, HU, false, true>(m, tv, plan, out_ll, sub_list, stream)
+                 : launch_nt_tail<NT, HU, false, false>(m, tv, plan, out_ll, sub_list, stream);
 }
 
 } // namespace
