@@ -20,6 +20,7 @@ quoted on (repeat model, 10k-bin histogram):
   c5  (next row F1) canonical 21-mer histogram of synthetic reads, --kmer-gbp gigabases
   f2  (next row F2) the `-sp 20` L-BFGS-B multi-start refinement of the repeats model on H10k_rep
   f3  (next row F3) histogram down-sampling (K-thin) of H10k_rep by a factor of 2
+  og  covest.grid.optimize_grid end to end (the reference's consumer of batched evaluations): time-to-argmin
 Weak scaling (default): with N ranks the c axis has N times as many values over the same
 range and the flat index range is block-partitioned, one contiguous block of the
 single-GPU size per rank.  --scaling strong: ONE fixed grid, c3 refined to c128 x e128 x q1 16 x q 16 =
@@ -431,12 +432,60 @@ def tail_variant(cls, hist, axes, args, device, stream):
     return out
 
 
+def bench_optimize_grid(args):
+    """Workload og: the reference's actual consumer of batched evaluations -- covest.grid.optimize_grid
+    (covest/grid.py:17-79), repeats model, free (c, e, q1, q2, q).  Case A: the reference's own 15-bin test
+    histogram (its trace: 21 iterations of 3 888 - 7 776 points, 8.2 s on 8 processes).  Case B: the
+    same search on H10k_rep (981 counted keys) -- out of the reference's reach (~0.6 core-seconds per copy number and
+    point).  A step = one whole search: total time-to-argmin, with the split per iteration (grid handle + plan /
+    kernels / read-back of the values for the host-side scan)."""
+    from covest_amd import CoverageEstimator, RepeatsModel, optimize_grid
+    cases = [("sim_c10_e0.05 (15 keys)", "sim_c10_e0.05", [10.0, 0.05, 0.65, 0.5, 0.5]),
+             ("H10k_rep (981 counted keys)", "H10k_rep", [25.0, 0.02, 0.6, 0.5, 0.1])]
+    out_cases = []
+    for label, hname, guess in cases:
+        m = RepeatsModel(21, 100, load_hist(hname), 0, max_error=8)
+        est = CoverageEstimator(m)
+        est.likelihood_f(guess)  # module load, handle creation
+        walls, last = [], None
+        for rep in range(max(1, min(args.steps, 5)) + 1):
+            est.timings = []
+            t0 = time.perf_counter()
+            res = optimize_grid(est.likelihood_f, list(guess), bounds=est.bounds)
+            wall = time.perf_counter() - t0
+            if rep:  # the first search warms everything up
+                walls.append(wall)
+            last = (res, est.timings, optimize_grid.trace)
+        res, timings, trace = last
+        pts = sum(t["points"] for t in timings)
+        out_cases.append({
+            "histogram": label, "iterations": len(trace), "points_evaluated": pts,
+            "time_to_argmin_s": float(np.median(walls)), "evals_per_s": pts / float(np.median(walls)),
+            "split_ms": {"grid_handle_and_plan": 1e3 * sum(t["create_s"] for t in timings),
+                         "kernels": 1e3 * sum(t["eval_s"] for t in timings),
+                         "read_back": 1e3 * sum(t["readback_s"] for t in timings)},
+            "kernels_used": sorted(set(t["kernel"] for t in timings)),
+            "largest_grid": max(t["points"] for t in timings),
+            "result": [float(v) for v in res], "min_negll": float(trace[-1]["value"])})
+        m.close()
+    a = out_cases[0]
+    print(json.dumps({
+        "metric": "optimize_grid time-to-argmin (repeats model, 5 free parameters)", "value": a["evals_per_s"],
+        "unit": "evals/s", "n_gpus": 1, "steps": len(walls), "warmup": 1, "ms_per_step": 1e3 * a["time_to_argmin_s"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "OG: covest.grid.optimize_grid over CoverageEstimator.likelihood_f, each iteration's grid "
+                               "one batched evaluation"},
+        "cases": out_cases,
+        "reference": {"sim_c10_e0.05": "21 iterations, 8.2 s on 8 processes (SURVEY.md 3.2, measured in the survey container)"}}),
+        flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5", "f2", "f3"])
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5", "f2", "f3", "og"])
     ap.add_argument("--kmer-gbp", type=float, default=1.0, help="c5: gigabases of synthetic reads")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -453,6 +502,8 @@ def main():
         return bench_thin(args)
     if args.workload == "f2":
         return bench_refine(args)
+    if args.workload == "og":
+        return bench_optimize_grid(args)
 
     import torch
     import torch.distributed as dist

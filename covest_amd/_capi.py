@@ -22,7 +22,7 @@ EXPORTS = (
     "covest_abi_version", "covest_device_count", "covest_last_error",
     "covest_model_create", "covest_model_destroy", "covest_model_param_count",
     "covest_model_bins_evaluated", "covest_threshold_o", "covest_eval_points",
-    "covest_probabilities", "covest_reference_overflow", "covest_grid_create", "covest_grid_destroy", "covest_grid_size",
+    "covest_probabilities", "covest_reference_overflow", "covest_grid_create", "covest_grid_reset", "covest_grid_destroy", "covest_grid_size",
     "covest_grid_eval", "covest_grid_argmin", "covest_grid_argmin_pair_device", "covest_grid_ll_device",
     "covest_grid_ll_host",
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
@@ -98,6 +98,8 @@ def lib():
     L.covest_grid_create.restype = ctypes.c_int
     L.covest_grid_create.argtypes = [vp, i32, ctypes.POINTER(dp), ctypes.POINTER(i64), i64, i64,
                                      ctypes.POINTER(vp)]
+    L.covest_grid_reset.restype = ctypes.c_int
+    L.covest_grid_reset.argtypes = [vp, i32, ctypes.POINTER(dp), ctypes.POINTER(i64), i64, i64]
     L.covest_grid_destroy.restype = None
     L.covest_grid_destroy.argtypes = [vp]
     L.covest_grid_size.restype = i64

@@ -109,7 +109,14 @@ struct covest_grid {
     int64_t len[kMaxParams] = {1, 1, 1, 1, 1};
     int64_t flat_begin = 0, flat_end = 0;
     PointSource src{};
-    DevBuf axes, t_table, ll, sub_index, sub_word, sub_ctl, partial_val, partial_idx, result, plan_buf;
+    // one allocation (grown on demand, kept across covest_grid_reset) behind the fixed-purpose views below
+    DevBuf arena, plan_buf;
+    struct View {
+        void *ptr = nullptr;
+        template <class T> T *as() const { return static_cast<T *>(ptr); }
+        void release() { ptr = nullptr; }
+    };
+    View axes, t_table, ll, sub_index, sub_word, sub_ctl, partial_val, partial_idx, result;
     FactoredPlan plan{};        // K-factored work description (repeats model, dense grid): the weight vectors whose
                                 //   threshold_o fits a workgroup's lanes (build_factored_plan)
     bool has_plan = false;
@@ -206,6 +213,9 @@ class DeviceGuard {
   public:
     explicit DeviceGuard(int device)
     {
+        // (HIP keeps the last error of the thread until somebody reads it: whatever an earlier, unrelated call left
+        // behind must not be taken for a failure of the launches this entry point is about to make)
+        (void)hipGetLastError();
         had_prev_ = hipGetDevice(&prev_) == hipSuccess;
         if (had_prev_ && prev_ == device)
             return; // nothing to switch, nothing to restore
@@ -518,7 +528,13 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     const int nt = (n_columns <= 256 && n_units <= 4 * units_per_wave) ? 256 : 512;
     const int nw = nt / 64;
     const int cap_block = nw * units_per_wave;
-    const int n_qblocks = std::max(1, (n_units + cap_block - 1) / cap_block);
+    // workgroups per (c, e): as many as the units need -- and, for a grid with few (c, e) pairs (optimize_grid's
+    // have 36), enough to put the chip's 256 CUs to work: each rebuilds G, but they share the contraction and the logs
+    // (decided by the WHOLE grid's (c, e) count, not the block's: a point's value may not depend on how the grid was
+    // cut into blocks, and the assignment of units to waves fixes the order of its sums)
+    const int64_t n_ce_grid = std::max<int64_t>(1, g->len[0] * g->len[1]);
+    const int want_blocks = n_ce_grid >= 192 ? 1 : (int)std::min<int64_t>(n_qtiles, (256 + n_ce_grid - 1) / n_ce_grid);
+    const int n_qblocks = std::max(std::max(1, (n_units + cap_block - 1) / cap_block), want_blocks);
     // cost model of the assignment, in MFMA steps: a unit costs its steps (in every pass) plus its share of the
     // logs; a builder wave starts with the cost of phase A (tuned on C3 with the in-kernel stamps)
     const int unit_overhead = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD") ? std::atoi(std::getenv("COVEST_FACTORED_UNIT_OVERHEAD")) : kUnitOverhead;
@@ -601,20 +617,33 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     }
     // weights of every slot's first two MFMA steps, per lane (lane = 16 * (o mod 4) + column)
     std::vector<double> piece_w(n_unit * 2 * 64, 0.0);
+    // (eight consecutive copy numbers per slot and column: one libm pow, the rest by multiplication -- the kernel
+    // advances the weights the same way from the third step on; a grid with few (c, e) pairs has many slots)
     for (size_t at = 0; at < n_unit; ++at) {
         const int qt = unit_tile[at];
         if (qt < 0)
             continue;
-        for (int which = 0; which < 2; ++which)
-            for (int lane = 0; lane < 64; ++lane) {
-                const size_t gs = ((size_t)tile_lo + (size_t)qt) * 16 + (size_t)(lane & 15);
-                if (gs >= (size_t)nq)
-                    continue; // padding column
-                double q1, q2, q;
-                weights_of(gs, q1, q2, q);
-                const int o = o_base + unit_o0[at] + 4 * which + (lane >> 4);
-                piece_w[(at * 2 + (size_t)which) * 64 + (size_t)lane] = copy_number_weight_host(q1, q2, q, o);
+        for (int colx = 0; colx < 16; ++colx) {
+            const size_t gs = ((size_t)tile_lo + (size_t)qt) * 16 + (size_t)colx;
+            if (gs >= (size_t)nq)
+                continue; // padding column
+            double q1, q2, q;
+            weights_of(gs, q1, q2, q);
+            const int o_first = o_base + unit_o0[at];
+            const double head = (1 - q1) * (1 - q2) * q, base = 1 - q;
+            double geo = o_first >= 3 ? std::pow(base, (double)(o_first - 3)) : 1.0; // base^(o - 3) at o = max(o_first, 3)
+            for (int d = 0; d < 8; ++d) {
+                const int o = o_first + d;
+                double w;
+                if (o < 3) {
+                    w = copy_number_weight_host(q1, q2, q, o);
+                } else {
+                    w = head * geo;
+                    geo *= base;
+                }
+                piece_w[(at * 2 + (size_t)(d >> 2)) * 64 + (size_t)((d & 3) * 16 + colx)] = w;
             }
+        }
     }
     // one buffer: doubles first (r4 | piece_w), then int32 (q_T | q_orig | unit tables)
     const size_t n_dbl = n_slots + piece_w.size();
@@ -704,6 +733,8 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
 {
     covest_model *m = g->model;
     g->has_plan = false;
+    for (covest_grid::Part &part : g->long_parts)
+        part.buf.release();
     g->long_parts.clear();
     g->n_long_tiles = 0;
     if (!m->has_tiles || m->n_par != 5 || m->dm.n_err > 32)
@@ -1172,17 +1203,18 @@ static hipError_t launch_factored_grid(covest_grid *g, double *out, const SubLis
     return hipSuccess;
 }
 
-static SubList sub_list_of(const covest_model *m, int t_max, const DevBuf &index, const DevBuf &word, const DevBuf &ctl)
+static SubList sub_list_of(const covest_model *m, int t_max, void *index, void *word, void *ctl)
 {
     SubList l{};
     l.p_clamp = clamp_for(m, t_max);
     l.log_p_clamp = std::log(l.p_clamp);
-    l.count = ctl.as<unsigned>();
-    l.index = index.as<int64_t>();
-    l.word = word.as<unsigned long long>();
+    l.count = static_cast<unsigned *>(ctl);
+    l.index = static_cast<int64_t *>(index);
+    l.word = static_cast<unsigned long long *>(word);
     l.index_offset = 0;
     return l;
 }
+
 
 // `sub`: the queue the recurrence kernels append the points they hand back to (direct_point.h) -- drained right
 // behind them by the fix pass; K-direct has nothing to hand back.  The queue must be empty (counter 0) on entry.
@@ -1259,7 +1291,7 @@ static int fix_points_host(covest_model *m, int64_t n, const double *params, dou
     src.params = m->ws_params.as<double>();
     src.t_list = P == 5 ? m->ws_t.as<int32_t>() : nullptr;
     HIP_TRY(launch_ll_fix_list(m->dm, m->tv, src, m->ws_out.as<double>(),
-                               sub_list_of(m, m->n_par == 5 ? 513 : 2, m->ws_sub_index, m->ws_sub_word, m->ws_sub_ctl), nullptr));
+                               sub_list_of(m, m->n_par == 5 ? 513 : 2, m->ws_sub_index.ptr, m->ws_sub_word.ptr, m->ws_sub_ctl.ptr), nullptr));
     HIP_TRY(hipMemcpy(sub_ll.data(), m->ws_out.ptr, na * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < na; ++k)
         out_ll[again[k]] = sub_ll[k];
@@ -1295,7 +1327,7 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         if (qrc != COVEST_OK)
             return qrc;
     }
-    const SubList queue = sub_list_of(m, m->n_par == 5 ? 513 : 2, m->ws_sub_index, m->ws_sub_word, m->ws_sub_ctl);
+    const SubList queue = sub_list_of(m, m->n_par == 5 ? 513 : 2, m->ws_sub_index.ptr, m->ws_sub_word.ptr, m->ws_sub_ctl.ptr);
     PointSource src{};
     src.is_grid = 0;
     src.params = m->ws_params.as<double>();
@@ -1496,77 +1528,81 @@ int covest_probabilities(covest_model *m, const double *params, int32_t clamp, d
     return COVEST_OK;
 }
 
-int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axes,
-                       const int64_t *axis_len, int64_t flat_begin, int64_t flat_end,
-                       covest_grid **out)
+// Everything a grid handle holds besides its identity: called by covest_grid_create and covest_grid_reset.  Device
+// memory is only ever grown, and the small inputs (axes, threshold table, the queue's counter) go up in ONE copy:
+// optimize_grid re-configures a handle every iteration (21 times 0.2 ms of allocations and copies otherwise).
+static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *axes, const int64_t *axis_len,
+                          int64_t flat_begin, int64_t flat_end, const char *who)
 {
-    if (!m || !axes || !axis_len || !out)
-        return fail(COVEST_E_INVALID, "covest_grid_create: null argument");
-    *out = nullptr;
+    covest_model *m = g->model;
+    if (!axes || !axis_len)
+        return fail(COVEST_E_INVALID, std::string(who) + ": null argument");
     if (n_axes != m->n_par)
-        return fail(COVEST_E_INVALID, "covest_grid_create: n_axes must equal the model's param_count");
+        return fail(COVEST_E_INVALID, std::string(who) + ": n_axes must equal the model's param_count");
     int64_t total = 1, n_values = 0;
     for (int d = 0; d < n_axes; ++d) {
         if (axis_len[d] < 1 || !axes[d])
-            return fail(COVEST_E_INVALID, "covest_grid_create: every axis needs at least one value");
+            return fail(COVEST_E_INVALID, std::string(who) + ": every axis needs at least one value");
         if (total > (int64_t)1 << 40)
-            return fail(COVEST_E_INVALID, "covest_grid_create: grid too large");
+            return fail(COVEST_E_INVALID, std::string(who) + ": grid too large");
         total *= axis_len[d];
         n_values += axis_len[d];
     }
     if (flat_end < 0)
         flat_end = total;
     if (flat_begin < 0 || flat_begin > flat_end || flat_end > total)
-        return fail(COVEST_E_INVALID, "covest_grid_create: bad flat index range");
-
-    covest_grid *g = new (std::nothrow) covest_grid();
-    if (!g)
-        return fail(COVEST_E_NOMEM, "covest_grid_create: out of host memory");
-    g->model = m;
+        return fail(COVEST_E_INVALID, std::string(who) + ": bad flat index range");
     g->flat_begin = flat_begin;
     g->flat_end = flat_end;
+    g->evaluated = false;
+    g->ev_used = 0;
     const int64_t n = flat_end - flat_begin;
+    const int64_t n1 = n_axes == 5 ? axis_len[2] : 1, n2 = n_axes == 5 ? axis_len[3] : 1, n3 = n_axes == 5 ? axis_len[4] : 1;
+    const int64_t nq = n_axes == 5 ? n1 * n2 * n3 : 0;
 
-    std::lock_guard<std::mutex> guard(m->lock);
-    DeviceGuard dev_guard(m->device);
-    int rc = dev_guard.status();
-    auto bail = [&](int code) {
-        g->axes.release();
-        g->t_table.release();
-        g->ll.release();
-        g->sub_index.release();
-        g->sub_word.release();
-        g->sub_ctl.release();
-        g->partial_val.release();
-        g->partial_idx.release();
-        g->result.release();
-        g->plan_buf.release();
-        for (covest_grid::Part &part : g->long_parts)
-            part.buf.release();
-        g->long_q_orig.release();
-        g->long_partial.release();
-        delete g;
-        return code;
-    };
-    if (rc != COVEST_OK)
-        return bail(rc);
+    // threshold_o over the (q1, q2, q) sub-grid (host, libm)
+    std::vector<int32_t> table((size_t)nq);
+    for (int64_t a = 0; a < n1 && nq; ++a)
+        for (int64_t b = 0; b < n2; ++b)
+            for (int64_t c = 0; c < n3; ++c) {
+                const double par[5] = {0, 0, axes[2][a], axes[3][b], axes[4][c]};
+                table[(size_t)((a * n2 + b) * n3 + c)] = threshold_for_point(m, par);
+            }
 
-    std::vector<double> flat_axes;
-    flat_axes.reserve((size_t)n_values);
-    for (int d = 0; d < n_axes; ++d) {
-        g->len[d] = axis_len[d];
-        flat_axes.insert(flat_axes.end(), axes[d], axes[d] + axis_len[d]);
+    // arena layout: [axes | queue counter (8 B) | t_table] uploaded together, then the outputs
+    auto up8 = [](size_t v) { return (v + 7) / 8 * 8; };
+    const size_t o_axes = 0, o_ctl = o_axes + (size_t)n_values * sizeof(double), o_table = o_ctl + 8;
+    const size_t o_ll = up8(o_table + (size_t)nq * sizeof(int32_t)), n_pts = (size_t)(n > 0 ? n : 1);
+    const size_t o_idx = o_ll + n_pts * sizeof(double), o_word = o_idx + n_pts * sizeof(int64_t);
+    const size_t o_pv = o_word + n_pts * sizeof(unsigned long long), o_pi = o_pv + kArgminBlocks * sizeof(double);
+    const size_t o_res = o_pi + kArgminBlocks * sizeof(int64_t), bytes = o_res + sizeof(ArgminResult);
+    HIP_TRY(g->arena.reserve(bytes));
+    char *base = g->arena.as<char>();
+    {
+        std::vector<char> stage(o_ll, 0);
+        double *sa = reinterpret_cast<double *>(stage.data());
+        for (int d = 0; d < n_axes; ++d) {
+            g->len[d] = axis_len[d];
+            std::copy(axes[d], axes[d] + axis_len[d], sa);
+            sa += axis_len[d];
+        }
+        for (int d = n_axes; d < kMaxParams; ++d)
+            g->len[d] = 1;
+        if (nq)
+            std::memcpy(stage.data() + o_table, table.data(), (size_t)nq * sizeof(int32_t));
+        HIP_TRY(hipMemcpy(base, stage.data(), stage.size(), hipMemcpyHostToDevice));
     }
-#define GRID_TRY(expr)                                   \
-    do {                                                 \
-        hipError_t e__ = (expr);                         \
-        if (e__ != hipSuccess)                           \
-            return bail(fail_hip(e__, #expr));           \
-    } while (0)
-    GRID_TRY(g->axes.reserve(flat_axes.size() * sizeof(double)));
-    GRID_TRY(hipMemcpy(g->axes.ptr, flat_axes.data(), flat_axes.size() * sizeof(double),
-                       hipMemcpyHostToDevice));
+    g->axes.ptr = base + o_axes;
+    g->sub_ctl.ptr = base + o_ctl;
+    g->t_table.ptr = base + o_table;
+    g->ll.ptr = base + o_ll;
+    g->sub_index.ptr = base + o_idx;
+    g->sub_word.ptr = base + o_word;
+    g->partial_val.ptr = base + o_pv;
+    g->partial_idx.ptr = base + o_pi;
+    g->result.ptr = base + o_res;
     PointSource &src = g->src;
+    src = PointSource{};
     src.is_grid = 1;
     src.flat_begin = flat_begin;
     {
@@ -1579,21 +1615,11 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
         }
     }
 
-    // threshold_o over the (q1, q2, q) sub-grid, and the block's sum of (T - 1)
+    // the block's sum of (T - 1), and the K-factored plan
     g->sum_t_minus_1 = (double)n; // basic: T = 2 everywhere
+    g->q_sum_t_minus_1 = 0.0;
+    g->has_plan = false;
     if (m->n_par == 5) {
-        const int64_t n1 = axis_len[2], n2 = axis_len[3], n3 = axis_len[4];
-        const int64_t nq = n1 * n2 * n3;
-        std::vector<int32_t> table((size_t)nq);
-        for (int64_t a = 0; a < n1; ++a)
-            for (int64_t b = 0; b < n2; ++b)
-                for (int64_t c = 0; c < n3; ++c) {
-                    const double par[5] = {0, 0, axes[2][a], axes[3][b], axes[4][c]};
-                    table[(size_t)((a * n2 + b) * n3 + c)] = threshold_for_point(m, par);
-                }
-        GRID_TRY(g->t_table.reserve((size_t)nq * sizeof(int32_t)));
-        GRID_TRY(hipMemcpy(g->t_table.ptr, table.data(), (size_t)nq * sizeof(int32_t),
-                           hipMemcpyHostToDevice));
         src.t_table = g->t_table.as<int32_t>();
         // sum of (T-1) over flat indices [begin, end): whole (c,e) rows plus two ragged ends
         std::vector<double> prefix((size_t)nq + 1, 0.0);
@@ -1606,21 +1632,66 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
         g->q_sum_t_minus_1 = prefix[(size_t)nq];
         const int prc = build_factored_plan(g, axes, axis_len, table);
         if (prc != COVEST_OK)
-            return bail(prc);
+            return prc;
     }
+    return COVEST_OK;
+}
 
-    GRID_TRY(g->ll.reserve((size_t)(n > 0 ? n : 1) * sizeof(double)));
-    // the queue of points the recurrence kernels hand back (direct_point.h): as many entries as points, two counters
-    GRID_TRY(g->sub_index.reserve((size_t)(n > 0 ? n : 1) * sizeof(int64_t)));
-    GRID_TRY(g->sub_word.reserve((size_t)(n > 0 ? n : 1) * sizeof(unsigned long long)));
-    GRID_TRY(g->sub_ctl.reserve(sizeof(unsigned)));
-    GRID_TRY(hipMemset(g->sub_ctl.ptr, 0, sizeof(unsigned)));
-    GRID_TRY(g->partial_val.reserve(kArgminBlocks * sizeof(double)));
-    GRID_TRY(g->partial_idx.reserve(kArgminBlocks * sizeof(int64_t)));
-    GRID_TRY(g->result.reserve(sizeof(ArgminResult)));
-#undef GRID_TRY
+static void grid_release(covest_grid *g)
+{
+    g->arena.release();
+    g->plan_buf.release();
+    for (covest_grid::Part &part : g->long_parts)
+        part.buf.release();
+    g->long_parts.clear();
+    g->long_q_orig.release();
+    g->long_partial.release();
+    for (hipEvent_t e : g->ev_begin)
+        (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->ev_end)
+        (void)hipEventDestroy(e);
+    g->ev_begin.clear();
+    g->ev_end.clear();
+}
+
+int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axes,
+                       const int64_t *axis_len, int64_t flat_begin, int64_t flat_end,
+                       covest_grid **out)
+{
+    if (!m || !out)
+        return fail(COVEST_E_INVALID, "covest_grid_create: null argument");
+    *out = nullptr;
+    covest_grid *g = new (std::nothrow) covest_grid();
+    if (!g)
+        return fail(COVEST_E_NOMEM, "covest_grid_create: out of host memory");
+    g->model = m;
+    std::lock_guard<std::mutex> guard(m->lock);
+    DeviceGuard dev_guard(m->device);
+    int rc = dev_guard.status();
+    if (rc == COVEST_OK)
+        rc = grid_configure(g, n_axes, axes, axis_len, flat_begin, flat_end, "covest_grid_create");
+    if (rc != COVEST_OK) {
+        grid_release(g);
+        delete g;
+        return rc;
+    }
     *out = g;
     return COVEST_OK;
+}
+
+int covest_grid_reset(covest_grid *g, int32_t n_axes, const double *const *axes, const int64_t *axis_len,
+                      int64_t flat_begin, int64_t flat_end)
+{
+    if (!g)
+        return fail(COVEST_E_INVALID, "covest_grid_reset: null grid");
+    covest_model *m = g->model;
+    std::lock_guard<std::mutex> guard(m->lock);
+    DeviceGuard dev_guard(m->device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
+    if (g->last_stream || g->evaluated)
+        HIP_TRY(hipStreamSynchronize(g->last_stream)); // nothing of the last evaluation may still be in flight
+    return grid_configure(g, n_axes, axes, axis_len, flat_begin, flat_end, "covest_grid_reset");
 }
 
 void covest_grid_destroy(covest_grid *g)
@@ -1628,24 +1699,7 @@ void covest_grid_destroy(covest_grid *g)
     if (!g)
         return;
     DeviceGuard dev_guard(g->model->device);
-    g->axes.release();
-    g->t_table.release();
-    g->ll.release();
-    g->sub_index.release();
-    g->sub_word.release();
-    g->sub_ctl.release();
-    g->partial_val.release();
-    g->partial_idx.release();
-    g->result.release();
-    g->plan_buf.release();
-    for (covest_grid::Part &part : g->long_parts)
-        part.buf.release();
-    g->long_q_orig.release();
-    g->long_partial.release();
-    for (hipEvent_t e : g->ev_begin)
-        (void)hipEventDestroy(e);
-    for (hipEvent_t e : g->ev_end)
-        (void)hipEventDestroy(e);
+    grid_release(g);
     delete g;
 }
 
@@ -1709,7 +1763,7 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
         g->ev_used++;
         HIP_TRY(hipEventRecord(e0, st));
     }
-    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), sub_list_of(m, g->has_plan ? g->t_max : 2, g->sub_index, g->sub_word, g->sub_ctl), st,
+    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), sub_list_of(m, g->has_plan ? g->t_max : 2, g->sub_index.ptr, g->sub_word.ptr, g->sub_ctl.ptr), st,
                       &g->last_kernel, g));
     g->last_kernel_id = kern;
     if (e1)

@@ -24,6 +24,7 @@ with it every iterate -- is bit-identical to what `minimize(..., jac=None)` comp
 likelihood values.  The kernels are deterministic per point, whatever else shares the launch.
 """
 import threading
+import time
 
 import numpy as np
 
@@ -40,10 +41,18 @@ class CoverageEstimator:
         self.err_scale = err_scale
         self.batched = batched      # value and gradient from one launch (else scipy differences a scalar objective)
         self.lock_step = lock_step  # multi-start: all starts advance together, one launch per round (see _best_of)
+        self._grid = None           # the grid handle negll_grid keeps (see there)
+        self.timings = None         # a list: negll_grid appends {points, create_s, eval_s, readback_s, kernel} per call
         bounds = [tuple(b) for b in model.bounds]
         lo, hi = bounds[self.ERROR_RATE]
         bounds[self.ERROR_RATE] = (lo, hi * err_scale)
         self.bounds = bounds
+
+    def __getstate__(self):
+        # (an estimator's bound methods get pickled into Pool workers by the reference's callers: plain data only)
+        state = dict(self.__dict__)
+        state['_grid'] = None
+        return state
 
     # ------------------------------------------------------------------ space mapping
     def _pinned(self, values):
@@ -69,12 +78,25 @@ class CoverageEstimator:
         if self.fix is not None:
             axes = [a if f is None else [f] * len(a) for a, f in zip(axes, self.fix)]
         axes[self.ERROR_RATE] = [v / self.err_scale for v in axes[self.ERROR_RATE]]
-        grid = DenseGrid(self.model, axes)
-        try:
+        t = self.timings
+        t0 = time.perf_counter() if t is not None else 0.0
+        # one grid handle per estimator, re-configured for every grid (covest_grid_reset): its device memory stays
+        if self._grid is not None and self._grid._handle is not None and self._grid.model is self.model:
+            grid = self._grid.reset(axes)
+        else:
+            grid = self._grid = DenseGrid(self.model, axes)
+        if True:
+            t1 = time.perf_counter() if t is not None else 0.0
             grid.evaluate(kernel=kernel)
-            return -grid.loglikelihoods()
-        finally:
-            grid.close()
+            if t is not None:
+                grid.argmin()  # (wait for the kernels: the split below is only meaningful with a sync here)
+            t2 = time.perf_counter() if t is not None else 0.0
+            out = -grid.loglikelihoods()
+            if t is not None:
+                t3 = time.perf_counter()
+                t.append({"points": len(grid), "create_s": t1 - t0, "eval_s": t2 - t1, "readback_s": t3 - t2,
+                          "kernel": grid.work()[2]})
+            return out
 
     def negll_points(self, xs):
         """likelihood_f of several optimiser-space vectors in one launch: ndarray."""

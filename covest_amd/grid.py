@@ -158,6 +158,25 @@ class DenseGrid:
         _capi.check(L.covest_grid_create(model.handle, n, ptrs, lens, self.flat_range[0],
                                          self.flat_range[1], ctypes.byref(h)), "covest_grid_create")
         self._handle = h
+        if hasattr(model, "_register_grid"):
+            model._register_grid(self)
+
+    def reset(self, axes, flat_range=None):
+        """Other axes and/or another block on the SAME handle (covest_grid_reset): the device memory stays; what
+        optimize_grid does between its iterations."""
+        if len(axes) != self.model.param_count:
+            raise ValueError("need one axis per model parameter")
+        self.axes = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in axes]
+        self.shape = tuple(len(a) for a in self.axes)
+        self.total = int(np.prod(self.shape, dtype=np.int64))
+        begin, end = (0, self.total) if flat_range is None else flat_range
+        self.flat_range = (int(begin), int(end))
+        n = len(self.axes)
+        ptrs = (_DP * n)(*[a.ctypes.data_as(_DP) for a in self.axes])
+        lens = (ctypes.c_int64 * n)(*self.shape)
+        _capi.check(_capi.lib().covest_grid_reset(self._handle, n, ptrs, lens, self.flat_range[0], self.flat_range[1]),
+                    "covest_grid_reset")
+        return self
 
     def close(self):
         if getattr(self, "_handle", None) is not None:

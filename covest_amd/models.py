@@ -139,7 +139,21 @@ class BasicModel:
             self._handle = h
         return self._handle
 
+    def _register_grid(self, grid):
+        """A grid handle borrows its model (include/covest_amd.h): the model closes the grids still open on it
+        before it goes (DenseGrid calls this)."""
+        import weakref
+        if not hasattr(self, '_grids'):
+            self._grids = []
+        self._grids = [g for g in self._grids if g() is not None]
+        self._grids.append(weakref.ref(grid))
+
     def close(self):
+        for ref in getattr(self, '_grids', []):
+            grid = ref()
+            if grid is not None:
+                grid.close()
+        self._grids = []
         if getattr(self, '_handle', None) is not None:
             _capi.lib().covest_model_destroy(self._handle)
             self._handle = None
@@ -155,6 +169,7 @@ class BasicModel:
         # (covest/grid.py:48 and covest/covest.py:68 pickle bound methods of the model).
         state = dict(self.__dict__)
         state['_handle'] = None
+        state.pop('_grids', None)
         return state
 
     def __setstate__(self, state):

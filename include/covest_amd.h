@@ -133,6 +133,11 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
                        const int64_t *axis_len, int64_t flat_begin, int64_t flat_end,
                        covest_grid **out);
 void covest_grid_destroy(covest_grid *g);
+/* Give an existing handle other axes and/or another block (same meaning of the arguments as
+ * covest_grid_create): the iterations of covest/grid.py:56-74 evaluate a new grid each time, and a
+ * handle keeps its device memory.  Waits for the handle's last evaluation. */
+int covest_grid_reset(covest_grid *g, int32_t n_axes, const double *const *axes, const int64_t *axis_len,
+                      int64_t flat_begin, int64_t flat_end);
 int64_t covest_grid_size(const covest_grid *g); /* flat_end - flat_begin */
 
 /* Evaluate LL at every point of the block into a device buffer owned by the
