@@ -86,19 +86,20 @@ __global__ __launch_bounds__(256) void argmin_stage1(const double *__restrict__ 
     }
 }
 
-// The hand-back of the recurrence kernels (direct_point.h): ONE WORKGROUP PER QUEUED POINT corrects the point's value
-// in place.  `fast` (the recurrence kernel's value, in which every p_j below p_clamp counted as p_clamp) gets, for
-// every counted row of the range named in the side word whose STRICT p_j is below p_clamp, h_j (safe_log(p_j) -
-// log(p_clamp)) added, in ascending row order.  The strict p_j: K-direct's expressions, every term rounded to a
-// double on its own (direct_point.h).  Lane r keeps the p_j of row r of a 64-row chunk; the mixture components are
-// prepared 64 at a time (one per lane) and dealt to the workgroup's 4 waves, whose partial p_j are added through
-// LDS -- where it matters (p_j subnormal) every one of these sums is exact, whatever its order.
+// The hand-back of the recurrence kernels (direct_point.h): the queued points' values are corrected in place.
+// `fast` (the recurrence kernel's value, in which every p_j below p_clamp counted as p_clamp) gets, for every counted
+// row of the range named in the side word whose STRICT p_j is below p_clamp, h_j (safe_log(p_j) - log(p_clamp)) added,
+// in ascending row order.  The strict p_j is K-direct's (direct_point.h) to the letter: LANE r of a wave keeps the
+// p_j of row r of a 64-row chunk; the mixture components are prepared 64 at a time (one per lane) and broadcast
+// through the scalar unit, every term rounded to a double on its own, error classes inside, copy numbers outside, both
+// ascending.  A repeats-model point is shared by the 4 waves of a workgroup -- lots of copy numbers are dealt to them in turn, the partial p_j are added through LDS (where it matters -- p_j
+// subnormal -- every sum is exact, whatever the order); a basic-model point (one copy number) takes one wave.
 // Launched after every K-basic / K-factored launch, before anything reads the values; with an empty queue it costs
 // a launch and one load.  The queued points of a wide grid come in clusters (whole (c, e) rows of it) and the work
 // of one grows with its threshold_o, which is why they are compacted into a queue and spread over the chip instead
 // of being patched by whichever thread meets them.  The queue's counter is reset by whoever runs next on the
 // stream: the arg-min pass (grids) or the host (point lists).
-// NW: waves that share a point (basic model, a single copy number: 1 -- four points per workgroup; repeats model: 4).
+// NW: waves that share a point (basic model: 1 -- four points per workgroup; repeats model: 4).
 template <int P, int NW>
 __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                           const double *__restrict__ tile_dbl,
@@ -113,11 +114,10 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
     const int wave = wave_in_block % NW; // among the waves of its point
     const unsigned count = __builtin_amdgcn_readfirstlane(*list.count);
     const int S = m.n_err;
-    const int OT = kWave / S;
+    const int OT = kWave / S; // copy numbers prepared per lot of 64 components
     const int s = lane % S;
     const int og = lane / S;
     const bool lane_in_tile = og < OT;
-    const bool pow2 = (S & (S - 1)) == 0; // then the groups of S lanes are aligned and reduce by butterflies
     const double comb_s = m.comb[s];
     for (unsigned at0 = blockIdx.x * PPB; at0 < count; at0 += gridDim.x * PPB) { // workgroup-uniform
         const unsigned at = at0 + wave_in_block / NW;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
         const int64_t row_first = units16 ? (int64_t)sub_first(word) * 16 : (int64_t)sub_first(word);
         const int64_t row_last = units16 ? (int64_t)sub_last(word) * 16 + 15 : (int64_t)sub_last(word);
         const double lam = error_class_rate(m, par[0], par[1], s);
+        const int o_hi = T;
         double value = ll[pt];
         for (int64_t chunk = row_first; chunk <= row_last; chunk += kWave) { // workgroup-uniform
             const int64_t row = chunk + lane;
@@ -141,58 +142,66 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
             const bool counted = bin >= 0 && h != 0.0;
             const double key = counted ? m.bins.key[bin] : 0.0;
             const double nlg = counted ? -m.bins.lgam[bin] : 0.0;
-            const uint64_t rows = __ballot(counted);
             double pj = 0.0; // of this lane's row: this wave's share of the copy numbers
-            for (int o0 = 1 + OT * wave; o0 < T; o0 += OT * NW) {
-                const int o = o0 + og;
-                const bool live = lane_in_tile && o < T;
-                const double x = (double)o * lam;
-                const double n_os = comb_s * (1.0 - exp_neg_rn(x));
-                double tot = 0.0;
-                for (int t = 0; t < S; ++t)
-                    tot += __shfl(n_os, og * S + t, kWave);
-                if (tot == 0.0)
-                    tot = 1.0;
-                double a_os = n_os / tot;
-                const double b_o = (P == 5) ? copy_number_weight(par[2], par[3], par[4], o) : 1.0;
-                double lx = 0.0, nd = -INFINITY;
-                if (live && x > 0.0) {
-                    lx = log(x);
-                    nd = -log_trunc_norm(x, lx);
-                }
-                if (!live)
-                    a_os = 0.0;
-                const int n_o = min(OT, T - o0);
-                uint64_t todo = rows;
-                while (todo) { // wave-uniform: one counted row of the chunk after the other
-                    const int kk = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const double key_k = wave_bcast(key, kk), nlg_k = wave_bcast(nlg, kk);
-                    const double arg = fma(key_k, lx, nd + nlg_k);
-                    // exp(arg) rounds to 0 below ln(2^-1075) = -745.13: where all 64 components of this lot are
-                    // there (the copy numbers far from a deep-tail key: most of them), the row gains nothing
-                    if (!__any(a_os != 0.0 && !(arg < -745.2)))
-                        continue;
-                    const double term = a_os != 0.0 ? a_os * exp(arg) : 0.0;
-                    double add = 0.0;
-                    if (pow2) {
-                        double inner = term; // sum over the S error classes of a copy number (every lane of the group) ...
-                        for (int off = 1; off < S; off <<= 1)
-                            inner += __shfl_xor(inner, off, kWave);
-                        double u = og < n_o ? b_o * inner : 0.0; // ... times its weight, rounded ...
-                        for (int off = S; off < kWave; off <<= 1) // ... summed over the copy numbers: every lane (g, s)
-                            u += __shfl_xor(u, off, kWave);       //     adds the groups' values at its own s
-                        add = u;
-                    } else {
-                        for (int g = 0; g < n_o; ++g) {
-                            double inner = 0.0;
-                            for (int t = 0; t < S; ++t)
-                                inner += __shfl(term, g * S + t, kWave);
-                            add += __shfl(b_o, g * S, kWave) * inner;
-                        }
+            const uint64_t cm = __ballot(counted);
+            if (cm) {
+                // the chunk's smallest and largest counted key (rows ascend with the keys)
+                const int l_lo = __builtin_ctzll(cm), l_hi = 63 - __builtin_clzll(cm);
+                const double k_lo = wave_bcast(key, l_lo), g_lo = wave_bcast(nlg, l_lo);
+                const double k_hi = wave_bcast(key, l_hi), g_hi = wave_bcast(nlg, l_hi);
+                // lots of OT copy numbers, dealt to the point's waves in turn
+                for (int o0 = 1 + wave * OT; o0 < o_hi; o0 += NW * OT) {
+                    // ---- lane-parallel preparation of up to OT * S mixture components (as K-direct) ----
+                    const int o = o0 + og;
+                    const bool live = lane_in_tile && o < o_hi;
+                    const double x = (double)o * lam;
+                    {
+                        // A whole lot out of reach of the chunk (the usual case) is not prepared at all: the same
+                        // test as below in single precision, with the normaliser's floor  D(x) >= x - 19  for
+                        // x >= 1 (point_fetch.h: x + ln(1 - e^-xr), xr > 1e-8) and room for the float error of
+                        // key * ln x (<= 0.02 at the key cap).
+                        const float lxf = __logf((float)x);
+                        const float reach = fmaxf(fmaf((float)k_lo, lxf, (float)g_lo), fmaf((float)k_hi, lxf, (float)g_hi));
+                        const bool far = x >= 1.0 && (x < k_lo - 1.0 || x > k_hi + 1.0) &&
+                                         (double)reach - (x - 19.0) < -745.5;
+                        if (!__any(live && !far))
+                            continue; // wave-uniform
                     }
-                    if (lane == kk)
-                        pj += add;
+                    const double n_os = comb_s * (1.0 - exp_neg_rn(x));
+                    double tot = 0.0;
+                    for (int t = 0; t < S; ++t)
+                        tot += __shfl(n_os, og * S + t, kWave);
+                    if (tot == 0.0)
+                        tot = 1.0;
+                    double a_os = n_os / tot;
+                    const double b_o = (P == 5) ? copy_number_weight(par[2], par[3], par[4], o) : 1.0;
+                    double lx = 0.0, nd = -INFINITY;
+                    if (live && x > 0.0) {
+                        lx = log(x);
+                        nd = -log_trunc_norm(x, lx);
+                    }
+                    if (!live)
+                        a_os = 0.0;
+                    // Which components reach any row of the chunk at all?  exp(arg) rounds to 0 below ln 2^-1075
+                    // = -745.13, and arg is concave in the key with its top within 1 of x: outside [k_lo - 1,
+                    // k_hi + 1] it is monotone over the chunk's keys and the nearer end bounds it.  (Most copy
+                    // numbers, for the keys of a deep tail: their terms are exactly 0 in the reference too.)
+                    const bool inside = x >= k_lo - 1.0 && x <= k_hi + 1.0;
+                    const double top = fmax(fma(k_lo, lx, nd + g_lo), fma(k_hi, lx, nd + g_hi));
+                    const uint64_t keep = __ballot(a_os != 0.0 && (inside || top >= -745.2));
+                    // ---- every lane accumulates the kept ones for its own row ----
+                    for (int g = 0; g < OT; ++g) {
+                        uint64_t gm = (keep >> (g * S)) & ((1ull << S) - 1ull);
+                        if (gm == 0)
+                            continue;
+                        double inner = 0.0;
+                        while (gm) { // error classes, ascending
+                            const int i = g * S + __builtin_ctzll(gm);
+                            gm &= gm - 1;
+                            inner += wave_bcast(a_os, i) * exp(fma(key, wave_bcast(lx, i), wave_bcast(nd, i) + nlg));
+                        }
+                        pj += wave_bcast(b_o, g * S) * inner; // covest/models.py:237
+                    }
                 }
             }
             if (NW > 1) {

@@ -14,6 +14,12 @@ for w in c3 c2; do
   find "$out/trace_$w" -name "*kernel_stats.csv" -exec cp {} "$out/${w}_kernel_stats.csv" \;
   bash tools/pmc_profile.sh "$out/pmc_$w" --workload $w --steps 5 --warmup 1 > "$out/pmc_$w.log" 2>&1
   python3 tools/pmc_summary.py "$out/pmc_$w" ll_ > "$out/${w}_pmc_summary.json"
+  rm -rf "$out/trace_$w"
+  find "$out/pmc_$w" -name "*.csv" -size +2000k -delete
 done
 timeout -k 10 100 python3 bench.py --workload c1 > "$out/bench_c1.json" 2> "$out/bench_c1.err"
+timeout -k 10 200 python3 bench.py --workload og --steps 5 > "$out/bench_og.json" 2> "$out/bench_og.err"
+timeout -k 10 200 python3 bench.py --scaling strong --steps 5 --warmup 1 --cpu-budget 0 > "$out/bench_c3_strong_1gpu.json" 2> "$out/bench_strong.err"
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --backend gloo --share-gpu --scaling strong --steps 5 --warmup 1 --cpu-budget 0 2> "$out/bench_2rank.err" | tail -1 > "$out/bench_c3_strong_2rank_gloo_rehearsal.json"
+COVEST_FACTORED_DIAG=1 timeout -k 10 100 python3 tools/factored_diag.py > "$out/c3_factored_phase_stamps.txt" 2>&1
 ls "$out"

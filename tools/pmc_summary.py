@@ -18,8 +18,9 @@ for path in sorted(glob.glob(os.path.join(d, "*counter_collection.csv"))):
             if want not in name:
                 continue
             import re
-            mm = re.search(r"(ll_[a-z]+|argmin_stage\d)", name)
-            short = mm.group(1) if mm else name[:40]
+            # kernel name with its template arguments (the tail / no-tail variants are different kernels)
+            mm = re.search(r"(ll_[a-z_]+(?:<[^>]*>)?|argmin_stage\d)", name)
+            short = mm.group(1).replace(" ", "") if mm else name[:40]
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, counters in acc.items():
