@@ -132,6 +132,7 @@ struct covest_grid {
     DevBuf long_q_orig, long_partial;
     int t_max = 2; // largest threshold_o of the (q1, q2, q) product
     double q_sum_t_minus_1 = 0.0; // sum over the Q weight vectors of (threshold_o - 1)
+    double contract_flops_per_row = 0.0; // K-factored: useful flops of the contraction per row (build_factored_plan)
     double sum_t_minus_1 = 0.0; // sum over the block's points of (threshold_o - 1)
     const char *last_kernel = "none";
     int last_kernel_id = 0;
@@ -473,7 +474,11 @@ double copy_number_weight_host(double q1, double q2, double q, int o)
 // the same weight; a chunk then holds 512 / n_pass copy numbers.
 struct QOrder {
     int64_t n1, n2, n3, nq;
-    std::vector<int32_t> order; // slot -> index in the (q1, q2, q) product, by descending threshold_o
+    // slot -> index in the (q1, q2, q) product, -1 = padding; [n_qtiles * 16].  Either all weight vectors by
+    // descending threshold_o, or (shared steps, tiles.h) tile by tile: the 16 slots of a tile share q, descending
+    // threshold_o inside, the tiles by descending largest threshold_o.
+    std::vector<int32_t> order;
+    std::vector<int32_t> tile_nsh; // [n_qtiles] shared steps of the tile's units (0: none)
     int32_t n_qtiles;
     int t_max;
 };
@@ -497,9 +502,14 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         q2 = clamp_one(m->dm, 3, axes[3][b]);
         q = clamp_one(m->dm, 4, axes[4][c]);
     };
+    // shared steps (tiles.h): only the plain dense shape has them
+    std::vector<int32_t> nsh((size_t)n_qtiles, 0);
+    if (list_mode == 0 && n_pass == 1 && o_base == 0)
+        for (int32_t qt = 0; qt < n_qtiles; ++qt)
+            nsh[(size_t)qt] = qo.tile_nsh[(size_t)(tile_lo + qt)];
     for (size_t ls = 0; ls < n_slots; ++ls) {
         const size_t gs = (size_t)tile_lo * 16 + ls;
-        if (gs >= (size_t)nq)
+        if (qo.order[gs] < 0)
             continue; // padding column
         const int64_t qi = qo.order[gs];
         const int t_loc = std::min(chunk + 1, std::max(0, (int)t_table[(size_t)qi] - o_base));
@@ -519,7 +529,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     const int n_columns = n_pass == 1 ? max_o : n_pass * pass_stride;
     // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
     const int ld = ((n_columns + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 7680 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 8192 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const int n_units = 2 * n_qtiles;
     const int hu = kHalfUnits; // (768 threads with 2 slots per half, 3 waves/SIMD, was measured: +1 %)
     const int mu = 2 * hu;
@@ -539,9 +549,12 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     // logs; a builder wave starts with the cost of phase A (tuned on C3 with the in-kernel stamps)
     const int unit_overhead = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD") ? std::atoi(std::getenv("COVEST_FACTORED_UNIT_OVERHEAD")) : kUnitOverhead;
     const int build_cost = std::getenv("COVEST_FACTORED_BUILD_COST") ? std::atoi(std::getenv("COVEST_FACTORED_BUILD_COST")) : kBuildCost;
+    const int shared_div = std::getenv("COVEST_FACTORED_SHARED_DIV") ? std::max(1, std::atoi(std::getenv("COVEST_FACTORED_SHARED_DIV"))) : kSharedStepsPerMfma;
     const size_t n_unit = (size_t)n_qblocks * nw * mu;
     std::vector<int32_t> unit_tile(n_unit, -1), unit_half(n_unit, 0), unit_s0(n_unit, 0), unit_o0(n_unit, 1),
-        unit_len(n_unit, 0), unit_cont(n_unit, 0);
+        unit_len(n_unit, 0), unit_cont(n_unit, 0), unit_nsh(n_unit, 0);
+    // MFMA steps of a tile's units: all of them, or step 0 and those after the shared ones
+    auto mfma_steps = [&](int qt) { return (int)nsteps[(size_t)qt] - (int)nsh[(size_t)qt]; };
     for (int blk = 0; blk < n_qblocks; ++blk) {
         struct Unit {
             int tile, half, cost, pieces; // pieces: per pass
@@ -549,7 +562,8 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         std::vector<Unit> units;
         for (int qt = blk; qt < n_qtiles; qt += n_qblocks) // tiles are sorted by T: interleave over blocks
             for (int h = 0; h < 2; ++h)
-                units.push_back({qt, h, n_pass * std::max(1, (int)nsteps[(size_t)qt]) + unit_overhead, 1});
+                units.push_back({qt, h, n_pass * std::max(1, mfma_steps(qt)) + unit_overhead +
+                                            (nsh[(size_t)qt] ? 1 + (nsh[(size_t)qt] + shared_div - 1) / shared_div : 0), 1});
         std::stable_sort(units.begin(), units.end(), [](const Unit &a, const Unit &b) { return a.cost > b.cost; });
         // longest first into the lightest SIMD (waves w and w + 4 share one) that still has room,
         // then into the lighter of that SIMD's waves with room
@@ -581,13 +595,15 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         for (int w = 0; w < nw; ++w) {
             std::vector<Unit> &mine = held[(size_t)w];
             // cut the unit with the longest pieces once more (in every pass) while slots are free (tiles.h)
-            auto piece_len = [&](const Unit &u) { return ((int)nsteps[(size_t)u.tile] + u.pieces - 1) / u.pieces; };
+            auto piece_len = [&](const Unit &u) { return (mfma_steps(u.tile) + u.pieces - 1) / u.pieces; };
             int used = (int)mine.size() * n_pass;
             while (used + n_pass <= mu && !mine.empty()) {
                 size_t longest = 0;
                 for (size_t i = 1; i < mine.size(); ++i)
                     if (piece_len(mine[i]) > piece_len(mine[longest]))
                         longest = i;
+                if (nsh[(size_t)mine[longest].tile])
+                    break; // (a unit with shared steps is short already, and stays in one piece)
                 Unit trial = mine[longest];
                 trial.pieces += 1;
                 if (piece_len(trial) < kMinPieceSteps)
@@ -610,13 +626,14 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
                         unit_o0[at] = 1 + 4 * p * piece_len(u);
                         unit_len[at] = piece_len(u); // equal lengths: steps past the unit's end are cut off by T
                         unit_cont[at] = first ? 0 : 1;
+                        unit_nsh[at] = nsh[(size_t)u.tile];
                         first = false;
                     }
             }
         }
     }
     // weights of every slot's first two MFMA steps, per lane (lane = 16 * (o mod 4) + column)
-    std::vector<double> piece_w(n_unit * 2 * 64, 0.0);
+    std::vector<double> piece_w(n_unit * 3 * 64, 0.0), unit_rho(n_unit * 2, 1.0);
     // (eight consecutive copy numbers per slot and column: one libm pow, the rest by multiplication -- the kernel
     // advances the weights the same way from the third step on; a grid with few (c, e) pairs has many slots)
     for (size_t at = 0; at < n_unit; ++at) {
@@ -625,7 +642,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
             continue;
         for (int colx = 0; colx < 16; ++colx) {
             const size_t gs = ((size_t)tile_lo + (size_t)qt) * 16 + (size_t)colx;
-            if (gs >= (size_t)nq)
+            if (qo.order[gs] < 0)
                 continue; // padding column
             double q1, q2, q;
             weights_of(gs, q1, q2, q);
@@ -641,13 +658,24 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
                     w = head * geo;
                     geo *= base;
                 }
-                piece_w[(at * 2 + (size_t)(d >> 2)) * 64 + (size_t)((d & 3) * 16 + colx)] = w;
+                piece_w[(at * 3 + (size_t)(d >> 2)) * 64 + (size_t)((d & 3) * 16 + colx)] = w;
+            }
+            if (unit_nsh[at] > 0) {
+                // (one q per tile: every live column writes the same two values)
+                unit_rho[2 * at] = 1.0 / std::pow(base, 4.0);
+                unit_rho[2 * at + 1] = std::pow(unit_rho[2 * at], 4.0);
+            }
+            if (unit_nsh[at] > 0) { // the first step after the shared ones: o = 5 + 4 nsh .. 8 + 4 nsh
+                const int o_after = o_first + 4 * (unit_nsh[at] + 1);
+                double g2 = std::pow(base, (double)(o_after - 3));
+                for (int d = 0; d < 4; ++d, g2 *= base)
+                    piece_w[(at * 3 + 2) * 64 + (size_t)(d * 16 + colx)] = head * g2;
             }
         }
     }
     // one buffer: doubles first (r4 | piece_w), then int32 (q_T | q_orig | unit tables)
-    const size_t n_dbl = n_slots + piece_w.size();
-    const size_t n_int = 2 * n_slots + 6 * n_unit;
+    const size_t n_dbl = n_slots + piece_w.size() + unit_rho.size();
+    const size_t n_int = 2 * n_slots + 7 * n_unit;
     HIP_TRY(buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
     double *dbase = buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
@@ -658,6 +686,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         int32_t *si = reinterpret_cast<int32_t *>(sd + n_dbl);
         std::copy(r4.begin(), r4.end(), sd);
         std::copy(piece_w.begin(), piece_w.end(), sd + n_slots);
+        std::copy(unit_rho.begin(), unit_rho.end(), sd + n_slots + piece_w.size());
         std::copy(q_t.begin(), q_t.end(), si);
         std::copy(q_orig.begin(), q_orig.end(), si + n_slots);
         int32_t *sp = si + 2 * n_slots;
@@ -667,6 +696,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         std::copy(unit_o0.begin(), unit_o0.end(), sp + 3 * n_unit);
         std::copy(unit_len.begin(), unit_len.end(), sp + 4 * n_unit);
         std::copy(unit_cont.begin(), unit_cont.end(), sp + 5 * n_unit);
+        std::copy(unit_nsh.begin(), unit_nsh.end(), sp + 6 * n_unit);
         HIP_TRY(hipMemcpy(buf.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice));
     }
     pl = FactoredPlan{};
@@ -694,7 +724,9 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     pl.unit_o0 = ub + 3 * n_unit;
     pl.unit_len = ub + 4 * n_unit;
     pl.unit_cont = ub + 5 * n_unit;
+    pl.unit_nsh = ub + 6 * n_unit;
     pl.piece_w = dbase + n_slots;
+    pl.unit_rho = dbase + n_slots + piece_w.size();
     pl.q_first8 = nullptr;
     pl.q_r4 = dbase;
     pl.qtile_nsteps = nullptr;
@@ -749,20 +781,77 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     qo.t_max = 1;
     for (int64_t i = 0; i < qo.nq; ++i)
         qo.t_max = std::max(qo.t_max, (int)t_table[(size_t)i]);
-    qo.order.resize((size_t)qo.nq);
-    for (int64_t i = 0; i < qo.nq; ++i)
-        qo.order[(size_t)i] = (int32_t)i;
-    std::stable_sort(qo.order.begin(), qo.order.end(),
-                     [&](int32_t a, int32_t b) { return t_table[(size_t)a] > t_table[(size_t)b]; });
-    qo.n_qtiles = (int32_t)((qo.nq + 15) / 16);
     const int n_pass = (m->dm.n_err + 7) / 8;
     const int chunk = ((512 / n_pass) / 4) * 4; // copy numbers one workgroup's lanes hold
     g->t_max = qo.t_max;
-    // the long weight vectors are the first slots of the sorted order
-    int64_t n_long = 0;
-    while (n_long < qo.nq && (int)t_table[(size_t)qo.order[(size_t)n_long]] - 1 > chunk)
-        ++n_long;
-    const int32_t n_long_tiles = (int32_t)((n_long + 15) / 16);
+    // ---- the order of the weight vectors: slots of 16 per q-tile ----
+    // Shared steps (tiles.h) want the 16 columns of a tile to differ in q1 and q2 only: the n1 * n2 vectors of one q
+    // are then laid out by descending threshold_o and padded to whole tiles.  Padding columns cost logs, shared steps
+    // save MFMAs: taken when the padding stays below a third (n1 * n2 = 12, 16, 24, 27 .. 32, 36 ...), one lane per
+    // copy number (max_error <= 8).  COVEST_FACTORED_SHARE=0: never (A/B runs).
+    const int64_t group = qo.n1 * qo.n2, group_padded = (group + 15) / 16 * 16;
+    const char *share_env = std::getenv("COVEST_FACTORED_SHARE");
+    const bool share = n_pass == 1 && 3 * (group_padded - group) <= group && !(share_env && std::atoi(share_env) == 0);
+    auto by_t = [&](int32_t a, int32_t b) { return t_table[(size_t)a] > t_table[(size_t)b]; };
+    if (!share) {
+        std::vector<int32_t> all((size_t)qo.nq);
+        for (int64_t i = 0; i < qo.nq; ++i)
+            all[(size_t)i] = (int32_t)i;
+        std::stable_sort(all.begin(), all.end(), by_t);
+        qo.n_qtiles = (int32_t)((qo.nq + 15) / 16);
+        qo.order.assign((size_t)qo.n_qtiles * 16, -1);
+        std::copy(all.begin(), all.end(), qo.order.begin());
+        qo.tile_nsh.assign((size_t)qo.n_qtiles, 0);
+    } else {
+        struct Tile {
+            int32_t slot[16];
+            int t_hi, t_lo;
+        };
+        std::vector<Tile> tiles;
+        std::vector<int32_t> one((size_t)group);
+        for (int64_t c = 0; c < qo.n3; ++c) {
+            for (int64_t ab = 0; ab < group; ++ab)
+                one[(size_t)ab] = (int32_t)(ab * qo.n3 + c);
+            std::stable_sort(one.begin(), one.end(), by_t);
+            for (int64_t at = 0; at < group; at += 16) {
+                Tile t;
+                const int64_t live = std::min<int64_t>(16, group - at);
+                for (int64_t i = 0; i < 16; ++i)
+                    t.slot[i] = i < live ? one[(size_t)(at + i)] : -1;
+                t.t_hi = (int)t_table[(size_t)t.slot[0]];
+                t.t_lo = (int)t_table[(size_t)t.slot[live - 1]];
+                tiles.push_back(t);
+            }
+        }
+        std::stable_sort(tiles.begin(), tiles.end(), [](const Tile &a, const Tile &b) { return a.t_hi > b.t_hi; });
+        qo.n_qtiles = (int32_t)tiles.size();
+        qo.order.resize(tiles.size() * 16);
+        qo.tile_nsh.assign(tiles.size(), 0);
+        for (size_t t = 0; t < tiles.size(); ++t) {
+            std::copy(tiles[t].slot, tiles[t].slot + 16, qo.order.begin() + (std::ptrdiff_t)t * 16);
+            // steps 1 .. nsh cover o = 5 .. 4 + 4 nsh, all below the tile's smallest threshold_o; a tile of the
+            // long part (threshold_o - 1 > chunk) is contracted chunk by chunk, without them
+            const int n = (tiles[t].t_lo - 5) / 4;
+            qo.tile_nsh[t] = (tiles[t].t_hi - 1 <= chunk && n >= kMinSharedSteps) ? n : 0;
+        }
+    }
+    // useful flops of the contraction per row (covest_grid_work): 2 per (column, o < T) of the MFMA steps, 2 per
+    // (o mod 4 lane, shared step) and the 4-term MFMA per column that brings a shared sum in
+    g->contract_flops_per_row = 0.0;
+    for (int32_t t = 0; t < qo.n_qtiles; ++t) {
+        const int n = qo.tile_nsh[(size_t)t];
+        for (int i = 0; i < 16; ++i) {
+            const int32_t qi = qo.order[(size_t)t * 16 + (size_t)i];
+            if (qi >= 0)
+                g->contract_flops_per_row += 2.0 * (double)((int)t_table[(size_t)qi] - 1 - 4 * n) + (n ? 8.0 : 0.0);
+        }
+        g->contract_flops_per_row += 8.0 * n;
+    }
+    // the long weight vectors are the first tiles of the order
+    int32_t n_long_tl = 0;
+    while (n_long_tl < qo.n_qtiles && (int)t_table[(size_t)qo.order[(size_t)n_long_tl * 16]] - 1 > chunk)
+        ++n_long_tl;
+    const int32_t n_long_tiles = n_long_tl;
     if (n_long_tiles > 0) {
         const int n_chunks = (qo.t_max - 1 + chunk - 1) / chunk;
         g->long_parts.resize((size_t)n_chunks);
@@ -820,9 +909,9 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     for (int64_t i = 0; i < n; ++i)
         t_max = std::max(t_max, std::min(513, (int)t_list[(size_t)i] - o_base_of(i)));
     const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 7680 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 8192 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
-    std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 2 * 64, 0.0);
+    std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 3 * 64, 0.0);
     std::vector<int32_t> q_t(n_slots, 0), q_orig(n_slots, -1), unit_tile(n_unit, -1), unit_half(n_unit, 0),
         unit_s0(n_unit, 0), unit_o0(n_unit, 1), unit_len(n_unit, 0), unit_cont(n_unit, 0);
     for (int64_t p = 0; p < n; ++p) {
@@ -852,7 +941,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
                 unit_cont[at] = k > 0;
                 for (int which = 0; which < 2; ++which)
                     for (int kq = 0; kq < 4; ++kq) // column 0 only: lanes 16 kq
-                        piece_w[(at * 2 + (size_t)which) * 64 + (size_t)(16 * kq)] =
+                        piece_w[(at * 3 + (size_t)which) * 64 + (size_t)(16 * kq)] =
                             copy_number_weight_host(q1, q2, q, ob + 1 + 4 * (unit_s0[at] + which) + kq);
             }
     }
@@ -915,6 +1004,8 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     pl.unit_len = iptr[5];
     pl.unit_cont = iptr[6];
     pl.unit_o0 = iptr[7];
+    pl.unit_nsh = nullptr; // (list modes are not the PLAIN kernel: never read)
+    pl.unit_rho = nullptr;
     pl.qtile_nsteps = nullptr;
     pl.qtile_nfull = nullptr;
     pl.q_first8 = nullptr;
@@ -2159,13 +2250,14 @@ int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, con
         if (g->last_kernel_id == COVEST_KERNEL_FACTORED) {
             // algorithmic minimum of the factored formulation (ll_factored.hip header):
             // per (c,e): G build 2 flop per (key, o, s), contraction 2 flop per (row, q, o < T_q) -- a row is a key,
-            // or the sum of a whole count-less tile (tail != 0, tiles.h) --, one log (25 flop) per
+            // or the sum of a whole count-less tile (tail != 0, tiles.h); where the plan shares steps between the
+            // columns of a q-tile (tiles.h) the shared sums count once --, one log (25 flop) per
             // (counted key, q), prologue exps 25 per (o, s)
             const double n_ce = (double)(g->plan.ce_end - g->plan.ce_begin);
             const double max_o = (double)(g->t_max - 1);
             const double rows = m->tail_is_zero ? bins : m->rows_contracted;
             const double logged = m->tail_is_zero ? bins : m->keys_logged;
-            *flops = n_ce * (bins * S * max_o * 2.0 + rows * g->q_sum_t_minus_1 * 2.0 +
+            *flops = n_ce * (bins * S * max_o * 2.0 + rows * g->contract_flops_per_row +
                              logged * (double)g->plan.n_q * 25.0 + 25.0 * S * max_o);
         } else {
             // 4 flop per pmf term + 25 per log + 25 per exp of the prologue

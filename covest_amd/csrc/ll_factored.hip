@@ -98,6 +98,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         sub_rec[2 * i] = 0xFFFFFFFFu;
         sub_rec[2 * i + 1] = 0;
     }
+    // (1-q)^-4 and (1-q)^-16 of every slot with shared steps (tiles.h): wave-uniform, read back as LDS broadcasts
+    __shared__ __attribute__((aligned(16))) double rho_tab[PLAIN ? NW * MU * 2 : 2];
+    if (PLAIN && threadIdx.x < NW * MU * 2)
+        rho_tab[threadIdx.x] = plan.unit_rho[(int64_t)blockIdx.y * NW * MU * 2 + threadIdx.x];
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // ---- phase-B/C state: this wave's (q-tile, half) units ----
     const int col = lane & 15; // q column inside a tile / key row of the A fragment
     const int kq = lane >> 4;  // which of the 4 o of an MFMA step
-    int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU];
+    int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU], nsh[MU];
     double r4[MU], llacc[MU];
     uint64_t dead[MU]; // lanes that met a p_j <= 0 with h_j != 0
     CompSum spacc[MU];
@@ -187,12 +191,15 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         len[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_len[at] : 0);
         cont[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_cont[at] : 0);
         uhalf[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_half[at] : 0);
-        a_off[k] = (16 * uhalf[k] + col) * LD + kq + 4 * first_step; // this lane's A fragment inside a G buffer
+        // shared steps (tiles.h): steps 1 .. nsh of the unit are summed on the vector unit; the MFMA loops below
+        // then run over step 0 and the steps AFTER them, which is what a_off, cut and len are counted in
+        nsh[k] = PLAIN ? __builtin_amdgcn_readfirstlane(on ? plan.unit_nsh[at] : 0) : 0;
+        a_off[k] = (16 * uhalf[k] + col) * LD + kq + 4 * (first_step + nsh[k]); // this lane's A fragment inside a G buffer
         // iterations of the piece during which this lane's copy number o0 + 4 i + kq (o0: the piece's first one,
         // counted from the chunk's start) is below T (the chunk's local one)
         const int t_lane = on ? plan.q_T[slot] : 0;
         const int o0 = __builtin_amdgcn_readfirstlane(on ? plan.unit_o0[at] : 1);
-        cut[k] = (t_lane - (o0 + kq) + 3) >> 2;
+        cut[k] = ((t_lane - (o0 + kq) + 3) >> 2) - nsh[k];
         r4[k] = plan.q_r4[slot];
         llacc[k] = 0.0;
         dead[k] = 0;
@@ -207,9 +214,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     auto load_weights = [&]() {
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
-            const double *pw = plan.piece_w + ((int64_t)(slot_base + k) * 2) * kWave + lane;
+            const double *pw = plan.piece_w + ((int64_t)(slot_base + k) * 3) * kWave + lane;
             wfirst[k] = pw[0];
-            wrun[k] = pw[kWave];
+            wrun[k] = pw[(PLAIN && nsh[k]) ? 2 * kWave : kWave];
         }
     };
     load_weights();
@@ -339,6 +346,51 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         STAMP(dg_a)
 
         // ================= phase B: P = G x b on the matrix pipe =================
+        d4 acc[MU];
+        // the shared steps (tiles.h): sum_{i = 1 .. nsh} G[key][1 + 4 i + kq] r4^(i - 1) for this lane's key and
+        // o mod 4 -- Horner from the far end, two chains (odd and even steps) -- then ONE MFMA whose B is b_o of
+        // step 1: the four lanes of a key add up inside it, every column gets its beta
+        if (PLAIN && (nsh[0] | nsh[1] | nsh[2] | nsh[3] | nsh[4] | nsh[5])) { // wave-uniform
+#pragma unroll
+            for (int k = 0; k < MU; ++k) {
+                acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
+                if (nsh[k] == 0) // wave-uniform
+                    continue;
+                // Weights RELATIVE TO THE FIRST STEP AFTER the shared ones, whose b_o the slot holds anyway (wrun):
+                //   sum_i G[key][1 + 4 i + kq] rho^(nsh + 1 - i),  rho = (1-q)^-4  (wave-uniform: the tile has one q)
+                // Four Horner chains in rho^4 over ascending steps -- eight loads in flight per trip of the loop: a
+                // lane's steps are 4 columns apart in LDS, and one wave in two on this SIMD sits in the same loop,
+                // so nothing else hides their latency.  (rho^(4 nsh) <= 1e10: the cut-off is where b_o reaches 1e-8.)
+                const double rho = rho_tab[2 * (wave * MU + k)], rho4 = rho_tab[2 * (wave * MU + k) + 1]; // (LDS broadcast)
+                const double *g1 = cur + (a_off[k] - 4 * nsh[k]); // step 0 of the unit (o = 1 .. 4); step i at g1[4 i]
+                const int n4 = nsh[k] >> 2, rem = nsh[k] & 3;
+                // chain c: the steps i with (nsh - i) mod 4 == c; the first `rem` steps are the chains' heads
+                double h0 = rem > 0 ? g1[4 * rem] : 0.0, h1 = rem > 1 ? g1[4 * (rem - 1)] : 0.0,
+                       h2 = rem > 2 ? g1[4 * (rem - 2)] : 0.0, h3 = 0.0;
+                const double *q = g1 + 4 * (rem + 1);
+                int gq = 0;
+                for (; gq + 2 <= n4; gq += 2, q += 32) {
+                    const double a3 = q[0], a2 = q[4], a1 = q[8], a0 = q[12];
+                    const double b3 = q[16], b2 = q[20], b1 = q[24], b0 = q[28];
+                    h3 = fma(fma(h3, rho4, a3), rho4, b3);
+                    h2 = fma(fma(h2, rho4, a2), rho4, b2);
+                    h1 = fma(fma(h1, rho4, a1), rho4, b1);
+                    h0 = fma(fma(h0, rho4, a0), rho4, b0);
+                }
+                if (gq < n4) {
+                    h3 = fma(h3, rho4, q[0]);
+                    h2 = fma(h2, rho4, q[4]);
+                    h1 = fma(h1, rho4, q[8]);
+                    h0 = fma(h0, rho4, q[12]);
+                }
+                const double hs = rho * fma(fma(fma(h3, rho, h2), rho, h1), rho, h0);
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(hs, wrun[k], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < MU; ++k)
+                acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
         // counts of the 8 rows this lane will log (latency hidden under the MFMAs)
         double hrow[2][4];
 #pragma unroll
@@ -348,14 +400,12 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 const int bin = 16 * u + kq + 4 * r;
                 hrow[u][r] = tv.item_cnt[(int64_t)t * kTileBins + bin];
             }
-        d4 acc[MU];
         // the piece's first step (weights wfirst/wrun were fetched during the previous tile's logs)
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
-            acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
             if (len[k] > 0) { // wave-uniform
-                const double w = (0 < cut[k]) ? wfirst[k] : 0.0;
-                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[a_off[k]], w, acc[k], 0, 0, 0);
+                const double w = (0 < cut[k] + nsh[k]) ? wfirst[k] : 0.0;
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[a_off[k] - 4 * nsh[k]], w, acc[k], 0, 0, 0);
             }
         }
         STAMP(dg_b0)

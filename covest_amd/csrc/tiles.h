@@ -90,6 +90,8 @@ constexpr int kHalfUnits = 3;      // (kept for the 256-thread capacity rule: 4 
 constexpr int kBuildCost = 36;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3)
 constexpr int kListSegments = 8;   // key segments of a point-list evaluation (list mode): latency of ONE point
 constexpr int kMinPieceSteps = 6;  // pieces are not made shorter than this
+constexpr int kSharedStepsPerMfma = 5; // cost of the shared steps in the assignment: this many weigh one MFMA step
+constexpr int kMinSharedSteps = 3; // fewer shared steps than this are left to the MFMA steps
 constexpr int kUnitOverhead = 3;   // per-unit cost besides its MFMA steps (logs, setup), same unit
 
 struct FactoredPlan {
@@ -116,8 +118,20 @@ struct FactoredPlan {
     const int32_t *unit_len;       // steps of the piece (equal for all pieces of a unit; steps past the
                                    //   unit's end are masked by the T cut-off)
     const int32_t *unit_cont;      // 1 = this slot continues the unit of the slot before it
-    const double *piece_w;         // [slots][2][64 lanes] b_o at the piece's first and second step
-                                   //   (o = 1 + 4 step + lane/16, column lane%16), libm pow on the host
+    const int32_t *unit_nsh;       // SHARED steps of the slot's unit (0: none), see below
+    const double *unit_rho;        // [slots][2] (1-q)^-4 and (1-q)^-16 of the unit's q-tile (units with unit_nsh > 0)
+    const double *piece_w;         // [slots][3][64 lanes] b_o at the piece's first and second step
+                                   //   (o = 1 + 4 step + lane/16, column lane%16), libm pow on the host; third:
+                                   //   b_o at the first step AFTER the shared ones (units with unit_nsh > 0)
+    // Shared steps.  The 16 weight vectors of a q-tile of a dense grid can be chosen to differ in q1 and q2 only
+    // (the host sorts the product that way when it pays): then b_o = beta_col (1-q)^(o-3) for o >= 3, and for
+    // the copy numbers below EVERY column's cut-off the contraction  sum_o G[key][o] b_o(col)  is beta_col times a
+    // sum that does not depend on the column.  Steps 1 .. unit_nsh of such a unit (o = 5 .. 4 + 4 nsh, all below
+    // the tile's smallest T) are therefore summed ONCE per key, on the vector unit (Horner in (1-q)^-4, lane =
+    // (key, o mod 4), weights relative to the first step after them), and enter the accumulator through one MFMA whose
+    // B is b_o of that step; step 0 (o = 1 .. 4, the weights that are not geometric) and the steps after the shared
+    // ones (where the columns' cut-offs differ) are MFMA steps as before.  unit_len counts step 0 and the steps after
+    // the shared ones.
     const int32_t *qtile_nsteps;   // [n_qtiles] ceil((max T in tile - 1) / 4): MFMA steps of the tile
     const int32_t *qtile_nfull;    // [n_qtiles] floor((min T in tile - 1) / 4): steps with no column cut off
     const int32_t *q_T;            // [n_qtiles*16] threshold_o per slot (0 = padding)

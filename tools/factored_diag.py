@@ -31,5 +31,6 @@ tot = d.sum(axis=2)
 print("mean cycles per wave (s_memtime ticks): total %.0f" % tot.mean())
 for w in range(8):
     a, b, c, bar = d[:, w, :].mean(axis=0)
-    print("wave %d: build %8.0f  contract %8.0f  log %8.0f  barrier %8.0f   total %8.0f" % (
-        w, a, b, c, bar, a + b + c + bar))
+    b0 = extra[:, w, 4].mean()  # shared steps + first MFMA step
+    print("wave %d: build %8.0f  shared+first %8.0f  contract %8.0f  log %8.0f  barrier %8.0f   total %8.0f" % (
+        w, a, b0, b, c, bar, a + b0 + b + c + bar))
