@@ -28,6 +28,7 @@ EXPORTS = (
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
     "covest_kmer_create", "covest_kmer_destroy", "covest_kmer_reserve", "covest_kmer_add",
     "covest_kmer_add_device", "covest_kmer_histogram", "covest_kmer_slots", "covest_kmer_clear",
+    "covest_reads_open", "covest_reads_close", "covest_reads_next", "covest_reads_bytes",
     "covest_thin_histogram", "covest_thin_histogram_timed",
 )
 
@@ -138,6 +139,14 @@ def lib():
     L.covest_kmer_clear.argtypes = [vp, vp]
     L.covest_kmer_slots.restype = i64
     L.covest_kmer_slots.argtypes = [vp]
+    L.covest_reads_open.restype = ctypes.c_int
+    L.covest_reads_open.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_uint64, ctypes.POINTER(vp)]
+    L.covest_reads_close.restype = None
+    L.covest_reads_close.argtypes = [vp]
+    L.covest_reads_next.restype = ctypes.c_int
+    L.covest_reads_next.argtypes = [vp, i64, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)), ctypes.POINTER(i64p), i64p]
+    L.covest_reads_bytes.restype = i64
+    L.covest_reads_bytes.argtypes = [vp]
     L.covest_thin_histogram.restype = ctypes.c_int
     L.covest_thin_histogram.argtypes = [ctypes.c_int32, i64, ctypes.POINTER(ctypes.c_int32), dp, ctypes.c_double, i64, dp]
     L.covest_thin_histogram_timed.restype = ctypes.c_int
@@ -147,6 +156,13 @@ def lib():
     L.covest_grid_diag.argtypes = [vp, ctypes.POINTER(i64), i64]
     _lib = L
     return L
+
+
+COVEST_E_INVALID = -1
+
+
+def last_error():
+    return (lib().covest_last_error() or b"").decode()
 
 
 def check(status, what):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcovest_amd.so")
-SOURCES = ["capi.cpp", "ll_direct.hip", "ll_basic.hip", "ll_factored.hip", "argmin.hip", "kmer_count.hip", "thin_hist.hip"]
+SOURCES = ["capi.cpp", "reads_io.cpp", "ll_direct.hip", "ll_basic.hip", "ll_factored.hip", "argmin.hip", "kmer_count.hip", "thin_hist.hip"]
 ARCH = "gfx950"
 
 

@@ -32,6 +32,15 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
+} // namespace
+
+namespace covest {
+// for the library's other translation units (reads_io.cpp): record the message covest_last_error returns
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+} // namespace covest
+
+namespace {
+
 int fail_hip(hipError_t e, const char *what)
 {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);

@@ -126,6 +126,16 @@ class KmerCounts:
             offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(reads)), "covest_kmer_add")
         return self
 
+    def add_packed(self, bases, offsets, n_reads, n_bases):
+        """Preprocessed reads in the packed host layout of covest_kmer_add (ctypes pointers: the bases back to
+        back, offsets[n_reads + 1]) -- what ReadBatches yields."""
+        if n_reads <= 0:
+            return self
+        # k-mers the batch can add: sum(max(len - k + 1, 1)) <= n_bases + n_reads
+        self._reserve_for(int(n_bases) + int(n_reads))
+        _capi.check(_capi.lib().covest_kmer_add(self._handle, bases, offsets, int(n_reads)), "covest_kmer_add")
+        return self
+
     def add_device(self, d_bases_ptr, n_reads, read_len, d_offsets_ptr=None, stream=None, reserve=True):
         """Reads already resident in HBM (raw device pointers); asynchronous on `stream`.
         reserve=False: the caller sized the table for the DISTINCT k-mers it expects (an
@@ -174,38 +184,82 @@ def compute_histogram(counts):
     return counts.histogram()
 
 
-def load_reads(fname):
-    """Sequences of a FASTA or FASTQ file (the reference delegates this to Bio.SeqIO, :67-74)."""
-    _, ext = path.splitext(fname)
-    fastq = ext in ('.fq', '.fastq')
-    with open(fname) as f:
-        if fastq:
-            for i, line in enumerate(f):
-                if i % 4 == 1:
-                    yield line.strip()
-        else:
-            chunk = []
-            for line in f:
-                if line.startswith('>'):
-                    if chunk:
-                        yield ''.join(chunk)
-                    chunk = []
-                else:
-                    chunk.append(line.strip())
-            if chunk:
-                yield ''.join(chunk)
+class ReadBatches:
+    """load_reads + preprocess (bin/kmer_hist.py:67-74, :44-54) in the library's C++ reader (csrc/reads_io.cpp):
+    iterating yields (bases_ptr, offsets_ptr, n_reads, n_bases) batches in the packed layout covest_kmer_add takes
+    -- no per-read work in Python.  The pointers are the reader's own buffers, valid until the next batch."""
+
+    def __init__(self, fname, n_strategy=NS_IGNORE, batch_bases=1 << 28, seed=0):
+        if n_strategy not in (NS_IGNORE, NS_SINGLE, NS_RANDOM):
+            raise ValueError('Invalid N strategy')
+        self.batch_bases = int(batch_bases)
+        h = ctypes.c_void_p()
+        _capi.check(_capi.lib().covest_reads_open(str(fname).encode(), int(n_strategy), int(seed), ctypes.byref(h)),
+                    "covest_reads_open")
+        self._handle = h
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            _capi.lib().covest_reads_close(self._handle)
+            self._handle = None
+
+    __del__ = close
+
+    @property
+    def bytes_read(self):
+        return int(_capi.lib().covest_reads_bytes(self._handle))
+
+    def __iter__(self):
+        L = _capi.lib()
+        bases = ctypes.POINTER(ctypes.c_uint8)()
+        offsets = ctypes.POINTER(ctypes.c_int64)()
+        n = ctypes.c_int64()
+        while True:
+            rc = L.covest_reads_next(self._handle, self.batch_bases, ctypes.byref(bases), ctypes.byref(offsets),
+                                     ctypes.byref(n))
+            if rc == _capi.COVEST_E_INVALID and "outside acgtn" in _capi.last_error():
+                raise KeyError(_capi.last_error())  # single_hash raises KeyError (bin/kmer_hist.py:15)
+            _capi.check(rc, "covest_reads_next")
+            if n.value == 0:
+                return
+            yield bases, offsets, n.value, int(offsets[n.value])
 
 
-def main(fname, out_fname, k, n_strategy, canonical=False, batch=1 << 16):
-    """bin/kmer_hist.py:77-89, reads counted in batches of `batch` per launch."""
+def load_reads(fname, n_strategy=None):
+    """Sequences of a FASTA or FASTQ file, one str per record (bin/kmer_hist.py:67-74; the reference delegates the
+    parsing to Bio.SeqIO).  With n_strategy they come preprocessed (:44-54).  Kept for callers that want strings:
+    `main` feeds the packed batches of ReadBatches to the counter directly."""
+    if n_strategy is None:  # the records as they stand (the reader always applies preprocess): parsed here
+        _, ext = path.splitext(fname)
+        fastq = ext in ('.fq', '.fastq')
+        with open(fname) as f:
+            if fastq:
+                for i, line in enumerate(f):
+                    if i % 4 == 1:
+                        yield line.strip()
+            else:
+                chunk, seen = [], False
+                for line in f:
+                    if line.startswith('>'):
+                        if seen:
+                            yield ''.join(chunk)
+                        chunk, seen = [], True
+                    elif seen:
+                        chunk.append(''.join(line.split()))
+                if seen:
+                    yield ''.join(chunk)
+        return
+    for bases, offsets, n, n_bases in ReadBatches(fname, n_strategy, batch_bases=1 << 24):
+        blob = ctypes.string_at(bases, n_bases).decode("ascii")
+        for i in range(n):
+            yield blob[offsets[i]:offsets[i + 1]]
+
+
+def main(fname, out_fname, k, n_strategy, canonical=False, batch=1 << 28):
+    """bin/kmer_hist.py:77-89.  The file is parsed and preprocessed by the C++ reader, `batch` bases per launch."""
     counts = KmerCounts(k, canonical=canonical)
-    pending = []
-    for seq in load_reads(fname):
-        pending.append(preprocess(seq, n_strategy))
-        if len(pending) >= batch:
-            counts.add_reads(pending)
-            pending = []
-    counts.add_reads(pending)
+    for bases, offsets, n, n_bases in ReadBatches(fname, n_strategy, batch_bases=batch):
+        counts.add_packed(bases, offsets, n, n_bases)
     hist = compute_histogram(counts)
     if out_fname:
         with open(out_fname, 'w') as f:

@@ -209,6 +209,24 @@ int64_t covest_kmer_slots(const covest_kmer *c);
 /* Forget every count (counts = defaultdict(int) again), keeping the table's size; asynchronous on `stream`. */
 int covest_kmer_clear(covest_kmer *c, void *stream);
 
+/* ---- FASTA / FASTQ front-end of the k-mer histogram: bin/kmer_hist.py:44-54 preprocess, :67-74 load_reads ----
+ * HOST code (no GPU call): one pass over the file's bytes yields batches in the packed layout covest_kmer_add
+ * takes.  Format by extension, as the reference: ".fq" / ".fastq" = FASTQ (4-line records), anything else FASTA
+ * (a record = a '>' header line and the concatenation of the lines up to the next header; the reference leaves
+ * the parsing to Bio.SeqIO).  preprocess is applied on the way: lower case; 'n' dropped (n_strategy 0, IGNORE),
+ * replaced by 'a' (1, SINGLE) or by a random base (2, RANDOM: splitmix64 from `seed` -- the reference draws from
+ * Python's unseeded random, which nothing can reproduce).  Any other letter fails with COVEST_E_INVALID, where
+ * the reference's single_hash raises KeyError (:15).  An empty record is a read (it counts k-mer 0, :36-37). */
+typedef struct covest_reads covest_reads; /* opaque */
+int covest_reads_open(const char *path, int32_t n_strategy, uint64_t seed, covest_reads **out);
+void covest_reads_close(covest_reads *r);
+/* The next batch: whole reads, closed as soon as it holds max_bases bases or more (one read at least).
+ * *bases / *offsets[*n_reads + 1] stay valid until the next call on `r`; *n_reads == 0: end of file. */
+int covest_reads_next(covest_reads *r, int64_t max_bases, const uint8_t **bases, const int64_t **offsets,
+                      int64_t *n_reads);
+/* file bytes consumed so far */
+int64_t covest_reads_bytes(const covest_reads *r);
+
 /* ---- histogram down-sampling: covest/histogram.py:47-70 sample_histogram ----
  * Expected counts of the histogram after keeping every read with probability 1/factor, BEFORE the
  * reference's randomised rounding (:71-74, host side): out[j-1] = sum_i counts_i * pmf_i(j) for

@@ -123,3 +123,55 @@ def test_conservation_at_scale(hip_lib):
     add(c, codes)
     assert c.histogram() == h
     c.close()
+
+
+def test_one_gigabase_from_a_fasta_file(hip_lib, tmp_path):
+    """BASELINE config 5's shape at 1 Gbp, through the file front-end (C++ reader -> covest_kmer_add): 10^7 reads of
+    100 bases of a random 25 Mbp genome in a FASTA file (1.1 GB), no substitutions.  Properties that do not need
+    an oracle of that size: every window lands in exactly one bin; the distinct 21-mers are (almost all of) the
+    genome's; counting the file a second time into the same table doubles every count; and the canonical table of
+    the same file has no more keys than the forward one."""
+    from covest_amd import kmer_hist as kh
+    rng = np.random.default_rng(20240601)
+    n_reads, L, k, g_len = 10_000_000, 100, 21, 25_000_000
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = lut[rng.integers(0, 4, size=g_len, dtype=np.uint8)]
+    fa = tmp_path / "reads_1gbp.fa"
+    chunk = 500_000
+    hdr = np.frombuffer(b">r\n", dtype=np.uint8)
+    with open(fa, "wb") as f:
+        for a in range(0, n_reads, chunk):
+            starts = rng.integers(0, g_len - L, size=chunk)
+            rec = np.empty((chunk, 3 + L + 1), dtype=np.uint8)
+            rec[:, :3] = hdr
+            rec[:, 3:3 + L] = genome[starts[:, None] + np.arange(L)[None, :]]
+            rec[:, -1] = 10
+            f.write(rec.tobytes())
+    windows = n_reads * (L - k + 1)
+    counts = kh.KmerCounts(k, min_slots=4 * g_len)
+    n_seen = 0
+    for bases, offs, n, n_bases in kh.ReadBatches(str(fa), kh.NS_IGNORE, batch_bases=1 << 28):
+        counts.add_packed(bases, offs, n, n_bases)
+        n_seen += n
+    assert n_seen == n_reads
+    h1 = counts.histogram()
+    distinct = len(counts)
+    assert sum(i * v for i, v in enumerate(h1)) == windows
+    assert sum(h1) == distinct
+    # 40x coverage: all but a sliver of the genome's 21-mers are seen; a random 25 Mbp genome repeats almost none
+    assert 0.98 * (g_len - k + 1) < distinct <= g_len - k + 1
+    peak = int(np.argmax(h1[5:]) + 5)
+    assert abs(peak - n_reads * (L - k + 1) / g_len) < 4  # Poisson with mean 32
+    for bases, offs, n, n_bases in kh.ReadBatches(str(fa), kh.NS_IGNORE, batch_bases=1 << 28):
+        counts.add_packed(bases, offs, n, n_bases)
+    h2 = counts.histogram()
+    assert len(counts) == distinct
+    assert h2[1::2] == [0] * len(h2[1::2]) and h2[0::2][:len(h1)] == h1 and sum(h2) == sum(h1)
+    counts.close()
+    canon = kh.KmerCounts(k, canonical=True, min_slots=4 * g_len)
+    for bases, offs, n, n_bases in kh.ReadBatches(str(fa), kh.NS_IGNORE, batch_bases=1 << 28):
+        canon.add_packed(bases, offs, n, n_bases)
+    hc = canon.histogram()
+    assert sum(i * v for i, v in enumerate(hc)) == windows
+    assert len(canon) <= distinct
+    canon.close()

@@ -1,0 +1,77 @@
+"""The C++ FASTA / FASTQ reader (csrc/reads_io.cpp, covest_reads_* in include/covest_amd.h) against the
+reference's load_reads + preprocess semantics (bin/kmer_hist.py:44-54, :67-74).  Host code only: runs without a GPU."""
+import ctypes
+import random
+
+import pytest
+
+from covest_amd import kmer_hist as kh
+
+
+def _batches(path, strategy, batch_bases):
+    out = []
+    for bases, offs, n, n_bases in kh.ReadBatches(str(path), strategy, batch_bases=batch_bases):
+        blob = ctypes.string_at(bases, n_bases).decode("ascii")
+        assert offs[0] == 0 and offs[n] == n_bases
+        out += [blob[offs[i]:offs[i + 1]] for i in range(n)]
+    return out
+
+
+def test_fasta_records_and_n_strategies(tmp_path):
+    fa = tmp_path / "r.fa"
+    fa.write_text("text before the first header\n>r1 some description\nACGTNACGTACG\r\nTTTGACA\n>empty\n>r2\nNNACGTACGTAC")
+    raw = ["ACGTNACGTACGTTTGACA", "", "NNACGTACGTAC"]
+    assert list(kh.load_reads(str(fa))) == raw
+    for strategy in (kh.NS_IGNORE, kh.NS_SINGLE):
+        assert list(kh.load_reads(str(fa), strategy)) == [kh.preprocess(r, strategy) for r in raw]
+    rnd = list(kh.load_reads(str(fa), kh.NS_RANDOM))
+    assert [len(r) for r in rnd] == [len(r) for r in raw]
+    assert all(set(r) <= set("acgt") for r in rnd)
+    assert all(a == b.lower() or b == "N" for r, w in zip(rnd, raw) for a, b in zip(r, w))
+
+
+def test_fastq_records(tmp_path):
+    fq = tmp_path / "r.fastq"
+    fq.write_text("@a\nACGTACGT\n+\nIIIIIIII\n@b\nTTTTNCGT\n+\n@III>III\n@c\nAC")  # a quality line starting with '@'
+    assert list(kh.load_reads(str(fq), kh.NS_IGNORE)) == ["acgtacgt", "ttttcgt", "ac"]
+    assert list(kh.load_reads(str(fq), kh.NS_SINGLE)) == ["acgtacgt", "ttttacgt", "ac"]
+
+
+def test_other_letters_are_a_keyerror(tmp_path):
+    for name, text in (("b.fa", ">x\nACGT\nACRT\n"), ("b.fq", "@x\nACGU\n+\nIIII\n")):
+        f = tmp_path / name
+        f.write_text(text)
+        with pytest.raises(KeyError):  # single_hash, bin/kmer_hist.py:15
+            list(kh.load_reads(str(f), kh.NS_IGNORE))
+    with pytest.raises(ValueError):
+        kh.ReadBatches(str(tmp_path / "b.fa"), 7)
+    with pytest.raises(Exception):
+        kh.ReadBatches(str(tmp_path / "missing.fa"), kh.NS_IGNORE)
+
+
+@pytest.mark.parametrize("batch_bases", [1, 1000, 1 << 22])
+def test_batches_are_whole_reads_whatever_their_size(tmp_path, batch_bases):
+    rng = random.Random(5)
+    reads = ["".join(rng.choice("ACGTNacgtn") for _ in range(rng.randint(0, 400))) for _ in range(3000)]
+    fa = tmp_path / "many.fa"
+    with open(fa, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(">read_%d %s\n" % (i, "x" * rng.randint(0, 50)))
+            for j in range(0, len(r), 70):
+                f.write(r[j:j + 70] + "\n")
+    assert _batches(fa, kh.NS_IGNORE, batch_bases) == [kh.preprocess(r, kh.NS_IGNORE) for r in reads]
+
+
+def test_a_file_larger_than_the_read_buffer(tmp_path):
+    # 8 MiB of file per fread: headers, sequence lines and records all straddle the refills
+    rng = random.Random(9)
+    line = "".join(rng.choice("ACGT") for _ in range(997))
+    fa = tmp_path / "big.fa"
+    n = 20000
+    with open(fa, "w") as f:
+        for i in range(n):
+            f.write(">r%d\n%s\n%s\n" % (i, line[i % 100:], "N" * (i % 3)))
+    got = _batches(fa, kh.NS_SINGLE, 1 << 20)
+    assert len(got) == n
+    assert all(got[i] == (line[i % 100:] + "a" * (i % 3)).lower() for i in range(0, n, 97))
+    assert sum(len(g) for g in got) == sum(997 - i % 100 + i % 3 for i in range(n))
