@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 #include "direct_point.h"
 #include "fastmath.h"
@@ -222,43 +223,66 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     load_weights();
 
     // ================= phase A: G[key][o] of key tile t into `dst` =================
+    // the 32 keys of a full tile with the streams 0 .. N-1 (the others are zero in every lane of the wave)
+    auto walk_tile = [&](auto n_tag, const double *scal, double *colp, double renorm) __attribute__((always_inline)) {
+        constexpr int N = decltype(n_tag)::value;
+        // squared rates (the streams advance two keys per step, streams.h step2): N multiplies per tile
+        // rather than 16 registers held through phases B and C -- the empty asm keeps the compiler from
+        // hoisting them back out of the tile loop (it would spill them)
+        double xx[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            double xs = st.x[s];
+            if (s < N) {
+                asm volatile("" : "+v"(xs));
+                xx[s] = xs * xs;
+            } else {
+                xx[s] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < kTileBins; b += 2) {
+            double g1, g2;
+            st.template step2n<N>(xx, g1, g2);
+            g1 *= scal[b];
+            g2 *= scal[b + 1];
+            if (lane_in_row) {
+                colp[b * LD] = g1;
+                colp[(b + 1) * LD] = g2;
+            }
+        }
+        st.template leave_tile_n<N>(renorm);
+    };
     auto build_tile = [&](int t, bool seg_start, double *dst) __attribute__((always_inline)) {
         if (plan.skip_phases & 1)
             return;
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
-        st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                      tv.run_start[t] != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
+        // n_live: streams above it are zero in every lane of this wave (streams.h) -- most of them, for most tiles
+        const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
+                                         tv.run_start[t] != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         double *colp = dst + (lane_in_row ? tid : 0);
         if (nb == kTileBins) { // the common case: straight-line code, scales in SGPRs
-            // squared rates (the streams advance two keys per step, streams.h step2): 8 multiplies per tile
-            // rather than 16 registers held through phases B and C -- the empty asm keeps the compiler from
-            // hoisting them back out of the tile loop (it would spill them)
-            double xx[8];
+            if (n_live > 4) {
+                walk_tile(std::integral_constant<int, 8>{}, scal, colp, tv.renorm[t]);
+            } else if (n_live > 2) {
+                walk_tile(std::integral_constant<int, 4>{}, scal, colp, tv.renorm[t]);
+            } else if (n_live == 2) {
+                walk_tile(std::integral_constant<int, 2>{}, scal, colp, tv.renorm[t]);
+            } else if (n_live == 1) {
+                walk_tile(std::integral_constant<int, 1>{}, scal, colp, tv.renorm[t]);
+            } else if (lane_in_row) { // nothing is on: G = 0 for this wave's copy numbers
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                double xs = st.x[s];
-                asm volatile("" : "+v"(xs));
-                xx[s] = xs * xs;
+                for (int b = 0; b < kTileBins; ++b)
+                    colp[b * LD] = 0.0;
             }
-#pragma unroll
-            for (int b = 0; b < kTileBins; b += 2) {
-                double g1, g2;
-                st.step2(xx, g1, g2);
-                g1 *= scal[b];
-                g2 *= scal[b + 1];
-                if (lane_in_row) {
-                    colp[b * LD] = g1;
-                    colp[(b + 1) * LD] = g2;
-                }
-            }
-        } else {
-            for (int b = 0; b < kTileBins; ++b) {
-                const double g = b < nb ? st.step() * scal[b] : 0.0;
-                if (lane_in_row)
-                    colp[b * LD] = g;
-            }
+            return;
+        }
+        for (int b = 0; b < kTileBins; ++b) {
+            const double g = b < nb ? st.step() * scal[b] : 0.0;
+            if (lane_in_row)
+                colp[b * LD] = g;
         }
         st.leave_tile(tv.renorm[t]);
     };

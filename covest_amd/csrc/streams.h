@@ -104,9 +104,14 @@ struct StreamSet {
     // Entering a tile: streams that are off (v == 0) and whose log-term reaches
     // the window inside this tile, or all streams at a run start, get
     // v = u_{k0-1} * 2^SC from one exp.  km1 = k0 - 1, klast = last key of the tile.
-    __device__ __forceinline__ void enter_tile(double km1, double klast, double lgam_prev,
-                                               double lgam_last, bool run_start)
+    // Returns 1 + the highest stream that is on in ANY lane of the wave (0: none): the streams above it hold exact
+    // zeros in every lane, and a caller may leave them out of the tile's steps (stepN below) -- adding their zeros
+    // changes no bit.  The error classes' rates fall geometrically with s (covest/models.py:74-79), so along the
+    // keys the streams go out from the top: beyond the first few hundred keys one or two of the eight are left.
+    __device__ __forceinline__ int enter_tile(double km1, double klast, double lgam_prev,
+                                              double lgam_last, bool run_start)
     {
+        int n_live = 0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const double lx = an.lx(s), c = an.c(s);
@@ -130,7 +135,10 @@ struct StreamSet {
                 const double anchored = deep ? e0 : ldexp(e0, kScaleBits);
                 v[s] = need ? anchored : v[s];
             }
+            if (__any(v[s] != 0.0))
+                n_live = s + 1; // wave-uniform
         }
+        return n_live;
     }
 
     // Advance every stream by one key and return the sum of the scaled terms.  (Splitting
@@ -163,6 +171,32 @@ struct StreamSet {
             v[s] *= xx[s];
             g2 += v[s];
         }
+    }
+
+    // step2 / squares / leave_tile over the streams 0 .. N-1 only (the others are zero in every lane: enter_tile)
+    template <int N>
+    __device__ __forceinline__ void step2n(const double (&xx)[S], double &g1, double &g2)
+    {
+        static_assert(N >= 1 && N <= S, "live streams");
+        g1 = v[0] * x[0];
+#pragma unroll
+        for (int s = 1; s < N; ++s)
+            g1 = fma(v[s], x[s], g1);
+        v[0] *= xx[0];
+        g2 = v[0];
+#pragma unroll
+        for (int s = 1; s < N; ++s) {
+            v[s] *= xx[s];
+            g2 += v[s];
+        }
+    }
+
+    template <int N>
+    __device__ __forceinline__ void leave_tile_n(double renorm)
+    {
+#pragma unroll
+        for (int s = 0; s < N; ++s)
+            v[s] *= renorm;
     }
 
     __device__ __forceinline__ void squares(double (&xx)[S]) const
