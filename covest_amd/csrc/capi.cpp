@@ -538,7 +538,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     const int n_columns = n_pass == 1 ? max_o : n_pass * pass_stride;
     // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
     const int ld = ((n_columns + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 8192 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 11264 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const int n_units = 2 * n_qtiles;
     const int hu = kHalfUnits; // (768 threads with 2 slots per half, 3 waves/SIMD, was measured: +1 %)
     const int mu = 2 * hu;
@@ -918,7 +918,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     for (int64_t i = 0; i < n; ++i)
         t_max = std::max(t_max, std::min(513, (int)t_list[(size_t)i] - o_base_of(i)));
     const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 8192 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 11264 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
     std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 3 * 64, 0.0);
     std::vector<int32_t> q_t(n_slots, 0), q_orig(n_slots, -1), unit_tile(n_unit, -1), unit_half(n_unit, 0),

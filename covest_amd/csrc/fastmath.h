@@ -4,10 +4,10 @@
 // microbench_f64.hip) -- it became the dominant cost once a pmf term is down to 2
 // instructions.  The log-likelihood needs log(p_j) to an ABSOLUTE accuracy of a few
 // 1e-16 (it is summed with weights h_j into a total whose terms all have the same
-// sign), so: exponent/mantissa split (v_frexp_*), a 64-entry table {1/c, log c'}
-// in LDS indexed by the top 6 mantissa bits, r = fma(m, 1/c, -1) with |r| <= 2^-7,
-// and log1p(r) to r^7.  ~18 instructions, absolute error < 2e-16 (relative
-// < 2e-16 for |log x| > 1) for x in (0, 1].
+// sign), so: exponent/mantissa split (v_frexp_*), a 256-entry table {1/c, log c'}
+// in LDS (4 KB) indexed by the top 8 mantissa bits, r = fma(m, 1/c, -1) with |r| <= 2^-9,
+// and log1p(r) to r^5 (a 64-entry table needs r^7: two more FMAs per log).  ~16 instructions,
+// absolute error < 2e-16 (relative < 2e-16 for |log x| > 1) for x in (0, 1].
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -44,13 +44,18 @@ __device__ __forceinline__ double fast_log(double x, const double *tab_lds)
     // byte offset of the 16-byte entry: the top kLogTableBits mantissa bits
     const unsigned off = __builtin_amdgcn_ubfe((unsigned)__double2hiint(m), 20 - kLogTableBits, kLogTableBits) << 4;
     const double2 ent = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab_lds) + off);
-    const double r = fma(m, ent.x, -1.0); // |r| <= 2^-7
-    double q = fma_vvs(r, 1.0 / 7.0, -1.0 / 6.0);
-    q = fma_vvs(r, q, 0.2);
-    q = fma_vvs(r, q, -0.25);
+    const double r = fma(m, ent.x, -1.0); // |r| <= 2^-(kLogTableBits + 1)
+    double q;
+    if (kLogTableBits >= 8) { // |r| <= 2^-9: log1p(r) to r^5, truncation r^6/6 < 2^-56
+        q = fma_vvs(r, 0.2, -0.25);
+    } else { // |r| <= 2^-7: to r^7, truncation r^8/8 < 2^-59
+        q = fma_vvs(r, 1.0 / 7.0, -1.0 / 6.0);
+        q = fma_vvs(r, q, 0.2);
+        q = fma_vvs(r, q, -0.25);
+    }
     q = fma_vvs(r, q, 1.0 / 3.0);
     q = fma(r, q, -0.5);
-    const double lp = fma(r * r, q, r); // log1p(r), truncation r^8/8 < 2^-59
+    const double lp = fma(r * r, q, r); // log1p(r)
     return fma((double)e, 0.693147180559945309417232121458, ent.y) + lp;
 }
 

@@ -497,18 +497,20 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 // (the accumulators are not kept alive for it), and sorted out in a branch the wave takes for one
                 // unit in twenty.  Filler and padding keys have h == 0 (`if h`, covest/models.py:106) and add
                 // 0 * log below.
+                // (the compare does not look at h: rows without a count -- filler keys, a tile's padding -- have
+                // p == 0 and come through here too, in the few tiles that have such rows, and are sorted out inside)
                 uint64_t low[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
-                    low[r] = __ballot(acc[k][r] < p_clamp && h != 0.0);
-                }
+                for (int r = 0; r < 4; ++r)
+                    low[r] = __ballot(acc[k][r] < p_clamp);
                 if (__builtin_expect(((low[0] | low[1] | low[2] | low[3]) & ~dead[k]) != 0, 0)) {
                     // wave-uniform, cold (a lane that is dead already has nothing more to report).  Kept SHORT: a
                     // wave in here holds up its whole workgroup at the tile's barrier
                     uint64_t subm = 0, zero = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
+                        low[r] &= __ballot(h != 0.0);
                         const uint64_t z = __ballot(acc[k][r] <= 0.0) & low[r];
                         zero |= z;
                         subm |= low[r] & ~z;
