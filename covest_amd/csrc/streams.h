@@ -61,6 +61,7 @@ struct StreamSet {
     double v[S];   // scaled running term (see header)
     double x[S];   // o * lambda_s
     Anchors an;
+    unsigned gone; // (wave-uniform) streams that are off in every lane and past their mode: they never come back
 
     // Mixture weights and constants of one (copy number o) over the S error
     // classes: covest/models.py:85-90 (o = 1) and :217-233.
@@ -77,6 +78,7 @@ struct StreamSet {
     {
         double n_os[S];
         double tot = 0.0;
+        gone = 0u;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             x[s] = (double)o * lam[s];
@@ -114,6 +116,8 @@ struct StreamSet {
         int n_live = 0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
+            if ((gone >> s) & 1u)
+                continue; // wave-uniform: nothing to test, v[s] is 0 in every lane and stays 0
             const double lx = an.lx(s), c = an.c(s);
             const double a0 = fma(km1, lx, c - lgam_prev);
             const double a1 = fma(klast, lx, c - lgam_last);
@@ -137,6 +141,9 @@ struct StreamSet {
             }
             if (__any(v[s] != 0.0))
                 n_live = s + 1; // wave-uniform
+            else if (!__any(in_window || !(km1 >= x[s])))
+                gone |= 1u << s; // off, outside the window and past the mode (the log-term is concave in the key,
+                                 // its top near x): in every lane, for every later key
         }
         return n_live;
     }
