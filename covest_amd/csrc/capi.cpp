@@ -538,7 +538,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     const int n_columns = n_pass == 1 ? max_o : n_pass * pass_stride;
     // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
     const int ld = ((n_columns + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 11264 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 11776 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const int n_units = 2 * n_qtiles;
     const int hu = kHalfUnits; // (768 threads with 2 slots per half, 3 waves/SIMD, was measured: +1 %)
     const int mu = 2 * hu;
@@ -667,6 +667,10 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
                     w = head * geo;
                     geo *= base;
                 }
+                // (the piece's first step needs no mask in the kernel: a copy number at or beyond the column's
+                // cut-off gets weight 0 here -- covest/models.py:239; later steps are cut off by the step count)
+                if (d < 4 && unit_o0[at] + d >= (int)q_t[(size_t)qt * 16 + (size_t)colx])
+                    w = 0.0;
                 piece_w[(at * 3 + (size_t)(d >> 2)) * 64 + (size_t)((d & 3) * 16 + colx)] = w;
             }
             if (unit_nsh[at] > 0) {
@@ -918,7 +922,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     for (int64_t i = 0; i < n; ++i)
         t_max = std::max(t_max, std::min(513, (int)t_list[(size_t)i] - o_base_of(i)));
     const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 11264 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 11776 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
     std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 3 * 64, 0.0);
     std::vector<int32_t> q_t(n_slots, 0), q_orig(n_slots, -1), unit_tile(n_unit, -1), unit_half(n_unit, 0),
@@ -949,9 +953,12 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
                 unit_len[at] = piece_len;
                 unit_cont[at] = k > 0;
                 for (int which = 0; which < 2; ++which)
-                    for (int kq = 0; kq < 4; ++kq) // column 0 only: lanes 16 kq
+                    for (int kq = 0; kq < 4; ++kq) { // column 0 only: lanes 16 kq
+                        const int o_local = 1 + 4 * (unit_s0[at] + which) + kq;
+                        // (the piece's first step comes masked by the cut-off, as in build_plan_part)
                         piece_w[(at * 3 + (size_t)which) * 64 + (size_t)(16 * kq)] =
-                            copy_number_weight_host(q1, q2, q, ob + 1 + 4 * (unit_s0[at] + which) + kq);
+                            (which == 0 && o_local >= t) ? 0.0 : copy_number_weight_host(q1, q2, q, ob + o_local);
+                    }
             }
     }
     std::vector<std::pair<const void *, size_t>> dparts = {{axes.data(), axes.size()}, {r4.data(), r4.size()},

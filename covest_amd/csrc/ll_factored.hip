@@ -100,6 +100,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         sub_rec[2 * i + 1] = 0;
     }
     // (1-q)^-4 and (1-q)^-16 of every slot with shared steps (tiles.h): wave-uniform, read back as LDS broadcasts
+    // the counts h_j of the key tile being logged and of the next one: every unit reads the 4 rows of its lanes
+    // from here (LDS, addressed by the unit's half) instead of selecting between two register sets per row
+    __shared__ __attribute__((aligned(16))) double hbuf[2][kTileBins];
     __shared__ __attribute__((aligned(16))) double rho_tab[PLAIN ? NW * MU * 2 : 2];
     if (PLAIN && threadIdx.x < NW * MU * 2)
         rho_tab[threadIdx.x] = plan.unit_rho[(int64_t)blockIdx.y * NW * MU * 2 + threadIdx.x];
@@ -353,6 +356,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // With two buffers the builders fill tile t+1 while every wave contracts tile t: one
     // barrier per tile, and the host's unit assignment charges the builders for phase A.
     const bool dbuf = plan.n_buf == 2;
+    if (tid < kTileBins && t_begin < t_end)
+        hbuf[t_begin & 1][tid] = tv.item_cnt[(int64_t)t_begin * kTileBins + tid]; // (a barrier follows before phase C)
     if (dbuf && t_begin < t_end) {
         if (wave_builds)
             build_item(t_begin, Gs + (t_begin & 1) * kTileBins * LD);
@@ -360,6 +365,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
     for (int t = t_begin; t < t_end; ++t) {
         const double *cur = Gs + (dbuf ? (t & 1) * kTileBins * LD : 0);
+        if (tid < kTileBins && t + 1 < t_end) // read after this iteration's closing barrier
+            hbuf[(t + 1) & 1][tid] = tv.item_cnt[(int64_t)(t + 1) * kTileBins + tid];
         if (!dbuf) {
             if (wave_builds)
                 build_item(t, Gs);
@@ -371,66 +378,47 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 
         // ================= phase B: P = G x b on the matrix pipe =================
         d4 acc[MU];
-        // the shared steps (tiles.h): sum_{i = 1 .. nsh} G[key][1 + 4 i + kq] r4^(i - 1) for this lane's key and
-        // o mod 4 -- Horner from the far end, two chains (odd and even steps) -- then ONE MFMA whose B is b_o of
-        // step 1: the four lanes of a key add up inside it, every column gets its beta
-        if (PLAIN && (nsh[0] | nsh[1] | nsh[2] | nsh[3] | nsh[4] | nsh[5])) { // wave-uniform
-#pragma unroll
-            for (int k = 0; k < MU; ++k) {
-                acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
-                if (nsh[k] == 0) // wave-uniform
-                    continue;
-                // Weights RELATIVE TO THE FIRST STEP AFTER the shared ones, whose b_o the slot holds anyway (wrun):
-                //   sum_i G[key][1 + 4 i + kq] rho^(nsh + 1 - i),  rho = (1-q)^-4  (wave-uniform: the tile has one q)
-                // Four Horner chains in rho^4 over ascending steps -- eight loads in flight per trip of the loop: a
-                // lane's steps are 4 columns apart in LDS, and one wave in two on this SIMD sits in the same loop,
-                // so nothing else hides their latency.  (rho^(4 nsh) <= 1e10: the cut-off is where b_o reaches 1e-8.)
-                const double rho = rho_tab[2 * (wave * MU + k)], rho4 = rho_tab[2 * (wave * MU + k) + 1]; // (LDS broadcast)
-                const double *g1 = cur + (a_off[k] - 4 * nsh[k]); // step 0 of the unit (o = 1 .. 4); step i at g1[4 i]
-                const int n4 = nsh[k] >> 2, rem = nsh[k] & 3;
-                // chain c: the steps i with (nsh - i) mod 4 == c; the first `rem` steps are the chains' heads
-                double h0 = rem > 0 ? g1[4 * rem] : 0.0, h1 = rem > 1 ? g1[4 * (rem - 1)] : 0.0,
-                       h2 = rem > 2 ? g1[4 * (rem - 2)] : 0.0, h3 = 0.0;
-                const double *q = g1 + 4 * (rem + 1);
-                int gq = 0;
-                for (; gq + 2 <= n4; gq += 2, q += 32) {
-                    const double a3 = q[0], a2 = q[4], a1 = q[8], a0 = q[12];
-                    const double b3 = q[16], b2 = q[20], b1 = q[24], b0 = q[28];
-                    h3 = fma(fma(h3, rho4, a3), rho4, b3);
-                    h2 = fma(fma(h2, rho4, a2), rho4, b2);
-                    h1 = fma(fma(h1, rho4, a1), rho4, b1);
-                    h0 = fma(fma(h0, rho4, a0), rho4, b0);
-                }
-                if (gq < n4) {
-                    h3 = fma(h3, rho4, q[0]);
-                    h2 = fma(h2, rho4, q[4]);
-                    h1 = fma(h1, rho4, q[8]);
-                    h0 = fma(h0, rho4, q[12]);
-                }
-                const double hs = rho * fma(fma(fma(h3, rho, h2), rho, h1), rho, h0);
-                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(hs, wrun[k], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < MU; ++k)
-                acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
-        }
-        // counts of the 8 rows this lane will log (latency hidden under the MFMAs)
-        double hrow[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int bin = 16 * u + kq + 4 * r;
-                hrow[u][r] = tv.item_cnt[(int64_t)t * kTileBins + bin];
-            }
-        // the piece's first step (weights wfirst/wrun were fetched during the previous tile's logs)
+        // Every slot's accumulator starts from its first MFMA (C = 0 costs nothing; zeroing 8 registers per slot does).
+        // A unit with shared steps (tiles.h) first sums them: sum_{i = 1 .. nsh} G[key][1 + 4 i + kq] rho^(nsh + 1 - i)
+        // for this lane's key and o mod 4 (rho = (1-q)^-4, wave-uniform: the tile has one q) -- weights RELATIVE TO
+        // THE FIRST STEP AFTER the shared ones, whose b_o the slot holds anyway (wrun) -- and ONE MFMA brings the
+        // sum in: the four lanes of a key add up inside it, every column gets its own b_o.  Then step 0 (o = 1 .. 4;
+        // its weights come masked by the cut-off from the host).
+        const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
-            if (len[k] > 0) { // wave-uniform
-                const double w = (0 < cut[k] + nsh[k]) ? wfirst[k] : 0.0;
-                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[a_off[k] - 4 * nsh[k]], w, acc[k], 0, 0, 0);
+            if (!PLAIN || nsh[k] == 0) { // wave-uniform
+                acc[k] = len[k] > 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(cur[a_off[k]], wfirst[k], zero4, 0, 0, 0) : zero4;
+                continue;
             }
+            // Four Horner chains in rho^4 over ascending steps -- eight loads in flight per trip of the loop: a
+            // lane's steps are 4 columns apart in LDS, and one wave in two on this SIMD sits in the same loop,
+            // so nothing else hides their latency.  (rho^(4 nsh) <= 1e10: the cut-off is where b_o reaches 1e-8.)
+            const double rho = rho_tab[2 * (wave * MU + k)], rho4 = rho_tab[2 * (wave * MU + k) + 1]; // (LDS broadcast)
+            const double *g1 = cur + (a_off[k] - 4 * nsh[k]); // step 0 of the unit (o = 1 .. 4); step i at g1[4 i]
+            const int n4 = nsh[k] >> 2, rem = nsh[k] & 3;
+            // chain c: the steps i with (nsh - i) mod 4 == c; the first `rem` steps are the chains' heads
+            double h0 = rem > 0 ? g1[4 * rem] : 0.0, h1 = rem > 1 ? g1[4 * (rem - 1)] : 0.0,
+                   h2 = rem > 2 ? g1[4 * (rem - 2)] : 0.0, h3 = 0.0;
+            const double *q = g1 + 4 * (rem + 1);
+            int gq = 0;
+            for (; gq + 2 <= n4; gq += 2, q += 32) {
+                const double a3 = q[0], a2 = q[4], a1 = q[8], a0 = q[12];
+                const double b3 = q[16], b2 = q[20], b1 = q[24], b0 = q[28];
+                h3 = fma(fma(h3, rho4, a3), rho4, b3);
+                h2 = fma(fma(h2, rho4, a2), rho4, b2);
+                h1 = fma(fma(h1, rho4, a1), rho4, b1);
+                h0 = fma(fma(h0, rho4, a0), rho4, b0);
+            }
+            if (gq < n4) {
+                h3 = fma(h3, rho4, q[0]);
+                h2 = fma(h2, rho4, q[4]);
+                h1 = fma(h1, rho4, q[8]);
+                h0 = fma(h0, rho4, q[12]);
+            }
+            const double hs = rho * fma(fma(fma(h3, rho, h2), rho, h1), rho, h0);
+            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(hs, wrun[k], zero4, 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(g1[0], wfirst[k], acc[k], 0, 0, 0);
         }
         STAMP(dg_b0)
         // the remaining steps, specialised on the number of slots still running (len is sorted)
@@ -499,6 +487,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 // 0 * log below.
                 // (the compare does not look at h: rows without a count -- filler keys, a tile's padding -- have
                 // p == 0 and come through here too, in the few tiles that have such rows, and are sorted out inside)
+                const double *hp = &hbuf[t & 1][16 * uhalf[k] + kq]; // h of this lane's rows kq, kq + 4, ...
                 uint64_t low[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -509,7 +498,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     uint64_t subm = 0, zero = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
+                        const double h = hp[4 * r];
                         low[r] &= __ballot(h != 0.0);
                         const uint64_t z = __ballot(acc[k][r] <= 0.0) & low[r];
                         zero |= z;
@@ -533,7 +522,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double h = uhalf[k] ? hrow[1][r] : hrow[0][r];
+                    const double h = hp[4 * r];
                     const double p = acc[k][r];
                     if (TAIL)
                         spacc[k].add(p); // (filler and padding keys: p == 0)

@@ -22,4 +22,16 @@ timeout -k 10 200 python3 bench.py --workload og --steps 5 > "$out/bench_og.json
 timeout -k 10 200 python3 bench.py --scaling strong --steps 5 --warmup 1 --cpu-budget 0 > "$out/bench_c3_strong_1gpu.json" 2> "$out/bench_strong.err"
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --backend gloo --share-gpu --scaling strong --steps 5 --warmup 1 --cpu-budget 0 2> "$out/bench_2rank.err" | tail -1 > "$out/bench_c3_strong_2rank_gloo_rehearsal.json"
 COVEST_FACTORED_DIAG=1 timeout -k 10 100 python3 tools/factored_diag.py > "$out/c3_factored_phase_stamps.txt" 2>&1
+# the rows either side of the path, the shapes that used to fall back, the microbenchmarks behind DESIGN's rooflines
+timeout -k 10 300 python3 bench.py --workload c5 --kmer-gbp 1 --steps 5 --warmup 1 > "$out/bench_c5_1gbp.json" 2> "$out/bench_c5.err"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c5" -o c5 -- python3 bench.py --workload c5 --kmer-gbp 1 --steps 3 --warmup 1 --cpu-budget 0 > /dev/null 2> "$out/trace_c5.err"
+find "$out/trace_c5" -name "*kernel_stats.csv" -exec cp {} "$out/c5_kernel_stats.csv" \;
+rm -rf "$out/trace_c5"
+timeout -k 10 200 python3 bench.py --workload f2 > "$out/bench_f2.json" 2> "$out/bench_f2.err"
+timeout -k 10 100 python3 bench.py --workload f3 > "$out/bench_f3.json" 2> "$out/bench_f3.err"
+timeout -k 10 200 python3 tools/time_cliffs.py > "$out/cliffs.txt" 2>&1
+timeout -k 10 100 python3 tools/time_tail.py > "$out/tail_timing.txt" 2>&1
+timeout -k 10 100 python3 tools/latency.py > "$out/latency_single_evaluation.txt" 2>&1
+[ -x tools/bin/microbench_atomics ] && timeout -k 10 100 tools/bin/microbench_atomics > "$out/microbench_atomics.txt" 2>&1
+[ -x tools/bin/microbench_contract ] && timeout -k 10 60 tools/bin/microbench_contract > "$out/microbench_contract.txt" 2>&1
 ls "$out"
