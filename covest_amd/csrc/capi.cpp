@@ -805,6 +805,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     const int64_t group = qo.n1 * qo.n2, group_padded = (group + 15) / 16 * 16;
     const char *share_env = std::getenv("COVEST_FACTORED_SHARE");
     const bool share = n_pass == 1 && 3 * (group_padded - group) <= group && !(share_env && std::atoi(share_env) == 0);
+    const int min_shared = std::getenv("COVEST_FACTORED_MIN_SHARED") ? std::atoi(std::getenv("COVEST_FACTORED_MIN_SHARED")) : kMinSharedSteps;
     auto by_t = [&](int32_t a, int32_t b) { return t_table[(size_t)a] > t_table[(size_t)b]; };
     if (!share) {
         std::vector<int32_t> all((size_t)qo.nq);
@@ -845,7 +846,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
             // steps 1 .. nsh cover o = 5 .. 4 + 4 nsh, all below the tile's smallest threshold_o; a tile of the
             // long part (threshold_o - 1 > chunk) is contracted chunk by chunk, without them
             const int n = (tiles[t].t_lo - 5) / 4;
-            qo.tile_nsh[t] = (tiles[t].t_hi - 1 <= chunk && n >= kMinSharedSteps) ? n : 0;
+            qo.tile_nsh[t] = (tiles[t].t_hi - 1 <= chunk && n >= min_shared) ? n : 0;
         }
     }
     // useful flops of the contraction per row (covest_grid_work): 2 per (column, o < T) of the MFMA steps, 2 per
