@@ -420,6 +420,54 @@ def test_factored_plan_shapes(hip_lib, oracle):
         print("factored plan shape:", name, "points", fac.total, "worst rel err vs direct", worst)
 
 
+def test_shared_steps_layouts(hip_lib, oracle, monkeypatch):
+    """K-factored's shared steps (tiles.h): the weight vectors of one q fill whole q-tiles of 16 -- exactly (16), with
+    padding columns inside the order (12 -> 16, 27 -> 32, 36 -> 48), or not at all (9: too much padding, the plain
+    order).  Each layout against K-direct on the whole grid, against the same grid with the sharing switched off
+    (COVEST_FACTORED_SHARE=0: every step an MFMA step), and against the oracle on a sample; the grid cut into
+    blocks gives bit-identical values."""
+    from covest_amd import DenseGrid, RepeatsModel
+    rng = np.random.default_rng(11)
+    hist = {j: int(v) for j, v in zip(range(1, 301), rng.integers(1, 3000, size=300))}
+    q_axis = np.array([0.04, 0.07, 0.15, 0.33, 0.6, 0.97])  # threshold_o from ~350 down to 8
+    for n1, n2, tail in ((4, 4, 0), (4, 3, 0), (9, 3, 7), (6, 6, 0), (3, 3, 0)):
+        axes = [np.array([14.0, 27.0]), np.array([0.01, 0.06]), np.linspace(0.3, 0.95, n1),
+                np.linspace(0.05, 0.9, n2) if n2 > 1 else np.array([0.5]), q_axis]
+        m = RepeatsModel(21, 100, hist, tail, max_error=8)
+        om = oracle.OracleModel("repeats", 21, 100, hist, tail, max_error=8)
+        name = "shared steps %dx%d tail %d" % (n1, n2, tail)
+        fac = DenseGrid(m, axes)
+        fac.evaluate(kernel="factored")
+        ll = fac.loglikelihoods()
+        ref = DenseGrid(m, axes)
+        ref.evaluate(kernel="direct")
+        _check(ll, ref.loglikelihoods(), name + " vs direct", tol=1e-10)
+        assert fac.argmin()[1] == ref.argmin()[1]
+        monkeypatch.setenv("COVEST_FACTORED_SHARE", "0")
+        plain = DenseGrid(m, axes)
+        plain.evaluate(kernel="factored")
+        monkeypatch.delenv("COVEST_FACTORED_SHARE")
+        _check(ll, plain.loglikelihoods(), name + " vs the plain order", tol=1e-12)
+        # two blocks of the flat range: the same plan, the same bits
+        half = fac.total // 2 + 3
+        parts = []
+        for lo, hi in ((0, half), (half, fac.total)):
+            blk = DenseGrid(m, axes, flat_range=(lo, hi))
+            blk.evaluate(kernel="factored")
+            parts.append(blk.loglikelihoods())
+            blk.close()
+        assert np.array_equal(np.concatenate(parts), ll, equal_nan=True), name
+        sel = rng.choice(fac.total, size=16, replace=False)
+        pts = np.array([fac.point(i) for i in sel])
+        want = om.compute_loglikelihood_many(pts, n_threads=16)
+        slack = _tail_noise(om, pts, want, tail)
+        _slack_budget(name, slack)
+        _check(ll[sel], want, name + " vs oracle", slack=slack)
+        for g in (fac, ref, plain):
+            g.close()
+        m.close()
+
+
 def test_threshold_fixture_through_capi(hip_lib):
     from covest_amd import RepeatsModel
     g = load_golden("threshold_o.json")
