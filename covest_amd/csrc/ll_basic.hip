@@ -19,6 +19,8 @@
 // Algorithmic HBM bytes: 16 in (or the two axes) + 8 out per point.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "direct_point.h"
 #include "fastmath.h"
 #include "kernels.h"
@@ -88,21 +90,27 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
         }
     };
 
-    for (int t = 0; t < tv.n_tiles; ++t) {
+    // One key tile with the streams 0 .. N-1 (N = S: all of them; N = 1: see below).
+    auto do_tile = [&](auto n_tag, int t) __attribute__((always_inline)) {
+        constexpr int N = decltype(n_tag)::value;
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
-        st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                      tv.run_start[t] != 0);
+        st.template enter_tile_n<N>(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
+                                    tv.run_start[t] != 0);
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         const double *cnt = tv.cnt + (int64_t)t * kTileBins;
+        double xx[S]; // squared rates, recomputed per tile (N multiplies) rather than held in 2 S registers
+        if (nb == kTileBins) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                xx[s] = s < N ? st.x[s] * st.x[s] : 0.0;
+        }
         if (TAIL && tv.all_zero[t] != 0) {
             // a tile without a single count (they exist only with a tail): its keys take no log, only their
             // p_j enter sp_j (covest/models.py:103) -- add them up plainly (32 terms of one sign) and hand the
             // compensated accumulator ONE value per tile
             double tile_sum = 0.0;
             if (nb == kTileBins) {
-                double xx[S];
-                st.squares(xx);
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     double sc[16];
@@ -112,19 +120,17 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
 #pragma unroll
                     for (int b = 0; b < 16; b += 2) {
                         double g1, g2;
-                        st.step2(xx, g1, g2);
+                        st.template step2n<N>(xx, g1, g2);
                         tile_sum = fma(g1, sc[b], tile_sum);
                         tile_sum = fma(g2, sc[b + 1], tile_sum);
                     }
                 }
             } else {
                 for (int b = 0; b < nb; ++b)
-                    tile_sum = fma(st.step(), scal[b], tile_sum);
+                    tile_sum = fma(st.template step_n<N>(), scal[b], tile_sum);
             }
             acc_sp.add(tile_sum);
         } else if (nb == kTileBins) {
-            double xx[S]; // squared rates, recomputed per tile (S multiplies) rather than held in 2 S registers
-            st.squares(xx);
             // full tile: two straight-line halves of 16 keys, their scales and counts fetched
             // into SGPRs up front (s_load_dwordx16) so no key waits on the scalar cache; the
             // streams advance two keys per step (streams.h step2)
@@ -139,17 +145,27 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
 #pragma unroll
                 for (int b = 0; b < 16; b += 2) {
                     double g1, g2;
-                    st.step2(xx, g1, g2);
+                    st.template step2n<N>(xx, g1, g2);
                     account(g1 * sc[b], hc[b], t * kTileBins + 16 * half + b);
                     account(g2 * sc[b + 1], hc[b + 1], t * kTileBins + 16 * half + b + 1);
                 }
             }
         } else {
             for (int b = 0; b < nb; ++b)
-                account(st.step() * scal[b], cnt[b], t * kTileBins + b);
+                account(st.template step_n<N>() * scal[b], cnt[b], t * kTileBins + b);
         }
-        st.leave_tile(tv.renorm[t]);
-    }
+        st.template leave_tile_n<N>(tv.renorm[t]);
+    };
+    // The rates of the error classes fall geometrically (covest/models.py:74-79): along the keys the streams go out
+    // from the top, and once every class but the error-free one has gone for good in all lanes of the wave
+    // (streams.h `gone`: off, outside the window, past the mode) the rest of the tiles -- most of them, for a
+    // histogram whose counted keys lie in the hundreds and thousands -- is walked with that one stream, in a loop of
+    // its own so that the other streams' registers are free there.  Their terms are exact zeros: no bit changes.
+    int t = 0;
+    for (; t < tv.n_tiles && !st.only_first_left(); ++t)
+        do_tile(std::integral_constant<int, S>{}, t);
+    for (; t < tv.n_tiles; ++t)
+        do_tile(std::integral_constant<int, 1>{}, t);
 
     double tail_term = 0.0;
     if (TAIL) {

@@ -113,9 +113,17 @@ struct StreamSet {
     __device__ __forceinline__ int enter_tile(double km1, double klast, double lgam_prev,
                                               double lgam_last, bool run_start)
     {
+        return enter_tile_n<S>(km1, klast, lgam_prev, lgam_last, run_start);
+    }
+
+    // ... looking at the streams 0 .. N-1 only: for a caller that has seen the others go for good (`gone`)
+    template <int N>
+    __device__ __forceinline__ int enter_tile_n(double km1, double klast, double lgam_prev,
+                                                double lgam_last, bool run_start)
+    {
         int n_live = 0;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
+        for (int s = 0; s < N; ++s) {
             if ((gone >> s) & 1u)
                 continue; // wave-uniform: nothing to test, v[s] is 0 in every lane and stays 0
             const double lx = an.lx(s), c = an.c(s);
@@ -197,6 +205,22 @@ struct StreamSet {
             g2 += v[s];
         }
     }
+
+    template <int N>
+    __device__ __forceinline__ double step_n()
+    {
+        v[0] *= x[0];
+        double g = v[0];
+#pragma unroll
+        for (int s = 1; s < N; ++s) {
+            v[s] *= x[s];
+            g += v[s];
+        }
+        return g;
+    }
+
+    // true once every stream but the first has gone for good (wave-uniform)
+    __device__ __forceinline__ bool only_first_left() const { return (gone | 1u) == (~0u >> (32 - S)); }
 
     template <int N>
     __device__ __forceinline__ void leave_tile_n(double renorm)
