@@ -707,6 +707,18 @@ def main():
                         "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
+        if kernel_name == "ll_factored" and world == 1 and model.tail == 0:
+            # The same kernel time on ROUND 1's flop count of K-factored (one multiply-add per (key, column, o < T)
+            # in the contraction; since round 2 the steps below a q-tile's smallest cut-off are summed once per key --
+            # DESIGN.md 4): for comparison with the 0.37 of round 1 only, `frac` above is the honest one.
+            import itertools
+            q123 = np.array(list(itertools.product(*axes[2:5])))
+            t_q = model.get_hist_threshold_values(q123).astype(np.float64)
+            bins, n_ce, max_o = float(model.bins_evaluated), float(shape[0] * shape[1]), float(t_q.max() - 1)
+            flops_r1 = n_ce * (bins * 8 * max_o * 2.0 + bins * float((t_q - 1).sum()) * 2.0 + bins * len(t_q) * 25.0
+                               + 25.0 * 8 * max_o)
+            out["roofline"]["round1_flop_count"] = {"algorithmic_flops_per_launch": flops_r1,
+                                                    "frac": flops_r1 / avg_kernel_s / 1e12 / FP64_PEAK_TFLOPS}
         if per_rank_kernel_ms is not None:
             out["multi_gpu"] = {"per_rank_kernel_ms": per_rank_kernel_ms,
                                 "kernel_imbalance": max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / world),

@@ -642,7 +642,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         }
     }
     // weights of every slot's first two MFMA steps, per lane (lane = 16 * (o mod 4) + column)
-    std::vector<double> piece_w(n_unit * 3 * 64, 0.0), unit_rho(n_unit * 2, 1.0);
+    std::vector<double> piece_w(n_unit * 64 * 2, 0.0), unit_rho(n_unit * 2, 1.0);
     // (eight consecutive copy numbers per slot and column: one libm pow, the rest by multiplication -- the kernel
     // advances the weights the same way from the third step on; a grid with few (c, e) pairs has many slots)
     for (size_t at = 0; at < n_unit; ++at) {
@@ -671,7 +671,10 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
                 // cut-off gets weight 0 here -- covest/models.py:239; later steps are cut off by the step count)
                 if (d < 4 && unit_o0[at] + d >= (int)q_t[(size_t)qt * 16 + (size_t)colx])
                     w = 0.0;
-                piece_w[(at * 3 + (size_t)(d >> 2)) * 64 + (size_t)((d & 3) * 16 + colx)] = w;
+                // layout [slot][lane][2]: {first step, the step the kernel's running weight starts from} -- the second
+                // step of the piece, or (units with shared steps) the first step after them, written below
+                if (d < 4 || unit_nsh[at] == 0)
+                    piece_w[(at * 64 + (size_t)((d & 3) * 16 + colx)) * 2 + (size_t)(d >> 2)] = w;
             }
             if (unit_nsh[at] > 0) {
                 // (one q per tile: every live column writes the same two values)
@@ -682,7 +685,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
                 const int o_after = o_first + 4 * (unit_nsh[at] + 1);
                 double g2 = std::pow(base, (double)(o_after - 3));
                 for (int d = 0; d < 4; ++d, g2 *= base)
-                    piece_w[(at * 3 + 2) * 64 + (size_t)(d * 16 + colx)] = head * g2;
+                    piece_w[(at * 64 + (size_t)(d * 16 + colx)) * 2 + 1] = head * g2;
             }
         }
     }
@@ -925,7 +928,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
     const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 11776 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
     const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
-    std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 3 * 64, 0.0);
+    std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 64 * 2, 0.0);
     std::vector<int32_t> q_t(n_slots, 0), q_orig(n_slots, -1), unit_tile(n_unit, -1), unit_half(n_unit, 0),
         unit_s0(n_unit, 0), unit_o0(n_unit, 1), unit_len(n_unit, 0), unit_cont(n_unit, 0);
     for (int64_t p = 0; p < n; ++p) {
@@ -957,7 +960,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
                     for (int kq = 0; kq < 4; ++kq) { // column 0 only: lanes 16 kq
                         const int o_local = 1 + 4 * (unit_s0[at] + which) + kq;
                         // (the piece's first step comes masked by the cut-off, as in build_plan_part)
-                        piece_w[(at * 3 + (size_t)which) * 64 + (size_t)(16 * kq)] =
+                        piece_w[(at * 64 + (size_t)(16 * kq)) * 2 + (size_t)which] =
                             (which == 0 && o_local >= t) ? 0.0 : copy_number_weight_host(q1, q2, q, ob + o_local);
                     }
             }

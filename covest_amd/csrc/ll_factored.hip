@@ -218,9 +218,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     auto load_weights = [&]() {
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
-            const double *pw = plan.piece_w + ((int64_t)(slot_base + k) * 3) * kWave + lane;
-            wfirst[k] = pw[0];
-            wrun[k] = pw[(PLAIN && nsh[k]) ? 2 * kWave : kWave];
+            // ONE 16-byte load per slot: {b_o of the first step, b_o the running weight starts from}
+            const double2 pw = reinterpret_cast<const double2 *>(plan.piece_w)[(int64_t)(slot_base + k) * kWave + lane];
+            wfirst[k] = pw.x;
+            wrun[k] = pw.y;
         }
     };
     load_weights();

@@ -120,9 +120,10 @@ struct FactoredPlan {
     const int32_t *unit_cont;      // 1 = this slot continues the unit of the slot before it
     const int32_t *unit_nsh;       // SHARED steps of the slot's unit (0: none), see below
     const double *unit_rho;        // [slots][2] (1-q)^-4 and (1-q)^-16 of the unit's q-tile (units with unit_nsh > 0)
-    const double *piece_w;         // [slots][3][64 lanes] b_o at the piece's first and second step
-                                   //   (o = 1 + 4 step + lane/16, column lane%16), libm pow on the host; third:
-                                   //   b_o at the first step AFTER the shared ones (units with unit_nsh > 0)
+    const double *piece_w;         // [slots][64 lanes][2] b_o at the piece's first step (masked by the column's
+                                   //   cut-off) and at its second (o = 1 + 4 step + lane/16, column lane%16), libm
+                                   //   pow on the host; units with unit_nsh > 0: second = the first step AFTER the
+                                   //   shared ones.  16-byte aligned (one load per slot and lane)
     // Shared steps.  The 16 weight vectors of a q-tile of a dense grid can be chosen to differ in q1 and q2 only
     // (the host sorts the product that way when it pays): then b_o = beta_col (1-q)^(o-3) for o >= 3, and for
     // the copy numbers below EVERY column's cut-off the contraction  sum_o G[key][o] b_o(col)  is beta_col times a
