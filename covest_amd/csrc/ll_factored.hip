@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
-            if (!PLAIN || nsh[k] == 0) { // wave-uniform
+            if (!PLAIN || nsh[k] == 0 || (plan.skip_phases & 8)) { // wave-uniform (skip bit 8: profiling aid, tiles.h)
                 acc[k] = len[k] > 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(cur[a_off[k]], wfirst[k], zero4, 0, 0, 0) : zero4;
                 continue;
             }

@@ -162,7 +162,7 @@ struct FactoredPlan {
     int64_t ce_first;              // list_mode 3: the (c, e) of partial's first row
     int64_t n_cols_partial;        // list_mode 3: weight-vector slots per (c, e) in partial
     long long *diag;               // PROFILING ONLY (env COVEST_FACTORED_DIAG): per-wave s_memtime sums [wg][wave][8]
-    int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C; results are wrong
+    int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C, bit 3 the shared steps; results are wrong
 };
 
 } // namespace covest
