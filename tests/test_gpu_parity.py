@@ -324,6 +324,45 @@ def test_config4_c3_in_eight_blocks(hip_lib):
     assert best[1] == 165489
 
 
+def test_strong_scaling_grid_sampled_against_direct(hip_lib, oracle):
+    """The fixed grid of `bench.py --scaling strong` (c128 x e128 x 16 x 1 x 16 = 4.2 M points): K-factored on the
+    whole grid against K-direct on 4 000 seeded points and against the oracle on 6 (its faithful O(j) product
+    manages half a point a second on this histogram); cut into 8 blocks balanced by
+    sum(T - 1), every block reproduces its slice bit for bit and the scan of the blocks' pairs is the whole grid's
+    arg-min (what N ranks compute, on one device)."""
+    import bench
+    from covest_amd import DenseGrid, RepeatsModel
+    from covest_amd.grid import partition_flat_range, repeats_cost_weights, scan_min_pairs
+    kind, hname, axes = bench.workload("c3", 1, "strong")
+    hist = load_hist(hname)
+    m = RepeatsModel(21, 100, hist, 0, max_error=8)
+    whole = DenseGrid(m, axes)
+    whole.evaluate()
+    assert whole.work()[2] == "ll_factored" and whole.total == 128 * 128 * 256
+    ll = whole.loglikelihoods()
+    best = whole.argmin()
+    assert best[1] == int(np.nanargmin(-ll)) and best[0] == float(-ll[best[1]])
+    rng = np.random.default_rng(20240905)
+    sel = np.sort(rng.choice(whole.total, size=4000, replace=False))
+    pts = np.array([whole.point(i) for i in sel])
+    _check(ll[sel], m.loglikelihood_points(pts, kernel="direct"), "strong grid vs K-direct", tol=1e-10)
+    om = oracle.OracleModel("repeats", 21, 100, hist, 0, max_error=8)
+    few = sel[rng.choice(len(sel), size=6, replace=False)]
+    _check(ll[few], om.compute_loglikelihood_many(np.array([whole.point(i) for i in few]), n_threads=16),
+           "strong grid vs oracle")
+    bounds = partition_flat_range(whole.total, 8, repeats_cost_weights(m, axes))
+    pairs = []
+    for r in range(8):
+        g = DenseGrid(m, axes, (bounds[r], bounds[r + 1]))
+        g.evaluate()
+        assert np.array_equal(g.loglikelihoods(), ll[bounds[r]:bounds[r + 1]], equal_nan=True), r
+        pairs.append(g.argmin())
+        g.close()
+    assert scan_min_pairs(pairs) == best
+    whole.close()
+    m.close()
+
+
 @pytest.mark.parametrize("tail", [0, 1000])
 @pytest.mark.parametrize("hname", ["sim_c10_e0.05", "sim_c10_e0.05_sparse", "sim_c10_e0"])
 def test_factored_small_histograms(hip_lib, oracle, hname, tail):
