@@ -468,13 +468,17 @@ def test_shared_steps_layouts(hip_lib, oracle, monkeypatch):
     from covest_amd import DenseGrid, RepeatsModel
     rng = np.random.default_rng(11)
     hist = {j: int(v) for j, v in zip(range(1, 301), rng.integers(1, 3000, size=300))}
-    q_axis = np.array([0.04, 0.07, 0.15, 0.33, 0.6, 0.97])  # threshold_o from ~350 down to 8
-    for n1, n2, tail in ((4, 4, 0), (4, 3, 0), (9, 3, 7), (6, 6, 0), (3, 3, 0)):
-        axes = [np.array([14.0, 27.0]), np.array([0.01, 0.06]), np.linspace(0.3, 0.95, n1),
-                np.linspace(0.05, 0.9, n2) if n2 > 1 else np.array([0.5]), q_axis]
+    q_short = np.array([0.04, 0.07, 0.15, 0.33, 0.6, 0.97])  # threshold_o from ~350 down to 8
+    # ... and with weight vectors beyond a workgroup's 512 lanes in the same grid (threshold_o ~1500 at q = 0.0105):
+    # their q-tiles go chunk by chunk without shared steps, the others share
+    q_long = np.array([0.0105, 0.02, 0.08, 0.5])
+    for n1, n2, tail, q_axis in ((4, 4, 0, q_short), (4, 3, 0, q_short), (9, 3, 7, q_short), (6, 6, 0, q_short),
+                                 (3, 3, 0, q_short), (4, 4, 0, q_long), (4, 3, 5, q_long)):
+        axes = [np.array([14.0, 27.0]) if q_axis is q_short else np.array([1.2, 2.5]), np.array([0.01, 0.06]),
+                np.linspace(0.3, 0.95, n1), np.linspace(0.05, 0.9, n2) if n2 > 1 else np.array([0.5]), q_axis]
         m = RepeatsModel(21, 100, hist, tail, max_error=8)
         om = oracle.OracleModel("repeats", 21, 100, hist, tail, max_error=8)
-        name = "shared steps %dx%d tail %d" % (n1, n2, tail)
+        name = "shared steps %dx%d tail %d%s" % (n1, n2, tail, "" if q_axis is q_short else " long")
         fac = DenseGrid(m, axes)
         fac.evaluate(kernel="factored")
         ll = fac.loglikelihoods()
