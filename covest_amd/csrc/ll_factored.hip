@@ -227,6 +227,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     load_weights();
 
     // ================= phase A: G[key][o] of key tile t into `dst` =================
+    // in-kernel stamps (diagnostic runs only): cycles per wave in build / contract / log / barrier
+    long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0, dg_zero = 0;
+    const bool diag = plan.diag != nullptr;
     // the 32 keys of a full tile with the streams 0 .. N-1 (the others are zero in every lane of the wave)
     auto walk_tile = [&](auto n_tag, const double *scal, double *colp, double renorm) __attribute__((always_inline)) {
         constexpr int N = decltype(n_tag)::value;
@@ -277,6 +280,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             } else if (n_live == 1) {
                 walk_tile(std::integral_constant<int, 1>{}, scal, colp, tv.renorm[t]);
             } else if (lane_in_row) { // nothing is on: G = 0 for this wave's copy numbers
+                if (diag)
+                    dg_zero += 1;
 #pragma unroll
                 for (int b = 0; b < kTileBins; ++b)
                     colp[b * LD] = 0.0;
@@ -343,8 +348,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     };
 
     // in-kernel stamps (diagnostic runs only): cycles per wave in build / contract / log / barrier
-    long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0;
-    const bool diag = plan.diag != nullptr;
 #define STAMP(acc)                                    \
     if (diag) {                                       \
         const long long now__ = (long long)clock64(); \
@@ -547,6 +550,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         d[2] = dg_c;
         d[3] = dg_w;
         d[4] = dg_b0;
+        d[5] = dg_zero; // key tiles whose G columns of this (builder) wave were all zero
     }
 #undef STAMP
     if (list_mode >= 2)

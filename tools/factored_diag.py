@@ -25,8 +25,8 @@ d = buf.reshape(-1, 8, 8)[:, :, :4].astype(np.float64)  # [wg][wave][build, cont
 extra = buf.reshape(-1, 8, 8)
 print("workgroups", d.shape[0], "units logged per wave %.1f, of which through the cold branch %.1f" % (
     extra[:, :, 6].mean(), extra[:, :, 5].mean()))
-for w in range(8):
-    print("  wave %d: units %.1f cold %.1f" % (w, extra[:, w, 6].mean(), extra[:, w, 5].mean()))
+print("key tiles (of %d) whose 64 G columns of a builder wave were all zero: " % 31 +
+      "  ".join("wave %d: %.1f" % (w, extra[:, w, 5].mean()) for w in range(5)))
 tot = d.sum(axis=2)
 print("mean cycles per wave (s_memtime ticks): total %.0f" % tot.mean())
 for w in range(8):
