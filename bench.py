@@ -196,10 +196,10 @@ def cpu_baseline(kind, hist, axes, budget_s, seed=20240521):
 SCATTERED_PAIRS_PER_S = 1.96e10  # tools/microbench_atomics.hip, row C, 16 GB table (profiles/r02_microbench_atomics.txt)
 
 
-def kmer_from_file(reads, n_reads, read_len, k, counts, cap_reads=4_000_000):
+def kmer_from_file(reads, n_reads, read_len, k, counts, cap_reads=10_000_000):
     """Config 5 'from a FASTA file': the first `cap_reads` reads of the same synthetic set written to a FASTA file on
     local disk (untimed), then timed end to end -- the C++ reader (parse + preprocess), covest_kmer_add (H2D copy +
-    count) per 2^28-base batch, the count-of-counts histogram.  Host-bound: reported beside `value`, never as it."""
+    count) per 2^26-base batch -- the next batch parsed while the GPU counts this one --, the count-of-counts histogram.  Host-bound: reported beside `value`, never as it."""
     import tempfile
     from covest_amd import kmer_hist as kh
     n = min(n_reads, cap_reads)

@@ -189,7 +189,7 @@ class ReadBatches:
     iterating yields (bases_ptr, offsets_ptr, n_reads, n_bases) batches in the packed layout covest_kmer_add takes
     -- no per-read work in Python.  The pointers are the reader's own buffers, valid until the next batch."""
 
-    def __init__(self, fname, n_strategy=NS_IGNORE, batch_bases=1 << 28, seed=0):
+    def __init__(self, fname, n_strategy=NS_IGNORE, batch_bases=1 << 26, seed=0):
         if n_strategy not in (NS_IGNORE, NS_SINGLE, NS_RANDOM):
             raise ValueError('Invalid N strategy')
         self.batch_bases = int(batch_bases)
@@ -209,20 +209,36 @@ class ReadBatches:
     def bytes_read(self):
         return int(_capi.lib().covest_reads_bytes(self._handle))
 
-    def __iter__(self):
+    def _next(self):
+        """One covest_reads_next call: (bases, offsets, n_reads, n_bases), or an exception instance."""
         L = _capi.lib()
         bases = ctypes.POINTER(ctypes.c_uint8)()
         offsets = ctypes.POINTER(ctypes.c_int64)()
         n = ctypes.c_int64()
-        while True:
-            rc = L.covest_reads_next(self._handle, self.batch_bases, ctypes.byref(bases), ctypes.byref(offsets),
-                                     ctypes.byref(n))
-            if rc == _capi.COVEST_E_INVALID and "outside acgtn" in _capi.last_error():
-                raise KeyError(_capi.last_error())  # single_hash raises KeyError (bin/kmer_hist.py:15)
-            _capi.check(rc, "covest_reads_next")
-            if n.value == 0:
-                return
-            yield bases, offsets, n.value, int(offsets[n.value])
+        rc = L.covest_reads_next(self._handle, self.batch_bases, ctypes.byref(bases), ctypes.byref(offsets),
+                                 ctypes.byref(n))
+        if rc != 0:
+            msg = _capi.last_error()  # (thread-local in the library: read it on the thread that made the call)
+            if rc == _capi.COVEST_E_INVALID and "outside acgtn" in msg:
+                return KeyError(msg)  # single_hash raises KeyError (bin/kmer_hist.py:15)
+            return _capi.CovestHipError("covest_reads_next failed (%d): %s" % (rc, msg))
+        return bases, offsets, n.value, int(offsets[n.value])
+
+    def __iter__(self):
+        """Batches in file order.  The reader keeps two batch buffers, so the NEXT batch is parsed on a helper
+        thread (the library's own threads do the work; ctypes releases the GIL) while the caller -- the GPU --
+        is busy with the one just handed out."""
+        import concurrent.futures
+        with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+            pending = pool.submit(self._next)
+            while True:
+                got = pending.result()
+                if isinstance(got, Exception):
+                    raise got
+                if got[2] == 0:
+                    return
+                pending = pool.submit(self._next)  # fills the OTHER buffer: `got` stays valid until the call after
+                yield got
 
 
 def load_reads(fname, n_strategy=None):
@@ -255,7 +271,7 @@ def load_reads(fname, n_strategy=None):
             yield blob[offsets[i]:offsets[i + 1]]
 
 
-def main(fname, out_fname, k, n_strategy, canonical=False, batch=1 << 28):
+def main(fname, out_fname, k, n_strategy, canonical=False, batch=1 << 26):
     """bin/kmer_hist.py:77-89.  The file is parsed and preprocessed by the C++ reader, `batch` bases per launch."""
     counts = KmerCounts(k, canonical=canonical)
     for bases, offsets, n, n_bases in ReadBatches(fname, n_strategy, batch_bases=batch):

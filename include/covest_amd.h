@@ -210,18 +210,21 @@ int64_t covest_kmer_slots(const covest_kmer *c);
 int covest_kmer_clear(covest_kmer *c, void *stream);
 
 /* ---- FASTA / FASTQ front-end of the k-mer histogram: bin/kmer_hist.py:44-54 preprocess, :67-74 load_reads ----
- * HOST code (no GPU call): one pass over the file's bytes yields batches in the packed layout covest_kmer_add
- * takes.  Format by extension, as the reference: ".fq" / ".fastq" = FASTQ (4-line records), anything else FASTA
+ * HOST code (the only HIP calls: a device count and the allocation of page-locked buffers): the mapped file
+ * is parsed span by span into batches in the packed layout covest_kmer_add takes.  Format by extension, as the reference: ".fq" / ".fastq" = FASTQ (4-line records), anything else FASTA
  * (a record = a '>' header line and the concatenation of the lines up to the next header; the reference leaves
  * the parsing to Bio.SeqIO).  preprocess is applied on the way: lower case; 'n' dropped (n_strategy 0, IGNORE),
- * replaced by 'a' (1, SINGLE) or by a random base (2, RANDOM: splitmix64 from `seed` -- the reference draws from
- * Python's unseeded random, which nothing can reproduce).  Any other letter fails with COVEST_E_INVALID, where
+ * replaced by 'a' (1, SINGLE) or by a random base (2, RANDOM: a hash of `seed` and of the N's position in the
+ * file -- the reference draws from Python's unseeded random, which nothing can reproduce).  Any other letter fails with COVEST_E_INVALID, where
  * the reference's single_hash raises KeyError (:15).  An empty record is a read (it counts k-mer 0, :36-37). */
 typedef struct covest_reads covest_reads; /* opaque */
 int covest_reads_open(const char *path, int32_t n_strategy, uint64_t seed, covest_reads **out);
 void covest_reads_close(covest_reads *r);
-/* The next batch: whole reads, closed as soon as it holds max_bases bases or more (one read at least).
- * *bases / *offsets[*n_reads + 1] stay valid until the next call on `r`; *n_reads == 0: end of file. */
+/* The next batch: whole reads, about max_bases bases of them (the span of the file that holds that many, up to the
+ * next record boundary; one read at least), parsed by several threads (COVEST_READER_THREADS, default: the
+ * machine's, 16 at most).  Two batch buffers alternate: *bases / *offsets[*n_reads + 1] stay valid until the call
+ * AFTER the next one on `r`, so batch i + 1 can be parsed while batch i is being counted.  The buffers are
+ * page-locked when the process has a HIP device (COVEST_READER_PINNED=0: never).  *n_reads == 0: end of file. */
 int covest_reads_next(covest_reads *r, int64_t max_bases, const uint8_t **bases, const int64_t **offsets,
                       int64_t *n_reads);
 /* file bytes consumed so far */

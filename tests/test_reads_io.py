@@ -75,3 +75,34 @@ def test_a_file_larger_than_the_read_buffer(tmp_path):
     assert len(got) == n
     assert all(got[i] == (line[i % 100:] + "a" * (i % 3)).lower() for i in range(0, n, 97))
     assert sum(len(g) for g in got) == sum(997 - i % 100 + i % 3 for i in range(n))
+
+
+def test_threads_cut_the_file_at_record_boundaries(tmp_path, monkeypatch):
+    """Several threads parse one batch (the span is cut at record starts): the same reads whatever the thread count,
+    for FASTA and for a FASTQ whose quality lines keep starting with '@' (the character that also opens a header);
+    NS_RANDOM depends on the seed and on where an N stands in the file, not on the threads."""
+    rng = random.Random(21)
+    reads = ["".join(rng.choice("ACGTN" if i % 50 == 0 else "ACGT") for _ in range(rng.randint(1, 300)))
+             for i in range(60000)]
+    fa, fq = tmp_path / "t.fa", tmp_path / "t.fq"
+    with open(fa, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(">r%d\n%s\n" % (i, r))
+    with open(fq, "w") as f:
+        for i, r in enumerate(reads):
+            qual = ("@" if i % 3 else "+") + "I" * (len(r) - 1)
+            f.write("@r%d\n%s\n+\n%s\n" % (i, r, qual))
+    want = [kh.preprocess(r, kh.NS_IGNORE) for r in reads]
+    results = {}
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("COVEST_READER_THREADS", threads)
+        for path in (fa, fq):
+            assert _batches(path, kh.NS_IGNORE, 1 << 22) == want, (threads, path.name)
+        results[threads] = _batches(fa, kh.NS_RANDOM, 1 << 22)
+    assert results["1"] == results["3"] == results["8"]
+    assert [len(r) for r in results["1"]] == [len(r) for r in reads]
+    other_seed = []
+    for bases, offs, n, n_bases in kh.ReadBatches(str(fa), kh.NS_RANDOM, batch_bases=1 << 22, seed=5):
+        blob = ctypes.string_at(bases, n_bases).decode("ascii")
+        other_seed += [blob[offs[i]:offs[i + 1]] for i in range(n)]
+    assert other_seed != results["1"] and [len(r) for r in other_seed] == [len(r) for r in reads]
