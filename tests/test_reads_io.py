@@ -106,3 +106,21 @@ def test_threads_cut_the_file_at_record_boundaries(tmp_path, monkeypatch):
         blob = ctypes.string_at(bases, n_bases).decode("ascii")
         other_seed += [blob[offs[i]:offs[i + 1]] for i in range(n)]
     assert other_seed != results["1"] and [len(r) for r in other_seed] == [len(r) for r in reads]
+
+
+def test_degenerate_files(tmp_path):
+    empty = tmp_path / "empty.fa"
+    empty.write_text("")
+    assert list(kh.load_reads(str(empty), kh.NS_IGNORE)) == []
+    junk = tmp_path / "junk.fa"
+    junk.write_text("no header anywhere\nACGT\n")
+    assert list(kh.load_reads(str(junk), kh.NS_IGNORE)) == []
+    one = tmp_path / "one.fa"  # one record much longer than a batch, no newline at the end of the file
+    rng = random.Random(3)
+    seq = "".join(rng.choice("acgt") for _ in range(3_000_000))
+    one.write_text(">chr\n" + "\n".join(seq[i:i + 80] for i in range(0, len(seq), 80)))
+    got = _batches(one, kh.NS_IGNORE, 1000)
+    assert len(got) == 1 and got[0] == seq
+    lone = tmp_path / "lone.fq"
+    lone.write_text("@r\nACGT")
+    assert list(kh.load_reads(str(lone), kh.NS_IGNORE)) == ["acgt"]
