@@ -59,4 +59,53 @@ __device__ __forceinline__ double fast_log(double x, const double *tab_lds)
     return fma((double)e, 0.693147180559945309417232121458, ent.y) + lp;
 }
 
+// The raw instruction: llvm's fmax quiets its operands first (a v_max_f64 x, x, x each) -- two extra full-rate
+// slots per log for a NaN nobody feeds it (a NaN parameter poisons the result by other means).
+__device__ __forceinline__ double max_raw(double a, double b)
+{
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// N logs at once, written stage by stage so that the N table reads are in flight together and the N dependent
+// chains interleave: one log after the other exposes the LDS latency and the latency of every FMA of its chain,
+// which two waves per SIMD do not hide (ll_factored.hip).
+template <int N>
+__device__ __forceinline__ void fast_log_n(const double (&x)[N], double (&out)[N], const double *tab_lds)
+{
+    double m[N], r[N], q[N], lp[N];
+    int e[N];
+    double2 ent[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        m[k] = __builtin_amdgcn_frexp_mant(x[k]);
+        e[k] = __builtin_amdgcn_frexp_exp(x[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const unsigned off = __builtin_amdgcn_ubfe((unsigned)__double2hiint(m[k]), 20 - kLogTableBits, kLogTableBits) << 4;
+        ent[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab_lds) + off);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        r[k] = fma(m[k], ent[k].x, -1.0);
+    static_assert(kLogTableBits >= 8, "log1p to r^5 needs |r| <= 2^-9");
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        q[k] = fma_vvs(r[k], 0.2, -0.25);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        q[k] = fma_vvs(r[k], q[k], 1.0 / 3.0);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        q[k] = fma(r[k], q[k], -0.5);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        lp[k] = fma(r[k] * r[k], q[k], r[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        out[k] = fma((double)e[k], 0.693147180559945309417232121458, ent[k].y) + lp[k];
+}
+
 } // namespace covest

@@ -524,17 +524,25 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                         rec[1] = max(rec[1], u + 1);
                     }
                 }
+                // no branch on h (it differs between the lanes' rows): the four logs of a unit go through fast_log_n
+                // stage by stage, their table reads in flight together.  log(max(p_j, p_clamp)): what a p_j deep in
+                // the subnormal range contributes is then a known constant, which the strict evaluation of that key
+                // replaces (direct_point.h)
+                double pc4[4], lg4[4], h4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h4[r] = hp[4 * r]; // (LDS: in flight under the logs)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double h = hp[4 * r];
                     const double p = acc[k][r];
                     if (TAIL)
                         spacc[k].add(p); // (filler and padding keys: p == 0)
-                    // no branch on h (it differs between the lanes' rows): the four logs of a unit are straight-line
-                    // code and interleave.  log(max(p_j, p_clamp)): what a p_j deep in the subnormal range contributes
-                    // is then a known constant, which the strict evaluation of that key replaces (direct_point.h)
-                    llacc[k] = fma(h, fast_log(fmax(p, p_clamp), log_tab), llacc[k]);
+                    pc4[r] = max_raw(p, p_clamp);
                 }
+                fast_log_n<4>(pc4, lg4, log_tab);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    llacc[k] = fma(h4[r], lg4[r], llacc[k]);
                 __builtin_amdgcn_sched_barrier(0); // ... one unit at a time: registers
             }
         }
