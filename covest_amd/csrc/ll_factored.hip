@@ -24,6 +24,17 @@
 //            f64 C/D layout a lane keeps ONE q column, so the running LL of a unit
 //            is a single register per lane (fast_log, fastmath.h).
 //
+// Round 2 (each step in DESIGN.md 6):
+//   * phase A walks a tile with the LIVE error classes only: the classes' rates fall geometrically, so beyond the
+//     first few hundred keys two of the eight streams are left and the others hold exact zeros in every lane
+//     (streams.h enter_tile / `gone`): variants of the straight-line walk for 8, 4, 2, 1 and no stream;
+//   * SHARED STEPS (tiles.h): the host lays the weight vectors out so that a q-tile's 16 columns differ in q1, q2
+//     only; below the tile's smallest cut-off the contraction is then beta_col times a sum that does not depend
+//     on the column -- summed once per key on the vector unit (Horner in (1-q)^-4) and brought in by ONE MFMA;
+//   * the four logs of a unit go through fast_log_n stage by stage (their table reads in flight together);
+//   * a p_j deep in the subnormal range is clamped and its row recorded: ll_fix_list_kernel (argmin.hip) redoes
+//     those rows with K-direct's arithmetic (direct_point.h).
+//
 // The unit of phases B/C is (q-tile of 16 weight vectors, half of the key tile);
 // the host deals units to waves longest-first, balanced per SIMD (tiles.h), and a
 // wave's o-loop stops at its own unit's T.  gfx950 measured (tools/
