@@ -1952,8 +1952,8 @@ int kmer_alloc_table(covest_kmer *c, int64_t min_slots, KmerTable &t, DevBuf &sl
     t.slots = slots.as<KmerSlot>();
     t.mask = n - 1;
     t.log2_slots = lg;
+    t.k = c->k;
     HIP_TRY(launch_kmer_fill_empty(t, nullptr));
-    (void)c;
     return COVEST_OK;
 }
 

@@ -72,6 +72,7 @@ struct KmerTable {
     KmerSlot *slots;
     unsigned long long mask;
     int log2_slots;
+    int k; // bases per key (a key's first slot is a function of its minimizer: kmer_count.hip)
 };
 hipError_t launch_kmer_fill_empty(const KmerTable &t, hipStream_t stream);
 // bases: ASCII acgt/ACGT; offsets[n_reads + 1] or nullptr with every read `fixed_len` long.

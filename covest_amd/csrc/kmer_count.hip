@@ -38,19 +38,84 @@ __device__ __forceinline__ unsigned long long slot_of(unsigned long long key, in
     return (key * 0x9E3779B97F4A7C15ull) >> (64 - log2_slots); // Fibonacci hashing
 }
 
-__device__ __forceinline__ void table_add(const KmerTable t, unsigned long long key,
+// A key's FIRST slot: [ line | slot in the line ], a line being 8 slots = 128 bytes.
+//   line  a hash of the key's MINIMIZER -- the canonical m-mer of smallest hash among its k - m + 1 = 8 windows
+//         (m = k - 7).  Neighbouring windows of a read mostly share their minimizer, so the 64 k-mers a wave inserts
+//         at a time fall into a dozen lines instead of 64 unrelated ones;
+//   slot  the POSITION of the minimizer inside the key (plus a rotation taken from its hash): the k-mers of one run
+//         -- same minimizer, positions 7, 6, 5, ... as the window moves on -- get slots of their own by construction.
+// Why: what bounds this kernel is the rate at which the memory side retires scattered 8-byte operations, about 2e10
+// load+add pairs a second whatever the table's size (tools/microbench_atomics.hip), and requests of one wave
+// instruction that fall into one 128-byte line are retired together (3.8x the rate with 8 lanes per line).
+// A key that finds its first slot taken by ANOTHER key does not probe on from there -- the k-mers that differ from
+// a genomic one by a substitution mostly share its minimizer and its position, and would walk through the run's
+// occupied slots -- but goes to the plain hash of the key and probes linearly from there (table_add).  Slots never
+// change their key, so every occurrence of a key takes the same decisions: exact counts.  `rc`: the reverse
+// complement of `key` as a 2k-bit code (the function is symmetric in the two up to the mirrored position).
+constexpr int kLineLog2 = 3;
+constexpr int kLineSlots = 1 << kLineLog2;
+
+__device__ __forceinline__ unsigned long long revcomp_code(unsigned long long x, int k)
+{
+    unsigned long long rc = 0;
+    for (int i = 0; i < k; ++i) {
+        rc = (rc << 2) | (3ull - (x & 3ull));
+        x >>= 2;
+    }
+    return rc;
+}
+
+__device__ __forceinline__ bool has_first_slot(const KmerTable &t)
+{
+    return t.k - (kLineSlots - 1) >= 6 && t.log2_slots > kLineLog2 + 4;
+}
+
+__device__ __forceinline__ unsigned long long first_slot(unsigned long long key, unsigned long long rc, const KmerTable &t)
+{
+    const int m = t.k - (kLineSlots - 1);
+    const unsigned long long mm = (1ull << (2 * m)) - 1ull;
+    unsigned long long best = ~0ull;
+    int at = 0;
+#pragma unroll
+    for (int i = 0; i < kLineSlots; ++i) {
+        const unsigned long long a = (key >> (2 * i)) & mm;                    // m-mer i of the key ...
+        const unsigned long long b = (rc >> (2 * (kLineSlots - 1 - i))) & mm;  // ... and its reverse complement
+        const unsigned long long c = a < b ? a : b;
+        const unsigned long long x = (c + 1ull) * 0x9E3779B97F4A7C15ull;
+        if (x < best) {
+            best = x;
+            at = i;
+        }
+    }
+    const unsigned long long h2 = best * 0xD6E8FEB86659FD93ull; // (the minimum of 8 hashes is small: spread it again)
+    const unsigned long long line = h2 >> (64 - (t.log2_slots - kLineLog2));
+    return (line << kLineLog2) | (unsigned long long)((at + (int)(h2 & 7ull)) & (kLineSlots - 1));
+}
+
+// true: the key was counted in slot h (found there, or put there)
+__device__ __forceinline__ bool try_slot(const KmerTable &t, unsigned long long h, unsigned long long key,
+                                         unsigned long long add)
+{
+    KmerSlot *slot = t.slots + h;
+    unsigned long long cur = __hip_atomic_load(&slot->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kEmptyKey)
+        cur = atomicCAS(&slot->key, kEmptyKey, key); // returns the previous value
+    if (cur == kEmptyKey || cur == key) {
+        atomicAdd(&slot->count, add);
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ void table_add(const KmerTable t, unsigned long long key, unsigned long long rc,
                                           unsigned long long add, int *overflow)
 {
+    if (has_first_slot(t) && try_slot(t, first_slot(key, rc, t), key, add))
+        return; // (a second try in the same line before leaving it was measured: no change)
     unsigned long long h = slot_of(key, t.log2_slots);
     for (int probe = 0; probe < kMaxProbe; ++probe) {
-        KmerSlot *slot = t.slots + h;
-        unsigned long long cur = __hip_atomic_load(&slot->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == kEmptyKey)
-            cur = atomicCAS(&slot->key, kEmptyKey, key); // returns the previous value
-        if (cur == kEmptyKey || cur == key) {
-            atomicAdd(&slot->count, add);
+        if (try_slot(t, h, key, add))
             return;
-        }
         h = (h + 1) & t.mask;
     }
     *overflow = 1;
@@ -77,15 +142,13 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(const unsigned char *__
                 const unsigned long long c = base_code(seq[i]);
                 h = (h << 2) | c;
             }
-            if (canonical) {
-                unsigned long long x = h;
-                for (int i = 0; i < k; ++i) {
-                    rc = (rc << 2) | (3ull - (x & 3ull));
-                    x >>= 2;
-                }
-                h = h < rc ? h : rc;
+            rc = revcomp_code(h, k);
+            if (canonical && rc < h) {
+                const unsigned long long x = h;
+                h = rc;
+                rc = x;
             }
-            table_add(t, h, 1ull, overflow);
+            table_add(t, h, rc, 1ull, overflow);
         }
         return;
     }
@@ -97,9 +160,12 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(const unsigned char *__
             h = (h << 2) | c;                  // hash_kmer, :18-23 (rehash :26-31 yields the same window code)
             rc |= (3ull - c) << (2 * i);       // reverse complement, built back to front
         }
-        if (canonical)
-            h = h < rc ? h : rc;
-        table_add(t, h, 1ull, overflow);
+        if (canonical && rc < h) {
+            const unsigned long long x = h;
+            h = rc;
+            rc = x;
+        }
+        table_add(t, h, rc, 1ull, overflow);
     }
 }
 
@@ -111,7 +177,7 @@ __global__ __launch_bounds__(256) void kmer_rehash_kernel(const KmerTable src, c
          i += (unsigned long long)gridDim.x * blockDim.x) {
         const KmerSlot e = src.slots[i];
         if (e.key != kEmptyKey)
-            table_add(dst, e.key, e.count, overflow);
+            table_add(dst, e.key, revcomp_code(e.key, dst.k), e.count, overflow);
     }
 }
 
