@@ -153,12 +153,35 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(const unsigned char *__
         return;
     }
     const int64_t n_windows = len - k + 1;
+    const int n_words = (k + 3) >> 2; // 32-bit words of 4 bases that cover a window
+    const unsigned long long kmask = k < 32 ? (1ull << (2 * k)) - 1ull : ~0ull;
     for (int64_t s = lane; s < n_windows; s += kWave) {
         unsigned long long h = 0, rc = 0;
-        for (int i = 0; i < k; ++i) {
-            const unsigned long long c = base_code(seq[s + i]);
-            h = (h << 2) | c;                  // hash_kmer, :18-23 (rehash :26-31 yields the same window code)
-            rc |= (3ull - c) << (2 * i);       // reverse complement, built back to front
+        if (s + 4 * n_words <= len) {
+            // Four bases per (unaligned) 32-bit load instead of one per byte load: base_code on the four bytes at
+            // once, the four 2-bit codes gathered into one byte by a multiply (base i of the word at bits 2i), the
+            // bytes strung together little-endian -- base i of the window at bits 2i.  That IS the reverse
+            // complement's code once complemented; the window's own code (first base in the highest bits:
+            // hash_kmer, bin/kmer_hist.py:18-23) is its mirror image, 2 bits at a time.
+            unsigned long long le = 0;
+            for (int j = 0; j < n_words; ++j) {
+                unsigned w;
+                __builtin_memcpy(&w, seq + s + 4 * j, 4);
+                unsigned x = (w >> 1) & 0x03030303u;
+                x ^= (x >> 1) & 0x01010101u;
+                le |= (unsigned long long)((x * 0x01041040u) >> 24) << (8 * j);
+            }
+            le &= kmask;
+            rc = ~le & kmask;
+            unsigned long long r = __brevll(le);
+            r = ((r & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((r & 0x5555555555555555ull) << 1);
+            h = r >> (64 - 2 * k);
+        } else { // the last windows of a read: byte by byte (a word would reach past the read's end)
+            for (int i = 0; i < k; ++i) {
+                const unsigned long long c = base_code(seq[s + i]);
+                h = (h << 2) | c;                  // hash_kmer, :18-23 (rehash :26-31 yields the same window code)
+                rc |= (3ull - c) << (2 * i);       // reverse complement, built back to front
+            }
         }
         if (canonical && rc < h) {
             const unsigned long long x = h;
