@@ -16,6 +16,8 @@
 // ~17x below the 1.3 TB/s contiguous-atomic rate); the arithmetic is noise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 #include "wave.h"
 
@@ -121,6 +123,48 @@ __device__ __forceinline__ void table_add(const KmerTable t, unsigned long long 
     *overflow = 1;
 }
 
+// One window of a read: its 2k-bit code (hash_kmer / rehash, bin/kmer_hist.py:18-31), the reverse complement's, the
+// canonical choice, the table.
+__device__ __forceinline__ void count_window(const unsigned char *__restrict__ seq, int64_t s, int64_t len, int k,
+                                             int canonical, const KmerTable &t, int *overflow)
+{
+    const int n_words = (k + 3) >> 2; // 32-bit words of 4 bases that cover a window
+    const unsigned long long kmask = k < 32 ? (1ull << (2 * k)) - 1ull : ~0ull;
+    unsigned long long h = 0, rc = 0;
+    if (s + 4 * n_words <= len) {
+        // Four bases per (unaligned) 32-bit load instead of one per byte load: base_code on the four bytes at
+        // once, the four 2-bit codes gathered into one byte by a multiply (base i of the word at bits 2i), the
+        // bytes strung together little-endian -- base i of the window at bits 2i.  That IS the reverse
+        // complement's code once complemented; the window's own code (first base in the highest bits:
+        // hash_kmer, bin/kmer_hist.py:18-23) is its mirror image, 2 bits at a time.
+        unsigned long long le = 0;
+        for (int j = 0; j < n_words; ++j) {
+            unsigned w;
+            __builtin_memcpy(&w, seq + s + 4 * j, 4);
+            unsigned x = (w >> 1) & 0x03030303u;
+            x ^= (x >> 1) & 0x01010101u;
+            le |= (unsigned long long)((x * 0x01041040u) >> 24) << (8 * j);
+        }
+        le &= kmask;
+        rc = ~le & kmask;
+        unsigned long long r = __brevll(le);
+        r = ((r & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((r & 0x5555555555555555ull) << 1);
+        h = r >> (64 - 2 * k);
+    } else { // the last windows of a read: byte by byte (a word would reach past the read's end)
+        for (int i = 0; i < k; ++i) {
+            const unsigned long long c = base_code(seq[s + i]);
+            h = (h << 2) | c;                  // hash_kmer, :18-23 (rehash :26-31 yields the same window code)
+            rc |= (3ull - c) << (2 * i);       // reverse complement, built back to front
+        }
+    }
+    if (canonical && rc < h) {
+        const unsigned long long x = h;
+        h = rc;
+        rc = x;
+    }
+    table_add(t, h, rc, 1ull, overflow);
+}
+
 __global__ __launch_bounds__(256) void kmer_count_kernel(const unsigned char *__restrict__ bases,
                                                          const int64_t *__restrict__ offsets,
                                                          int64_t n_reads, int64_t fixed_len, int k,
@@ -153,43 +197,24 @@ __global__ __launch_bounds__(256) void kmer_count_kernel(const unsigned char *__
         return;
     }
     const int64_t n_windows = len - k + 1;
-    const int n_words = (k + 3) >> 2; // 32-bit words of 4 bases that cover a window
-    const unsigned long long kmask = k < 32 ? (1ull << (2 * k)) - 1ull : ~0ull;
-    for (int64_t s = lane; s < n_windows; s += kWave) {
-        unsigned long long h = 0, rc = 0;
-        if (s + 4 * n_words <= len) {
-            // Four bases per (unaligned) 32-bit load instead of one per byte load: base_code on the four bytes at
-            // once, the four 2-bit codes gathered into one byte by a multiply (base i of the word at bits 2i), the
-            // bytes strung together little-endian -- base i of the window at bits 2i.  That IS the reverse
-            // complement's code once complemented; the window's own code (first base in the highest bits:
-            // hash_kmer, bin/kmer_hist.py:18-23) is its mirror image, 2 bits at a time.
-            unsigned long long le = 0;
-            for (int j = 0; j < n_words; ++j) {
-                unsigned w;
-                __builtin_memcpy(&w, seq + s + 4 * j, 4);
-                unsigned x = (w >> 1) & 0x03030303u;
-                x ^= (x >> 1) & 0x01010101u;
-                le |= (unsigned long long)((x * 0x01041040u) >> 24) << (8 * j);
-            }
-            le &= kmask;
-            rc = ~le & kmask;
-            unsigned long long r = __brevll(le);
-            r = ((r & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((r & 0x5555555555555555ull) << 1);
-            h = r >> (64 - 2 * k);
-        } else { // the last windows of a read: byte by byte (a word would reach past the read's end)
-            for (int i = 0; i < k; ++i) {
-                const unsigned long long c = base_code(seq[s + i]);
-                h = (h << 2) | c;                  // hash_kmer, :18-23 (rehash :26-31 yields the same window code)
-                rc |= (3ull - c) << (2 * i);       // reverse complement, built back to front
-            }
-        }
-        if (canonical && rc < h) {
-            const unsigned long long x = h;
-            h = rc;
-            rc = x;
-        }
-        table_add(t, h, rc, 1ull, overflow);
-    }
+    for (int64_t s = lane; s < n_windows; s += kWave)
+        count_window(seq, s, len, k, canonical, t, overflow);
+}
+
+// Reads of ONE length (what a sequencing run's FASTQ holds, and config 5's synthetic reads): the windows of all reads
+// are numbered through -- read = index / windows per read -- and a wave takes 64 consecutive ones, so that no lane
+// idles in a read's last 64-window round (100-base reads have 80 windows: 64 + 16 lanes, 37 % of the slots empty).
+__global__ __launch_bounds__(256) void kmer_count_fixed_kernel(const unsigned char *__restrict__ bases, int64_t n_reads,
+                                                               int64_t len, int k, int canonical, const KmerTable t,
+                                                               int *overflow)
+{
+    const int64_t n_windows = len - k + 1; // (the host sends reads shorter than k to kmer_count_kernel)
+    const int64_t total = n_reads * n_windows;
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= total)
+        return;
+    const int64_t r = w / n_windows;
+    count_window(bases + r * len, w - r * n_windows, len, k, canonical, t, overflow);
 }
 
 // Re-insert every entry of `src` into the (larger) `dst` table.
@@ -285,6 +310,19 @@ hipError_t launch_kmer_count(const unsigned char *bases, const int64_t *offsets,
 {
     if (n_reads <= 0)
         return hipSuccess;
+    if (!offsets && fixed_len >= k) {
+        // reads of one length: 64 consecutive windows per wave (kmer_count_fixed_kernel), at most 2^23 workgroups
+        // of 256 windows per launch, cut at whole reads
+        const int64_t n_windows = fixed_len - k + 1;
+        const int64_t reads_per_launch = std::max<int64_t>(1, (((int64_t)1 << 31) - 256) / n_windows);
+        for (int64_t first = 0; first < n_reads; first += reads_per_launch) {
+            const int64_t n = std::min(n_reads - first, reads_per_launch);
+            const int64_t total = n * n_windows;
+            hipLaunchKernelGGL(kmer_count_fixed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                               bases + first * fixed_len, n, fixed_len, k, canonical, t, overflow);
+        }
+        return hipGetLastError();
+    }
     // HIP wraps a grid of more than 2^32 threads silently: at most 2^23 workgroups per launch
     const int reads_per_block = 4;
     const int64_t reads_per_launch = (int64_t)reads_per_block << 23;

@@ -175,3 +175,46 @@ def test_one_gigabase_from_a_fasta_file(hip_lib, tmp_path):
     assert sum(i * v for i, v in enumerate(hc)) == windows
     assert len(canon) <= distinct
     canon.close()
+
+
+_FIXED_LEN_SCRIPT = r"""
+import os, sys
+import torch                      # first: ONE HIP runtime per process (INTEGRATION.md 8)
+sys.path.insert(0, os.environ["COVEST_REPO"])
+import numpy as np
+from covest_amd import kmer_hist as kh
+from oracle import kmer_oracle as ko
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(3)
+for k, L, canonical in ((21, 100, True), (21, 100, False), (31, 33, True), (5, 5, False), (12, 150, True)):
+    n = 3000
+    genome = rng.integers(0, 4, size=20000, dtype=np.uint8)
+    starts = rng.integers(0, genome.size - L, size=n)
+    codes = genome[starts[:, None] + np.arange(L)[None, :]]
+    ascii_reads = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    reads = ["".join(map(chr, row)) for row in ascii_reads]
+    d_bases = torch.from_numpy(np.ascontiguousarray(ascii_reads).reshape(-1)).to(dev)
+    d_offs = torch.arange(n + 1, dtype=torch.int64, device=dev) * L
+    fixed = kh.KmerCounts(k, canonical=canonical)
+    fixed.add_device(d_bases.data_ptr(), n, L)                     # reads of one length: windows numbered through
+    ragged = kh.KmerCounts(k, canonical=canonical)
+    ragged.add_device(d_bases.data_ptr(), n, L, d_offsets_ptr=d_offs.data_ptr())  # the same reads through offsets
+    torch.cuda.synchronize()
+    want = ko.histogram(reads, k, canonical=canonical)
+    assert fixed.histogram() == want, (k, L, canonical)
+    assert ragged.histogram() == want, (k, L, canonical)
+    fixed.close(); ragged.close()
+print("fixed-length ok")
+"""
+
+
+def test_reads_of_one_length_resident_in_hbm(hip_lib):
+    """covest_kmer_add_device without offsets (every read read_len long -- the layout config 5's synthetic reads
+    have in HBM) numbers the windows of all reads through and gives a wave 64 consecutive ones; with offsets a wave
+    takes a read.  Both against the numpy oracle: several k, read lengths down to exactly k, both strand modes."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, COVEST_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    proc = subprocess.run([sys.executable, "-c", _FIXED_LEN_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "fixed-length ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
