@@ -309,31 +309,48 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // The same walk over a tile WITHOUT counts (tail != 0 only): sum_j G[o][j] over its keys stays in a register
     // -- 32 terms of one sign added plainly, the compensated accumulator of phase C gets their contraction --
     // and is returned instead of 32 stores.
+    auto sum_tile = [&](auto n_tag, const double *scal, double renorm) __attribute__((always_inline)) -> double {
+        constexpr int N = decltype(n_tag)::value; // the live streams, as in walk_tile
+        double xx[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            double xs = st.x[s];
+            if (s < N) {
+                asm volatile("" : "+v"(xs));
+                xx[s] = xs * xs;
+            } else {
+                xx[s] = 0.0;
+            }
+        }
+        double gsum = 0.0;
+#pragma unroll
+        for (int b = 0; b < kTileBins; b += 2) {
+            double g1, g2;
+            st.template step2n<N>(xx, g1, g2);
+            gsum = fma(g1, scal[b], gsum);
+            gsum = fma(g2, scal[b + 1], gsum);
+        }
+        st.template leave_tile_n<N>(renorm);
+        return gsum;
+    };
     auto build_tile_sum = [&](int t, bool seg_start) __attribute__((always_inline)) -> double {
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
-        st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t], tv.run_start[t] != 0 || seg_start);
+        const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
+                                         tv.run_start[t] != 0 || seg_start);
         const double *scal = tv.scal + (int64_t)t * kTileBins;
-        double gsum = 0.0;
-        if (nb == kTileBins) {
-            double xx[8];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                double xs = st.x[s];
-                asm volatile("" : "+v"(xs));
-                xx[s] = xs * xs;
-            }
-#pragma unroll
-            for (int b = 0; b < kTileBins; b += 2) {
-                double g1, g2;
-                st.step2(xx, g1, g2);
-                gsum = fma(g1, scal[b], gsum);
-                gsum = fma(g2, scal[b + 1], gsum);
-            }
-        } else {
-            for (int b = 0; b < nb; ++b)
-                gsum = fma(st.step(), scal[b], gsum);
+        if (nb == kTileBins) { // (the count-less tiles of a histogram's tail are full ones: the live streams only)
+            if (n_live > 2)
+                return sum_tile(std::integral_constant<int, 8>{}, scal, tv.renorm[t]);
+            if (n_live == 2)
+                return sum_tile(std::integral_constant<int, 2>{}, scal, tv.renorm[t]);
+            if (n_live == 1)
+                return sum_tile(std::integral_constant<int, 1>{}, scal, tv.renorm[t]);
+            return 0.0; // nothing is on
         }
+        double gsum = 0.0;
+        for (int b = 0; b < nb; ++b)
+            gsum = fma(st.step(), scal[b], gsum);
         st.leave_tile(tv.renorm[t]);
         return gsum;
     };
