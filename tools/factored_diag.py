@@ -13,7 +13,7 @@ from bench import load_hist, workload  # noqa: E402
 from covest_amd import DenseGrid, RepeatsModel, _capi  # noqa: E402
 
 kind, hname, axes = workload("c3", 1)
-m = RepeatsModel(21, 100, load_hist(hname), 0, max_error=8)
+m = RepeatsModel(21, 100, load_hist(hname), float(os.environ.get("COVEST_DIAG_TAIL", "0")), max_error=8)  # COVEST_DIAG_TAIL=1000: all 10 000 keys
 g = DenseGrid(m, axes)
 g.evaluate(kernel="factored")
 g.argmin()
