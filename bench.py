@@ -26,7 +26,11 @@ range and the flat index range is block-partitioned, one contiguous block of the
 single-GPU size per rank.  --scaling strong: ONE fixed grid, c3 refined to c128 x e128 x q1 16 x q 16 =
 4.2 M points (~20 ms on one GPU), cut into N contiguous blocks balanced by sum(T - 1)
 (SURVEY.md 8(e)); the line then carries the ranks' kernel times (imbalance) and the cost of
-the exchange.  With N > 1 over RCCL the ranks' (min, index) pairs never visit the host: the
+the exchange.  With N > 1 the default (weak) invocation ALSO runs that strong-scaling grid in the same
+process group and reports it under variants.strong (per-rank kernel times, imbalance, RCCL exchange cost,
+speed-up over the one-GPU time recorded in profiles/): the driver issues one command per N, and the
+north-star's ">= 6x at 8 GPUs" is a strong-scaling statement.
+With N > 1 over RCCL the ranks' (min, index) pairs never visit the host: the
 arg-min kernel's 16 bytes in HBM go into one all-gather, are scanned where they land, and 16
 bytes are copied back.
 
@@ -283,7 +287,7 @@ def bench_kmer(args):
     kernel_s = 1e-3 * sum(a.elapsed_time(b) for a, b in evs) / args.steps
     distinct = len(counts)
     counted = sum(i * v for i, v in enumerate(hist))  # every window lands in exactly one bin
-    if (counted != n_kmers or sum(hist) != distinct) and not os.environ.get("COVEST_KMER_EXP_RUN"):
+    if counted != n_kmers or sum(hist) != distinct:
         raise SystemExit("k-mer histogram inconsistent: %d windows counted, %d expected" % (counted, n_kmers))
     alg_bytes = 16.0 * n_kmers + 1.0 * n_reads * read_len  # one 16-byte {key, count} slot per k-mer, each base once
     out = {
@@ -308,8 +312,7 @@ def bench_kmer(args):
                      "scattered_ops": {"achieved": n_kmers / kernel_s, "peak": SCATTERED_PAIRS_PER_S,
                                        "unit": "load+add pairs/s", "frac": n_kmers / kernel_s / SCATTERED_PAIRS_PER_S}},
     }
-    if not os.environ.get("COVEST_KMER_EXP_RUN"):  # (experiment builds of the kernel count nothing right)
-        out["config"]["from_file"] = kmer_from_file(reads, n_reads, read_len, k, counts)
+    out["config"]["from_file"] = kmer_from_file(reads, n_reads, read_len, k, counts)
     if args.cpu_budget > 0:
         from oracle import kmer_oracle as ko
         n_s = 20000
@@ -438,12 +441,19 @@ def bench_refine(args):
     print(json.dumps(out), flush=True)
 
 
-def tail_variant(cls, hist, axes, args, device, stream):
-    """The same grid on the same histogram with a tail (tail = 1000): what a trimmed real histogram has
-    (covest/histogram.py:125-134).  Then EVERY one of the 10 000 keys enters sp_j (covest/models.py:103-104), not
-    only the 981 counted ones.  Same step, same timing rules as the headline number."""
+def tail_variant(cls, axes, args, device, stream):
+    """The same grid on the histogram the reference's own pipeline would hand the model: H10k_rep TRIMMED by
+    get_trim / trim_hist (covest/histogram.py:105-134; tests/golden/H10k_rep_trim.hist, made by the reference in
+    make_golden.py section c3trim): the 380 keys below the trim point, tail = the trimmed mass (11 192), so that
+    1 - sp_j ~ 1e-4 at the optimum and the tail term tail * log(1 - sp_j) (covest/models.py:103-104) is well
+    conditioned.  With a tail EVERY key enters sp_j.  Same step, same timing rules as the headline number; the
+    arg-min is the one the reference finds (tests/golden/c3_trim.json, checked by tests/test_gpu_parity.py)."""
     from covest_amd import DenseGrid
-    model = cls(21, 100, hist, 1000, max_error=8, device=device)
+    hist = load_hist("H10k_rep_trim")
+    with open(os.path.join(REPO, "tests", "golden", "c3_trim.json")) as f:
+        fix = json.load(f)
+    tail = fix["tail"]
+    model = cls(21, 100, hist, tail, max_error=8, device=device)
     grid = DenseGrid(model, axes)
 
     def step():
@@ -464,15 +474,100 @@ def tail_variant(cls, hist, axes, args, device, stream):
     terms, flops, kernel_name = grid.work()
     avg_kernel_s = 1e-3 * kernel_ms / max(launches, 1)
     total = len(grid)
-    out = {"what": "same grid, same histogram, tail = 1000: all %d keys evaluated" % model.bins_evaluated,
+    ref = fix["candidates"]
+    out = {"what": "same grid, H10k_rep trimmed as the reference trims it (%d keys, all evaluated) with its tail = %d"
+                   % (model.bins_evaluated, tail),
            "value": total * args.steps / elapsed, "unit": "evals/s", "ms_per_step": 1e3 * elapsed / args.steps,
-           "argmin": {"min_negll": gmin, "flat_index": gidx},
+           "argmin": {"min_negll": gmin, "flat_index": gidx,
+                      "reference": {"min_negll": ref["reference_min_negll"], "flat_index": ref["reference_argmin_flat"]},
+                      "identical_index": gidx == ref["reference_argmin_flat"],
+                      "rel_err": abs(gmin - ref["reference_min_negll"]) / abs(ref["reference_min_negll"])},
            "roofline": {"bound": "mfma", "achieved": flops / avg_kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": flops / avg_kernel_s / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
                         "kernel": kernel_name, "kernel_ms_avg": 1e3 * avg_kernel_s, "launches": launches,
                         "algorithmic_flops_per_launch": flops, "pmf_terms_per_launch": terms}}
     grid.close()
     model.close()
+    return out
+
+
+def strong_variant(cls, hist, args, world, rank, local_rank, xdev, on_device, stream):
+    """N > 1: the strong-scaling answer in the SAME invocation as the weak one (the driver issues one command per N).
+    ONE fixed grid -- c128 x e128 x q1 16 x q 16 = 4.2 M points, `workload("c3", 1, "strong")` -- cut into N
+    contiguous flat-index blocks balanced by sum(T - 1) (covest/grid.py:63-64 maps the points over processes;
+    SURVEY.md 8(e)); a step = every rank evaluates its block, reduces it on the device, one all-gather of the
+    16-byte pairs.  Timed like the headline: barrier + synchronize on both sides, MAX over ranks.  The speed-up is
+    quoted against the N = 1 time of the same grid recorded in profiles/ (a one-GPU bench line of this repository)."""
+    import torch
+    import torch.distributed as dist
+    from covest_amd import DenseGrid
+    from covest_amd.grid import distributed_argmin, partition_flat_range, repeats_cost_weights
+    _, _, axes = workload("c3", 1, "strong")
+    model = cls(21, 100, hist, 0, max_error=8, device=local_rank)
+    total = int(np.prod([len(a) for a in axes]))
+    bounds = partition_flat_range(total, world, repeats_cost_weights(model, axes))
+    grid = DenseGrid(model, axes, (bounds[rank], bounds[rank + 1]))
+
+    def exchange():
+        if on_device:
+            return distributed_argmin(None, None, pair=grid.argmin_pair_tensor(local_rank))
+        lm, li = grid.argmin()
+        return distributed_argmin(lm, li, device=xdev)
+
+    def step():
+        grid.evaluate(kernel=args.kernel, stream=stream)
+        return exchange()
+
+    for _ in range(3 + args.warmup):
+        step()
+    grid.profile(True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gmin, gidx = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kernel_ms, launches = grid.kernel_ms()
+    grid.profile(False)
+    mine = torch.tensor([kernel_ms / max(launches, 1)], dtype=torch.float64, device=xdev)
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    per_rank = [float(v.item()) for v in every]
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        exchange()
+    torch.cuda.synchronize()
+    exchange_us = 1e6 * (time.perf_counter() - t1) / 20
+    grid.close()
+    model.close()
+    out = {"what": "strong scaling: ONE fixed grid c128 x e128 x q1 16 x q2 1 x q 16 (%d points) cut into %d contiguous "
+                   "blocks balanced by sum(T - 1)" % (total, world),
+           "value": total * args.steps / elapsed, "unit": "evals/s", "ms_per_step": 1e3 * elapsed / args.steps,
+           "grid_points": total, "argmin": {"min_negll": gmin, "flat_index": gidx},
+           "per_rank_kernel_ms": per_rank, "kernel_imbalance": max(per_rank) / (sum(per_rank) / world),
+           "exchange_us": exchange_us, "block_bounds": [int(b) for b in bounds],
+           "exchange": "device-resident pair -> RCCL all-gather -> device scan -> 16-byte copy" if on_device
+                       else "host pair -> all-gather (%s) -> scan" % args.backend}
+    # the N = 1 time of the same grid, from this repository's own one-GPU bench line (newest round first)
+    for name in ("r03_bench_c3_strong_1gpu.json", "r02_bench_c3_strong_1gpu.json"):
+        path = os.path.join(REPO, "profiles", name)
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    one = json.loads(f.read().strip().splitlines()[-1])
+                out["speedup_over_1gpu"] = {"value": one["ms_per_step"] / out["ms_per_step"],
+                                            "one_gpu_ms_per_step": one["ms_per_step"], "source": "profiles/" + name,
+                                            "note": "the N = 1 line was measured on another box of the same pool"}
+                break
+            except (OSError, ValueError, KeyError, IndexError):
+                continue
     return out
 
 
@@ -495,11 +590,12 @@ def bench_optimize_grid(args):
         for rep in range(max(1, min(args.steps, 5)) + 1):
             est.timings = []
             t0 = time.perf_counter()
-            res = optimize_grid(est.likelihood_f, list(guess), bounds=est.bounds)
+            og_trace = []
+            res = optimize_grid(est.likelihood_f, list(guess), bounds=est.bounds, trace=og_trace)
             wall = time.perf_counter() - t0
             if rep:  # the first search warms everything up
                 walls.append(wall)
-            last = (res, est.timings, optimize_grid.trace)
+            last = (res, est.timings, og_trace)
         res, timings, trace = last
         pts = sum(t["points"] for t in timings)
         out_cases.append({
@@ -657,7 +753,9 @@ def main():
         exchange_us = 1e6 * (time.perf_counter() - t1) / 20
     variants = None
     if rank == 0 and world == 1 and args.workload == "c3" and args.scaling == "weak":
-        variants = {"tail": tail_variant(cls, hist, axes, args, local_rank, stream)}
+        variants = {"tail": tail_variant(cls, axes, args, local_rank, stream)}
+    if world > 1 and args.workload == "c3" and args.scaling == "weak":  # (every rank takes part)
+        variants = {"strong": strong_variant(cls, hist, args, world, rank, local_rank, xdev, on_device, stream)}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -727,6 +825,11 @@ def main():
                                             if on_device else "host pair -> all-gather (%s) -> scan" % args.backend}
         if variants is not None:
             out["variants"] = variants
+            if "strong" in variants:
+                out["config"]["scaling_note"] = (
+                    "`value` is the WEAK-scaling step (the c axis grows N-fold: per-GPU work fixed, what the driver's "
+                    "efficiency column measures); variants.strong is the north-star question -- one fixed 4.2 M-point "
+                    "grid divided among the N GPUs -- answered in the same run")
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(kind, hist, axes, args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -147,6 +147,7 @@ struct covest_grid {
     int last_kernel_id = 0;
     hipStream_t last_stream = nullptr;
     bool evaluated = false;
+    bool configured = false; // false while (and after) a covest_grid_reset failed half way: the views may dangle
     // optional hipEvent bracketing of the likelihood kernel
     bool profiling = false;
     std::vector<hipEvent_t> ev_begin, ev_end;
@@ -391,7 +392,11 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     // items (tiles.h): runs of all-zero-count tiles (they exist only with a tail) are grouped, up to 32 per item
     std::vector<int32_t> item_first, item_ntiles, item_sum;
     std::vector<double> item_cnt;
-    const bool no_sum_items = std::getenv("COVEST_NO_SUM_ITEMS") != nullptr; // diagnostic: every tile a plain item
+#ifdef COVEST_DIAG
+    const bool no_sum_items = std::getenv("COVEST_NO_SUM_ITEMS") != nullptr; // diagnostic builds: every tile a plain item
+#else
+    const bool no_sum_items = false;
+#endif
     for (size_t t = 0; t < nt;) {
         auto all_zero = [&](size_t tt) {
             for (int b = 0; b < kTileBins; ++b)
@@ -556,9 +561,17 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     const int n_qblocks = std::max(std::max(1, (n_units + cap_block - 1) / cap_block), want_blocks);
     // cost model of the assignment, in MFMA steps: a unit costs its steps (in every pass) plus its share of the
     // logs; a builder wave starts with the cost of phase A (tuned on C3 with the in-kernel stamps)
-    const int unit_overhead = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD") ? std::atoi(std::getenv("COVEST_FACTORED_UNIT_OVERHEAD")) : kUnitOverhead;
-    const int build_cost = std::getenv("COVEST_FACTORED_BUILD_COST") ? std::atoi(std::getenv("COVEST_FACTORED_BUILD_COST")) : kBuildCost;
-    const int shared_div = std::getenv("COVEST_FACTORED_SHARED_DIV") ? std::max(1, std::atoi(std::getenv("COVEST_FACTORED_SHARED_DIV"))) : kSharedStepsPerMfma;
+    // (the assignment fixes the order of a point's sums: the shipped library takes the constants of tiles.h, only a
+    // diagnostic build -- tiles.h -- lets the environment override them for tuning sweeps)
+    int unit_overhead = kUnitOverhead, build_cost = kBuildCost, shared_div = kSharedStepsPerMfma;
+#ifdef COVEST_DIAG
+    if (const char *v = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD"))
+        unit_overhead = std::atoi(v);
+    if (const char *v = std::getenv("COVEST_FACTORED_BUILD_COST"))
+        build_cost = std::atoi(v);
+    if (const char *v = std::getenv("COVEST_FACTORED_SHARED_DIV"))
+        shared_div = std::max(1, std::atoi(v));
+#endif
     const size_t n_unit = (size_t)n_qblocks * nw * mu;
     std::vector<int32_t> unit_tile(n_unit, -1), unit_half(n_unit, 0), unit_s0(n_unit, 0), unit_o0(n_unit, 1),
         unit_len(n_unit, 0), unit_cont(n_unit, 0), unit_nsh(n_unit, 0);
@@ -732,7 +745,11 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     pl.half_units = hu;
     pl.n_qblocks = n_qblocks;
     pl.ld = ld;
-    pl.n_buf = std::getenv("COVEST_FACTORED_NBUF") ? std::atoi(std::getenv("COVEST_FACTORED_NBUF")) : n_buf;
+    pl.n_buf = n_buf;
+#ifdef COVEST_DIAG
+    if (std::getenv("COVEST_FACTORED_NBUF"))
+        pl.n_buf = std::atoi(std::getenv("COVEST_FACTORED_NBUF"));
+#endif
     int32_t *ub = ibase + 2 * n_slots;
     pl.unit_tile = ub;
     pl.unit_half = ub + n_unit;
@@ -758,11 +775,13 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     pl.partial = nullptr;
     pl.ce_first = pl.ce_begin;
     pl.n_cols_partial = (int64_t)n_slots;
+    pl.skip_phases = 0;
+    pl.diag = nullptr;
+#ifdef COVEST_DIAG // diagnostic builds only (tiles.h): the shipped library has no knob that changes values
     {
-        const char *skip = std::getenv("COVEST_FACTORED_SKIP"); // profiling aid, see tiles.h
+        const char *skip = std::getenv("COVEST_FACTORED_SKIP");
         pl.skip_phases = skip ? std::atoi(skip) : 0;
-        pl.diag = nullptr;
-        if (list_mode == 0 && std::getenv("COVEST_FACTORED_DIAG")) { // profiling aid: leaked on purpose, diagnostic runs only
+        if (list_mode == 0 && std::getenv("COVEST_FACTORED_DIAG")) { // leaked on purpose
             void *dp = nullptr;
             const size_t bytes = (size_t)(pl.ce_end - pl.ce_begin) * n_qblocks * nw * 8 * sizeof(long long);
             if (hipMalloc(&dp, bytes) == hipSuccess && hipMemset(dp, 0, bytes) == hipSuccess) {
@@ -771,6 +790,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
             }
         }
     }
+#endif
     return COVEST_OK;
 }
 
@@ -804,11 +824,18 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
     // Shared steps (tiles.h) want the 16 columns of a tile to differ in q1 and q2 only: the n1 * n2 vectors of one q
     // are then laid out by descending threshold_o and padded to whole tiles.  Padding columns cost logs, shared steps
     // save MFMAs: taken when the padding stays below a third (n1 * n2 = 12, 16, 24, 27 .. 32, 36 ...), one lane per
-    // copy number (max_error <= 8).  COVEST_FACTORED_SHARE=0: never (A/B runs).
+    // copy number (max_error <= 8).  (Diagnostic builds: COVEST_FACTORED_SHARE=0 switches it off for A/B runs.)
     const int64_t group = qo.n1 * qo.n2, group_padded = (group + 15) / 16 * 16;
-    const char *share_env = std::getenv("COVEST_FACTORED_SHARE");
-    const bool share = n_pass == 1 && 3 * (group_padded - group) <= group && !(share_env && std::atoi(share_env) == 0);
-    const int min_shared = std::getenv("COVEST_FACTORED_MIN_SHARED") ? std::atoi(std::getenv("COVEST_FACTORED_MIN_SHARED")) : kMinSharedSteps;
+    bool share = n_pass == 1 && 3 * (group_padded - group) <= group;
+#ifdef COVEST_DIAG
+    if (const char *share_env = std::getenv("COVEST_FACTORED_SHARE"))
+        share = share && std::atoi(share_env) != 0;
+#endif
+    int min_shared = kMinSharedSteps;
+#ifdef COVEST_DIAG
+    if (const char *v = std::getenv("COVEST_FACTORED_MIN_SHARED"))
+        min_shared = std::atoi(v);
+#endif
     auto by_t = [&](int32_t a, int32_t b) { return t_table[(size_t)a] > t_table[(size_t)b]; };
     if (!share) {
         std::vector<int32_t> all((size_t)qo.nq);
@@ -1663,6 +1690,7 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
         flat_end = total;
     if (flat_begin < 0 || flat_begin > flat_end || flat_end > total)
         return fail(COVEST_E_INVALID, std::string(who) + ": bad flat index range");
+    g->configured = false; // (set again at the very end: a failure below leaves views into a freed arena behind)
     g->flat_begin = flat_begin;
     g->flat_end = flat_end;
     g->evaluated = false;
@@ -1745,6 +1773,7 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
         if (prc != COVEST_OK)
             return prc;
     }
+    g->configured = true;
     return COVEST_OK;
 }
 
@@ -1849,6 +1878,8 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
 {
     if (!g)
         return fail(COVEST_E_INVALID, "covest_grid_eval: null grid");
+    if (!g->configured)
+        return fail(COVEST_E_INVALID, "covest_grid_eval: the last covest_grid_reset of this handle failed; reset it again");
     covest_model *m = g->model;
     const int kern = resolve_kernel(m, kernel, g);
     if (kern < 0)
@@ -2049,19 +2080,31 @@ int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
     DeviceGuard dev_guard(c->device);
     if (dev_guard.status() != COVEST_OK)
         return dev_guard.status();
+    // An overflow of an earlier covest_kmer_add_device (asynchronous: it never looks at the flag itself) is STICKY
+    // until covest_kmer_clear: its batch is partly counted, and a rehash of a table with k-mers missing must not make
+    // the next covest_kmer_histogram look clean.  So: everything in flight on this device first (the adds may run
+    // on a caller's non-blocking stream, the rehash runs on the null stream), then the flag.
+    HIP_TRY(hipDeviceSynchronize());
+    {
+        const int rc = kmer_check_overflow(c);
+        if (rc != COVEST_OK)
+            return rc;
+    }
     KmerTable bigger{};
     DevBuf slots;
     int rc = kmer_alloc_table(c, min_slots, bigger, slots);
+    hipError_t e = hipSuccess;
+    if (rc == COVEST_OK) { // (the flag is known to be clean here: whatever it holds afterwards is the rehash's)
+        e = launch_kmer_rehash(c->table, bigger, c->flag.as<int>(), nullptr);
+        if (e == hipSuccess)
+            e = hipDeviceSynchronize();
+        if (e != hipSuccess)
+            rc = fail_hip(e, "covest_kmer_reserve: rehash");
+    }
     if (rc != COVEST_OK) {
-        slots.release();
+        slots.release(); // (DevBuf has no destructor: every error path lets the new table go)
         return rc;
     }
-    // the flag now reports THIS rehash only: an overflow of an earlier covest_kmer_add has been reported by
-    // that call (the batch it was inserting is partly counted -- see the header: clear and recount, or count
-    // through covest_amd.kmer_hist, which grows ahead of every batch)
-    HIP_TRY(hipMemset(c->flag.ptr, 0, sizeof(int)));
-    HIP_TRY(launch_kmer_rehash(c->table, bigger, c->flag.as<int>(), nullptr));
-    HIP_TRY(hipDeviceSynchronize());
     c->slots.release();
     c->slots = slots;
     c->table = bigger;

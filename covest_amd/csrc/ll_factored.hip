@@ -240,7 +240,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // ================= phase A: G[key][o] of key tile t into `dst` =================
     // in-kernel stamps (diagnostic runs only): cycles per wave in build / contract / log / barrier
     long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0, dg_zero = 0;
+#ifdef COVEST_DIAG
     const bool diag = plan.diag != nullptr;
+#else
+    constexpr bool diag = false; // (the stamps exist in diagnostic builds only: tiles.h)
+#endif
     // the 32 keys of a full tile with the streams 0 .. N-1 (the others are zero in every lane of the wave)
     auto walk_tile = [&](auto n_tag, const double *scal, double *colp, double renorm) __attribute__((always_inline)) {
         constexpr int N = decltype(n_tag)::value;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         st.template leave_tile_n<N>(renorm);
     };
     auto build_tile = [&](int t, bool seg_start, double *dst) __attribute__((always_inline)) {
-        if (plan.skip_phases & 1)
+        if (COVEST_SKIP_PHASE(plan, 1))
             return;
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     auto build_item = [&](int it, double *dst) __attribute__((always_inline)) {
         const int first = TAIL ? __builtin_amdgcn_readfirstlane(tv.item_first[it]) : it;
         if (TAIL && tv.item_sum[it] != 0) {
-            if (plan.skip_phases & 1)
+            if (COVEST_SKIP_PHASE(plan, 1))
                 return;
             const int n = __builtin_amdgcn_readfirstlane(tv.item_ntiles[it]);
             double *colp = dst + (lane_in_row ? tid : 0);
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < MU; ++k) {
-            if (!PLAIN || nsh[k] == 0 || (plan.skip_phases & 8)) { // wave-uniform (skip bit 8: profiling aid, tiles.h)
+            if (!PLAIN || nsh[k] == 0 || COVEST_SKIP_PHASE(plan, 8)) { // wave-uniform (skip bit 8: profiling aid, tiles.h)
                 acc[k] = len[k] > 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(cur[a_off[k]], wfirst[k], zero4, 0, 0, 0) : zero4;
                 continue;
             }
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         }
         STAMP(dg_b0)
         // the remaining steps, specialised on the number of slots still running (len is sorted)
-        if (!(plan.skip_phases & 2)) {
+        if (!COVEST_SKIP_PHASE(plan, 2)) {
             int i = 1;
             for (; i < len[5]; ++i)
                 contract_step<6, MU>(i, cur, a_off, cut, r4, wrun, acc);
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
                 continue;
             }
-            if (qslot[k] >= 0 && !cont[k] && !(plan.skip_phases & 4)) { // wave-uniform: first slot of a unit
+            if (qslot[k] >= 0 && !cont[k] && !COVEST_SKIP_PHASE(plan, 4)) { // wave-uniform: first slot of a unit
                 // Everything out of the ordinary -- p_j <= 0, or deep in the subnormal range (below p_clamp,
                 // direct_point.h), at a key with h_j != 0 -- is caught by ONE compare per row, made BEFORE the logs
                 // (the accumulators are not kept alive for it), and sorted out in a branch the wave takes for one

@@ -91,6 +91,7 @@ struct Piece {
     Bytes bases;
     std::vector<int64_t> lens;   // one per record, in file order
     const uint8_t *bad = nullptr; // first letter single_hash would reject
+    const uint8_t *malformed = nullptr; // FASTQ: first line that breaks the 4-line framing ('@' / '+' expected)
     bool oom = false;
 };
 
@@ -241,10 +242,23 @@ void parse_piece(const covest_reads *r, const uint8_t *b, const uint8_t *e, Piec
             if (in_record)
                 pc.lens.push_back((int64_t)pc.bases.n - start);
         } else {
+            // Strict 4-line records (what sequencers write; wrapped sequence lines are NOT supported -- the reference
+            // delegates to Bio.SeqIO, which accepts them): @id / sequence / + / quality.  Blank lines between records
+            // (and at the end of the file) are skipped; a record whose first line does not start with '@' or whose
+            // third does not start with '+' is reported with its byte offset instead of being counted as garbage.
             int line = 0; // 0 = @id, 1 = sequence, 2 = +, 3 = quality
             while (p < e) {
                 const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(p, '\n', (size_t)(e - p)));
                 const uint8_t *stop = nl ? nl : e;
+                const bool blank = stop == p || (stop == p + 1 && *p == '\r');
+                if (line == 0 && blank) { // between records
+                    p = nl ? nl + 1 : e;
+                    continue;
+                }
+                if ((line == 0 && *p != '@') || (line == 2 && (blank || *p != '+'))) {
+                    pc.malformed = p;
+                    return;
+                }
                 if (line == 1) {
                     const int64_t start = (int64_t)pc.bases.n;
                     if (!put_line(r, pc, p, stop))
@@ -389,6 +403,7 @@ int covest_reads_next(covest_reads *r, int64_t max_bases, const uint8_t **bases,
         pieces[(size_t)i].bases.n = 0;
         pieces[(size_t)i].lens.clear();
         pieces[(size_t)i].bad = nullptr;
+        pieces[(size_t)i].malformed = nullptr;
         pieces[(size_t)i].oom = false;
     }
     if (n_pieces == 1) {
@@ -405,6 +420,10 @@ int covest_reads_next(covest_reads *r, int64_t max_bases, const uint8_t **bases,
         const Piece &pc = pieces[(size_t)i];
         if (pc.oom)
             return covest::set_error(COVEST_E_NOMEM, "covest_reads_next: out of host memory");
+        if (pc.malformed)
+            return covest::set_error(COVEST_E_INVALID, "covest_reads_next: malformed FASTQ record at byte " +
+                                                          std::to_string((long long)(pc.malformed - r->map)) +
+                                                          " (4-line records: @id, sequence, +, quality)");
         if (pc.bad) // (pieces are in file order: the first one reported is the first in the file)
             return covest::set_error(COVEST_E_INVALID, std::string("covest_reads_next: base '") + (char)*pc.bad +
                                                           "' outside acgtn (single_hash raises KeyError)");

@@ -161,8 +161,17 @@ struct FactoredPlan {
                                    //   weight vectors (threshold_o beyond a workgroup's lanes), summed chunk by chunk
     int64_t ce_first;              // list_mode 3: the (c, e) of partial's first row
     int64_t n_cols_partial;        // list_mode 3: weight-vector slots per (c, e) in partial
-    long long *diag;               // PROFILING ONLY (env COVEST_FACTORED_DIAG): per-wave s_memtime sums [wg][wave][8]
-    int32_t skip_phases;           // PROFILING ONLY (env COVEST_FACTORED_SKIP): bit 0/1/2 skips phase A/B/C, bit 3 the shared steps; results are wrong
+    // The two fields below are read by DIAGNOSTIC builds only (-DCOVEST_DIAG, built to tools/bin/ by
+    // `python -m covest_amd.build --out tools/bin/libcovest_amd_diag.so -DCOVEST_DIAG` and loaded through
+    // COVEST_AMD_LIB): the shipped library never looks at them -- a knob that changes VALUES is a parity hazard.
+    long long *diag;               // (env COVEST_FACTORED_DIAG) per-wave s_memtime sums [wg][wave][8]
+    int32_t skip_phases;           // (env COVEST_FACTORED_SKIP) bit 0/1/2 skips phase A/B/C, bit 3 the shared steps; results are wrong
 };
+
+#ifdef COVEST_DIAG
+#define COVEST_SKIP_PHASE(plan, bits) (((plan).skip_phases & (bits)) != 0)
+#else
+#define COVEST_SKIP_PHASE(plan, bits) false
+#endif
 
 } // namespace covest

@@ -85,18 +85,17 @@ class CoverageEstimator:
             grid = self._grid.reset(axes)
         else:
             grid = self._grid = DenseGrid(self.model, axes)
-        if True:
-            t1 = time.perf_counter() if t is not None else 0.0
-            grid.evaluate(kernel=kernel)
-            if t is not None:
-                grid.argmin()  # (wait for the kernels: the split below is only meaningful with a sync here)
-            t2 = time.perf_counter() if t is not None else 0.0
-            out = -grid.loglikelihoods()
-            if t is not None:
-                t3 = time.perf_counter()
-                t.append({"points": len(grid), "create_s": t1 - t0, "eval_s": t2 - t1, "readback_s": t3 - t2,
-                          "kernel": grid.work()[2]})
-            return out
+        t1 = time.perf_counter() if t is not None else 0.0
+        grid.evaluate(kernel=kernel)
+        if t is not None:
+            grid.argmin()  # (wait for the kernels: the split below is only meaningful with a sync here)
+        t2 = time.perf_counter() if t is not None else 0.0
+        out = -grid.loglikelihoods()
+        if t is not None:
+            t3 = time.perf_counter()
+            t.append({"points": len(grid), "create_s": t1 - t0, "eval_s": t2 - t1, "readback_s": t3 - t2,
+                      "kernel": grid.work()[2]})
+        return out
 
     def negll_points(self, xs):
         """likelihood_f of several optimiser-space vectors in one launch: ndarray."""

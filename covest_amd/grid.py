@@ -334,8 +334,11 @@ def _batched_negll(fn):
 
 
 def optimize_grid(fn, initial_guess, bounds=None, maximize=False, fix=None,
-                  n_threads=constants.DEFAULT_THREAD_COUNT):
-    """covest/grid.py:17-79.  n_threads is accepted and ignored on the GPU path."""
+                  n_threads=constants.DEFAULT_THREAD_COUNT, trace=None):
+    """covest/grid.py:17-79.  n_threads is accepted and ignored on the GPU path.  `trace`: a list the caller
+    owns; one record per iteration is appended to it (what the reference prints through verbose_print,
+    covest/grid.py:60,73-74) -- per call, so concurrent searches (the lock-step refinement runs threads) never
+    share one."""
     def generate_axes(args, step, max_depth):
         def single(var, fixed=None):
             if fixed is None:
@@ -361,7 +364,8 @@ def optimize_grid(fn, initial_guess, bounds=None, maximize=False, fix=None,
     grid_depth = constants.GRID_DEPTH
     diff = 1
     n_iter = 0
-    trace = optimize_grid.trace = []
+    if trace is None:
+        trace = []
     try:
         while diff > 0.1 or step > 1.001:
             n_iter += 1

@@ -140,8 +140,11 @@ class KmerCounts:
         """Reads already resident in HBM (raw device pointers); asynchronous on `stream`.
         reserve=False: the caller sized the table for the DISTINCT k-mers it expects (an
         overflow is reported by the next histogram call)."""
+        n_new = int(n_reads) * max(int(read_len) - self.k + 1, 1)
         if reserve:
-            self._reserve_for(int(n_reads) * max(int(read_len) - self.k + 1, 1))
+            self._reserve_for(n_new)
+        else:  # still occurrences inserted since the last measurement: later batches must see them in the bound
+            self._added += n_new
         _capi.check(_capi.lib().covest_kmer_add_device(
             self._handle, ctypes.c_void_p(d_bases_ptr), ctypes.c_void_p(d_offsets_ptr or 0),
             int(n_reads), int(read_len), ctypes.c_void_p(stream or 0)), "covest_kmer_add_device")

@@ -155,12 +155,13 @@ int covest_grid_argmin(covest_grid *g, double *min_negll, int64_t *argmin_flat);
 /* Device pointer of the reduction of the last covest_grid_eval as two doubles in HBM,
  * {min -LL, GLOBAL flat index of the arg-min as a double (-1 if none; flat indices stay
  * below 2^53)}: what the ranks of a multi-GPU search exchange (one all-gather of these 16
- * bytes) without a round trip through the host.  Valid until destroy;
- * written by covest_grid_eval on its stream. */
+ * bytes) without a round trip through the host.  Valid until the next
+ * covest_grid_reset (which may move the handle's device arena) or destroy; written by
+ * covest_grid_eval on its stream. */
 const double *covest_grid_argmin_pair_device(const covest_grid *g);
 
-/* Device pointer of the block's LL values (double[grid_size], valid until
- * destroy) and a copy to the host. */
+/* Device pointer of the block's LL values (double[grid_size], valid until the next
+ * covest_grid_reset or destroy) and a copy to the host. */
 const double *covest_grid_ll_device(const covest_grid *g);
 int covest_grid_ll_host(covest_grid *g, double *out_ll);
 
@@ -189,7 +190,9 @@ void covest_kmer_destroy(covest_kmer *c);
  * keeps the table at most half full: slots >= 2 * (DISTINCT k-mers held + those the next batch can
  * add).  Overflow contract: a covest_kmer_add / covest_kmer_histogram that returns COVEST_E_NOMEM has
  * counted PART of its batch; the counter is then only good for covest_kmer_clear (recount with a larger
- * table).  covest_kmer_reserve clears the overflow state before re-inserting and reports only its own. */
+ * table).  The overflow state is STICKY until covest_kmer_clear: covest_kmer_reserve waits for everything in
+ * flight on the device, returns COVEST_E_NOMEM if an earlier (asynchronous) add overflowed, and otherwise
+ * re-inserts into the larger table and reports its own outcome. */
 int covest_kmer_reserve(covest_kmer *c, int64_t min_slots);
 /* compute_counts(seq, prev_counts=counts, k) for n_reads preprocessed reads (bin/kmer_hist.py:44-54
  * already applied: only a/c/g/t in either case).  bases: the reads back to back; offsets[n_reads+1].

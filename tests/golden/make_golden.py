@@ -14,7 +14,7 @@ One session-local alias is needed: covest/models.py:10 does
 copied.  Interpreter-dependent semantics are recorded in every fixture's "env".
 
 Usage:  python tests/golden/make_golden.py [section ...]
-Sections: tp basic repeats threshold hists c1 c2 c3 c3tail c3argmin gridtrace   (default: all)
+Sections: tp basic repeats threshold hists c1 c2 c3 c3tail c3trim c3argmin gridtrace   (default: all)
 (c3argmin reads c3_candidates_gpu.json: flat indices written on the GPU box by tools/dump_c3_candidates.py)
 """
 import itertools
@@ -396,8 +396,23 @@ def _cached(name, tail):
     return out
 
 
+def _oracle_fast_ll(hist, tail, idx):
+    """The repository's CPU oracle in its log-domain mode (oracle/covest_oracle.c), used here ONLY to choose WHERE
+    the reference is asked (which points are finite, which are the best of a grid): every number that goes into a
+    fixture is the reference's own."""
+    sys.path.insert(0, REPO)
+    from oracle import covest_oracle as orc
+    import numpy as np
+    om = orc.OracleModel("repeats", 21, 100, hist, tail, max_error=8)
+    return om.compute_loglikelihood_many_fast(np.array([c3_point(i) for i in idx]), n_threads=8)
+
+
 def section_c3(pool):
-    """>= 256 seeded points of the C3 grid: the 64 of seed 20240522 plus 192 of seed 20240523."""
+    """Seeded points of the C3 grid: the 64 of seed 20240522 plus 192 of seed 20240523 -- half
+    of which are -inf, the grid being what it is (a counted key out of reach of a short weight vector) -- plus, so
+    that the 1e-9 claim rests on >= 256 FINITE reference values, seeded points drawn from q <= 0.59 (the ten smallest
+    values of the q axis) and kept where the likelihood is finite (pre-screened with the oracle's log-domain mode;
+    the values themselves are the reference's)."""
     hist = synth_hist("H10k_rep", pool)
     n = 32 * 32 * 16 * 16
     idx = set(random.Random(20240522).sample(range(n), 64))
@@ -405,10 +420,22 @@ def section_c3(pool):
         if len(idx) >= 256:
             break
         idx.add(i)
+    cache = _cached("c3_sample.json", 0)
+    want_finite = int(os.environ.get("COVEST_C3_FINITE", "264"))
+    have = sum(1 for i in idx if i in cache and math.isfinite(cache[i][0]))
+    pool_idx = [i for i in random.Random(20240925).sample(range(n), 4000) if i % 16 <= 9 and i not in idx]
+    screen = _oracle_fast_ll(hist, 0, pool_idx)
+    for i, v in zip(pool_idx, screen):
+        if have >= want_finite:
+            break
+        if math.isfinite(v):
+            idx.add(i)
+            have += 1
     idx = sorted(idx)
-    ll, secs, _ = _c3_eval(pool, hist, 0, idx, _cached("c3_sample.json", 0))
-    dump("c3_sample.json", {"what": "config 3: RepeatsModel on H10k_rep.hist, q2 fixed 0.5, 256 "
-                                    "seeded points of the 32x32x16x16 grid (c,e,q1,q)",
+    ll, secs, _ = _c3_eval(pool, hist, 0, idx, cache)
+    dump("c3_sample.json", {"what": "config 3: RepeatsModel on H10k_rep.hist, q2 fixed 0.5: 256 seeded points of the "
+                                    "32x32x16x16 grid (c,e,q1,q) plus seeded points of its q <= 0.59 part where the "
+                                    "likelihood is finite; finite values: %d" % sum(1 for v in ll if math.isfinite(v)),
                             "hist": "H10k_rep", "k": 21, "r": 100, "max_error": 8, "tail": 0,
                             "flat_index": idx, "points": [list(c3_point(i)) for i in idx],
                             "ll": ll, "cpu_seconds_per_point": secs})
@@ -424,6 +451,60 @@ def section_c3tail(pool):
                                  "hist": "H10k_rep", "k": 21, "r": 100, "max_error": 8, "tail": 1000,
                                  "flat_index": idx, "points": [list(c3_point(i)) for i in idx],
                                  "ll": ll, "sp": sp, "cpu_seconds_per_point": secs})
+
+
+def section_c3trim(pool):
+    """Config 3 on the histogram the reference's own pipeline would hand the model: H10k_rep TRIMMED as
+    process_histogram does it (covest/histogram.py:105-134: get_trim(ignore_last=True), trim_hist) -- the keys
+    below the trim point with their zero-count keys dropped, tail = the trimmed mass.  Then 1 - sp_j is of the
+    order tail / N (1e-4), the regime real inputs are in: the tail term tail * log(1 - sp_j)
+    (covest/models.py:103-104) is WELL CONDITIONED, unlike on the untrimmed synthetic histogram where
+    sp_j = 1 - a few ulp.  Writes the trimmed histogram, COVEST_C3TRIM_POINTS (default 4096) seeded points of the
+    C3 grid with the reference's LL and sp_j, and the reference's values at the best 96 points of the grid and at
+    the axis neighbours of the best one (chosen with the oracle's log-domain mode; the reference decides the
+    winner among them under the scan of covest/grid.py:65-70)."""
+    import covest.histogram as H
+    hist = synth_hist("H10k_rep", pool)
+    trim = H.get_trim(hist, ignore_last=True)
+    thist, tail = H.trim_hist(hist, trim)
+    save_hist(os.path.join(HERE, "H10k_rep_trim.hist"), thist,
+              "H10k_rep trimmed by the reference (get_trim(ignore_last=True) = %d, trim_hist): tail = %d" % (trim, tail))
+    n = 32 * 32 * 16 * 16
+    idx = sorted(random.Random(20240926).sample(range(n), int(os.environ.get("COVEST_C3TRIM_POINTS", "4096"))))
+    res = pool.map(_ll_sp_job, [("repeats", thist, tail, c3_point(i)) for i in idx], chunksize=8)
+    # arg-min candidates: the best 96 of the whole grid by the oracle's log-domain mode + the 2 P axis neighbours
+    import numpy as np
+    fast = _oracle_fast_ll(thist, tail, range(n))
+    negll = np.where(np.isnan(fast), np.inf, -fast)
+    order = np.argsort(negll, kind="stable")
+    cand = set(int(i) for i in order[:96])
+    shape = (32, 32, 16, 16)
+    top = np.unravel_index(int(order[0]), shape)
+    for d in range(4):
+        for step in (-1, 1):
+            j = list(top)
+            j[d] += step
+            if 0 <= j[d] < shape[d]:
+                cand.add(int(np.ravel_multi_index(j, shape)))
+    cand = sorted(cand)
+    cres = pool.map(_ll_sp_job, [("repeats", thist, tail, c3_point(i)) for i in cand], chunksize=1)
+    best, arg = None, -1
+    for i, (v, _, _) in zip(cand, cres):
+        if v == v and (best is None or -v < best):
+            best, arg = -v, i
+    print("c3trim: trim", trim, "keys", len(thist), "tail", tail, "reference winner", arg, best,
+          "finite sample values", sum(1 for v, _, _ in res if math.isfinite(v)), flush=True)
+    dump("c3_trim.json", {"what": "config 3 on H10k_rep trimmed as the reference's process_histogram trims it: "
+                                  "RepeatsModel, q2 fixed 0.5, seeded points of the 32x32x16x16 grid (c,e,q1,q) "
+                                  "with LL and sp_j = fsum(p_j), and the arg-min candidates",
+                          "hist": "H10k_rep_trim", "source_hist": "H10k_rep", "trim": trim, "k": 21, "r": 100,
+                          "max_error": 8, "tail": tail, "n_keys": len(thist),
+                          "axes": [list(a) for a in c3_axes()], "q2": 0.5,
+                          "flat_index": idx, "ll": [v for v, _, _ in res], "sp": [sp for _, _, sp in res],
+                          "cpu_seconds_total": sum(t for _, t, _ in res),
+                          "candidates": {"flat_index": cand, "ll": [v for v, _, _ in cres],
+                                         "sp": [sp for _, _, sp in cres],
+                                         "reference_argmin_flat": arg, "reference_min_negll": best}})
 
 
 def section_c3argmin(pool):
@@ -499,13 +580,13 @@ def section_gridtrace():
 
 
 def main():
-    wanted = sys.argv[1:] or ["tp", "basic", "repeats", "threshold", "hists", "c1", "c2", "c3", "c3tail",
+    wanted = sys.argv[1:] or ["tp", "basic", "repeats", "threshold", "hists", "c1", "c2", "c3", "c3tail", "c3trim",
                               "c3argmin", "gridtrace"]
     pool = multiprocessing.Pool(int(os.environ.get("COVEST_GOLDEN_PROCS", "8")))
     for name in wanted:
         t0 = time.time()
         fn = globals()["section_" + name]
-        if name in ("hists", "c1", "c2", "c3", "c3tail", "c3argmin"):
+        if name in ("hists", "c1", "c2", "c3", "c3tail", "c3trim", "c3argmin"):
             fn(pool)
         else:
             fn()

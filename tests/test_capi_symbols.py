@@ -31,6 +31,25 @@ def test_no_cpu_fallback_in_product():
                 assert "covest_oracle" not in text and "import oracle" not in text, f
 
 
+def test_no_value_changing_knob_in_the_shipped_library(hip_lib):
+    """The diagnostics that change what the kernels compute -- phases skipped for instruction counts, the sharing or
+    the sum items switched off for A/B runs, other assignment constants -- exist only in builds with -DCOVEST_DIAG
+    (tools/bin/, loaded through COVEST_AMD_LIB).  The shipped library must not even contain their names."""
+    from covest_amd import build
+    if os.environ.get("COVEST_AMD_LIB"):
+        import pytest
+        pytest.skip("COVEST_AMD_LIB points at another build")
+    blob = open(build.LIB_PATH, "rb").read()
+    for knob in (b"COVEST_FACTORED_SKIP", b"COVEST_FACTORED_DIAG", b"COVEST_FACTORED_SHARE", b"COVEST_FACTORED_NBUF",
+                 b"COVEST_NO_SUM_ITEMS", b"COVEST_FACTORED_BUILD_COST", b"COVEST_FACTORED_UNIT_OVERHEAD",
+                 b"COVEST_FACTORED_SHARED_DIV", b"COVEST_FACTORED_MIN_SHARED", b"COVEST_KMER_EXP"):
+        assert knob not in blob, knob.decode()
+    # what may stay: pure host-side I/O settings of the read parser (thread count, page-locked buffers)
+    allowed = set(re.findall(rb"COVEST_[A-Z_]{4,}", blob)) - {b"COVEST_READER_THREADS", b"COVEST_READER_PINNED"}
+    assert not {a for a in allowed if not a.startswith((b"COVEST_E_", b"COVEST_OK", b"COVEST_MODEL", b"COVEST_KERNEL",
+                                                        b"COVEST_MAX", b"COVEST_ABI"))}, allowed
+
+
 def test_compute_fails_loudly_without_device(hip_lib):
     """On a machine without a GPU every compute entry point raises -- it never
     silently computes on the CPU."""

@@ -39,40 +39,84 @@ def _oracle_model(oracle, kind, case, hist=None):
     return oracle.OracleModel(kind, case["k"], case["r"], hist, case["tail"], **kw)
 
 
+class _Slack(list):
+    """Per point the absolute difference tolerated in the tail term (a list of floats) plus `classes`: per point
+    None (the plain 1e-9 decides), "graded" (the conditioning-proportional slack is wider than 1e-10 |LL|) or
+    "flip" (the reference's own term is a coin toss); `unit`: |tail| eps / |1 - sp_j| per point, the first-order
+    price of ONE eps of error in sp_j (0 where there is no tail term to speak of)."""
+    classes = ()
+    unit = ()
+
+
 def _check(got, want, what, tol=TOL, slack=None):
-    """slack[i] > 0 marks a point whose REFERENCE value is itself rounding noise
-    (see _tail_noise) and gives the absolute difference tolerated there."""
-    worst = 0.0
+    """slack[i] > 0: the absolute difference tolerated at point i when the relative one exceeds `tol` (see
+    _tail_slack).  Returns the worst relative error among the points that met `tol`."""
+    worst, used, worst_use, k_eff = 0.0, 0, 0.0, 0.0
     for i, (a, b) in enumerate(zip(got, want)):
         e = rel_err(float(a), float(b))
+        if slack is not None and len(slack.unit) and slack.unit[i] > 0 and slack.classes[i] != "flip" and math.isfinite(e):
+            k_eff = max(k_eff, abs(float(a) - float(b)) / slack.unit[i])  # the sp_j error, in eps, this difference would mean
         if e > tol and slack is not None and slack[i] > 0 and abs(float(a) - float(b)) <= slack[i]:
+            used += 1
+            worst_use = max(worst_use, abs(float(a) - float(b)) / slack[i])
             continue
-        assert e <= tol, "%s[%d]: got %r want %r (rel %.3g)" % (what, i, float(a), float(b), e)
+        assert e <= tol, "%s[%d]: got %r want %r (rel %.3g%s)" % (
+            what, i, float(a), float(b), e,
+            "" if slack is None or not slack[i] else ", |diff| %.3g > tail slack %.3g" % (abs(float(a) - float(b)), slack[i]))
         worst = max(worst, e)
+    if used or k_eff:
+        print("%s: %d points beyond 1e-9 but inside the tail slack (largest share of it used: %.2g); the largest "
+              "difference outside the flip class, read as an error of sp_j: %.3g eps" % (what, used, worst_use, k_eff))
     return worst
 
 
-def _tail_noise(om, points, lls, tail):
-    """Where the reference's own tail term tail*log(1 - sp_j) (covest/models.py:103-104)
-    is rounding noise: sp_j is an fsum of rounded p_j, so 1 - sp_j carries an
-    absolute error of ~eps and the term an error of tail*eps/(1 - sp_j); when
-    sp_j rounds to 1 the term flips between 0 and tail*log(2^-53).  Returns per
-    point the absolute slack (0 = well conditioned, compare at 1e-9)."""
-    out = []
-    for p, ll in zip(points, lls):
-        if not tail or not math.isfinite(ll):
-            out.append(0.0)
-            continue
-        out.append(_tail_slack(tail, ll, math.fsum(om.compute_probabilities(*p).values())))
+K_TAIL = 8.0  # rounding errors of K eps per key are granted to the GPU's sp_j (first-order propagation)
+
+
+def _tail_slack(tail, ll, sp, n_keys):
+    """What may separate a correct implementation from the reference in the tail term tail * log(1 - sp_j)
+    (covest/models.py:103-104), given the sp_j = fsum(p_j) the REFERENCE saw.  The p_j of two correct
+    implementations differ by rounding, so their sp_j differ by up to delta = K eps n_keys and the term by
+    |tail| |log(1 - delta / (1 - sp_j))| ~ |tail| delta / (1 - sp_j): a slack GRADED by the conditioning, e.g.
+    7e-5 absolute at the optimum of the trimmed C3 histogram (1 - sp_j = 1e-4, 380 keys, tail 11 192) against
+    1e-9 |LL| = 0.1 -- there the term is simply checked.  Only where |1 - sp_j| <= delta -- the reference's term
+    itself hangs on the last bits of an fsum: it flips between 0 (sp_j rounds to >= 1) and tail * log(k 2^-53) -- is
+    the old absolute allowance of 40 |tail| (|log 2^-53| = 36.7) kept: the FLIP class.  sp_j > 1 + delta (the
+    reference's 200-chunk normaliser makes some pmfs too large) is no coin toss: the term is 0 on
+    both sides.  Returns (slack, class, unit) -- see _Slack."""
+    if not tail or not math.isfinite(ll):
+        return 0.0, None, 0.0
+    eps = 2.0 ** -52
+    delta = K_TAIL * eps * n_keys
+    if sp - 1.0 > delta:
+        return 0.0, None, 0.0
+    gap = 1.0 - sp
+    if gap <= delta:
+        return 40.0 * abs(tail), "flip", 0.0
+    slack = min(40.0, -math.log1p(-delta / gap)) * abs(tail)
+    return slack, ("graded" if slack > 1e-10 * abs(ll) else None), abs(tail) * eps / gap
+
+
+def _slack_of(tail, lls, sps, n_keys):
+    out, classes, unit = _Slack(), [], []
+    for ll, sp in zip(lls, sps):
+        v, c, u = _tail_slack(tail, ll, sp, n_keys)
+        out.append(v)
+        classes.append(c)
+        unit.append(u)
+    out.classes, out.unit = classes, unit
     return out
 
 
-def _tail_slack(tail, ll, sp):
-    """The criterion of _tail_noise for one point whose sp_j = fsum(p_j) is known."""
-    eps = 2.0 ** -52
-    gap = 1.0 - min(1.0, sp)
-    noise = abs(tail) * 4 * eps / gap if gap > 0 else math.inf
-    return abs(tail) * 40.0 if noise > 1e-10 * abs(ll) else 0.0
+def _tail_noise(om, points, lls, tail):
+    """_tail_slack for every point of a case whose reference values come from the oracle: sp_j = fsum of the
+    oracle's p_j (bit-equal to the reference's, tests/test_oracle_golden.py)."""
+    if not tail:
+        out = _Slack([0.0] * len(lls))
+        out.classes, out.unit = [None] * len(lls), [0.0] * len(lls)
+        return out
+    sps = [math.fsum(om.compute_probabilities(*p).values()) if math.isfinite(ll) else 1.0 for p, ll in zip(points, lls)]
+    return _slack_of(tail, lls, sps, len(om.hist))
 
 
 _BOUNDS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tail_noise_bounds.json")
@@ -81,22 +125,25 @@ _recorded = {}
 
 
 def _slack_budget(name, slack):
-    """The tail-noise slack must stay the exception: the number of points of case `name` that `_tail_noise`
-    marks (a property of the oracle's numbers alone, so it is the same on every box) may not exceed the count
-    committed in tests/golden/tail_noise_bounds.json.  A change that widened the criterion until every tail
-    point fell under it would fail here.  COVEST_RECORD_TAIL_BOUNDS=<path> records instead (new cases)."""
-    n = sum(1 for v in slack if v > 0)
+    """The slack must stay the exception: how many points of case `name` fall into the FLIP class and how many into
+    the GRADED one (a property of the reference's / the oracle's numbers alone, so the same on every box) may not
+    exceed the counts committed in tests/golden/tail_noise_bounds.json.  A change that widened the criterion until
+    every tail point fell under it would fail here.  COVEST_RECORD_TAIL_BOUNDS=<path> records instead (new cases)."""
+    n_flip = sum(1 for c in slack.classes if c == "flip")
+    n_graded = sum(1 for c in slack.classes if c == "graded")
     if _RECORD:
-        _recorded[name] = {"marked": n, "points": len(slack)}
+        _recorded[name] = {"flip": n_flip, "graded": n_graded, "points": len(slack)}
         with open(_RECORD, "w") as f:
             json.dump(_recorded, f, indent=0, sort_keys=True)
-        return n
+        return n_flip + n_graded
     with open(_BOUNDS_PATH) as f:
         bounds = json.load(f)
-    assert name in bounds, "no committed tail-noise bound for case %r" % name
-    assert n <= bounds[name]["marked"], "case %r: %d points under the tail-noise slack, committed bound %d of %d" % (
-        name, n, bounds[name]["marked"], bounds[name]["points"])
-    return n
+    assert name in bounds, "no committed tail-slack bound for case %r" % name
+    b = bounds[name]
+    assert n_flip <= b["flip"] and n_graded <= b["graded"], (
+        "case %r: %d flip / %d graded points under the tail slack, committed bounds %d / %d of %d" % (
+            name, n_flip, n_graded, b["flip"], b["graded"], b["points"]))
+    return n_flip + n_graded
 
 
 def test_device_present(hip_lib):
@@ -276,7 +323,7 @@ def test_config3_with_tail(hip_lib, oracle):
     assert m.bins_evaluated == 10000
     # where the reference's own tail term is rounding noise (1 - sp_j of a few ulp) the comparison carries the
     # explicit slack, decided from the sp_j the REFERENCE saw (recorded in the fixture)
-    slack = [_tail_slack(1000, v, sp) if math.isfinite(v) else 0.0 for v, sp in zip(g["ll"], g["sp"])]
+    slack = _slack_of(1000, g["ll"], [1.0 if sp is None else sp for sp in g["sp"]], 10000)
     _slack_budget("C3 tail sample", slack)
     got = m.loglikelihood_points(np.array(g["points"]), kernel="direct")
     worst = _check(got, g["ll"], "C3 tail sample (direct)", slack=slack)
@@ -288,10 +335,59 @@ def test_config3_with_tail(hip_lib, oracle):
     val, arg = grid.argmin()
     assert val == -ll[arg] and arg == int(np.argmin(np.where(np.isnan(ll), np.inf, -ll)))
     fix = load_golden("c3_argmin.json")["tail1000"]
-    aslack = [_tail_slack(1000, v, sp) if math.isfinite(v) else 0.0 for v, sp in zip(fix["ll"], fix["sp"])]
+    aslack = _slack_of(1000, fix["ll"], [1.0 if sp is None else sp for sp in fix["sp"]], 10000)
     _slack_budget("C3 tail arg-min candidates", aslack)
     _verify_argmin_with_reference(fix, grid, ll, arg, slack=aslack)
     print("C3 tail=1000 worst rel err", worst, "arg-min", arg, val)
+
+
+def test_config3_trimmed_histogram_with_its_tail(hip_lib):
+    """Config 3 on the histogram the reference's pipeline hands the model: H10k_rep trimmed by the reference's own
+    get_trim / trim_hist (covest/histogram.py:105-134) -- 380 keys, tail = 11 192, so that at the optimum
+    1 - sp_j ~ 1e-4 and the tail term tail * log(1 - sp_j) (covest/models.py:103-104) is WELL CONDITIONED.  4 096
+    seeded grid points with the reference's LL and sp_j: K-factored on the whole grid and K-direct on every eighth
+    point, graded slack (_tail_slack), at most 5 % of the points in the flip class; the arg-min confirmed by the
+    reference among the best 96 points of the grid and the axis neighbours of the best (tests/golden/c3_trim.json)."""
+    from covest_amd import DenseGrid, RepeatsModel
+    g = load_golden("c3_trim.json")
+    hist = load_hist(g["hist"])
+    assert len(hist) == g["n_keys"] == 380 and g["tail"] == 11192
+    m = RepeatsModel(g["k"], g["r"], hist, g["tail"], max_error=g["max_error"])
+    assert m.bins_evaluated == 380
+    axes = [g["axes"][0], g["axes"][1], g["axes"][2], [g["q2"]], g["axes"][3]]
+    grid = DenseGrid(m, axes)
+    grid.evaluate(kernel="factored")
+    assert grid.work()[2] == "ll_factored" and grid.total == 262144
+    ll = grid.loglikelihoods()
+    idx = np.array(g["flat_index"])
+    want = np.array(g["ll"])
+    assert int(np.isfinite(want).sum()) >= 4000
+    slack = _slack_of(g["tail"], g["ll"], g["sp"], g["n_keys"])
+    n_flip = sum(1 for c in slack.classes if c == "flip")
+    assert n_flip <= 0.05 * len(idx), n_flip
+    _slack_budget("C3 trimmed sample", slack)
+    worst = _check(ll[idx], want, "C3 trimmed (factored)", slack=slack)
+    sub = slice(0, None, 8)
+    pts = np.array([grid.point(int(i)) for i in idx[sub]])
+    dslack = _Slack(slack[sub])
+    dslack.classes, dslack.unit = slack.classes[sub], slack.unit[sub]
+    worst = max(worst, _check(m.loglikelihood_points(pts, kernel="direct"), want[sub], "C3 trimmed (direct)", slack=dslack))
+    # the arg-min: the GPU's candidates must be among those the reference was asked about, agree there, and the
+    # reference's winner under the scan of covest/grid.py:65-70 must be the GPU's
+    val, arg = grid.argmin()
+    assert val == -ll[arg] and arg == int(np.argmin(np.where(np.isnan(ll), np.inf, -ll)))
+    fix = g["candidates"]
+    known = {i: k for k, i in enumerate(fix["flat_index"])}
+    cand = _argmin_candidates(grid, ll, arg, top=64)
+    assert set(cand) <= set(known), "arg-min candidates outside the fixture: regenerate tests/golden/c3_trim.json"
+    cslack = _slack_of(g["tail"], fix["ll"], fix["sp"], g["n_keys"])
+    _slack_budget("C3 trimmed arg-min candidates", cslack)
+    _check(ll[fix["flat_index"]], fix["ll"], "C3 trimmed arg-min candidates", slack=cslack)
+    assert fix["reference_argmin_flat"] == arg
+    assert rel_err(val, fix["reference_min_negll"]) <= TOL
+    print("C3 trimmed: worst rel err", worst, "flip class", n_flip, "of", len(idx), "arg-min", arg, val)
+    grid.close()
+    m.close()
 
 
 def test_config4_c3_in_eight_blocks(hip_lib):
@@ -459,12 +555,12 @@ def test_factored_plan_shapes(hip_lib, oracle):
         print("factored plan shape:", name, "points", fac.total, "worst rel err vs direct", worst)
 
 
-def test_shared_steps_layouts(hip_lib, oracle, monkeypatch):
+def test_shared_steps_layouts(hip_lib, oracle):
     """K-factored's shared steps (tiles.h): the weight vectors of one q fill whole q-tiles of 16 -- exactly (16), with
     padding columns inside the order (12 -> 16, 27 -> 32, 36 -> 48), or not at all (9: too much padding, the plain
-    order).  Each layout against K-direct on the whole grid, against the same grid with the sharing switched off
-    (COVEST_FACTORED_SHARE=0: every step an MFMA step), and against the oracle on a sample; the grid cut into
-    blocks gives bit-identical values."""
+    order).  Each layout against K-direct on the whole grid and against the oracle on a sample; the grid cut into
+    blocks gives bit-identical values.  (The switch that turned the sharing off for A/B runs exists in diagnostic
+    builds only: the shipped library has no knob that changes values, tests/test_capi_symbols.py.)"""
     from covest_amd import DenseGrid, RepeatsModel
     rng = np.random.default_rng(11)
     hist = {j: int(v) for j, v in zip(range(1, 301), rng.integers(1, 3000, size=300))}
@@ -486,11 +582,6 @@ def test_shared_steps_layouts(hip_lib, oracle, monkeypatch):
         ref.evaluate(kernel="direct")
         _check(ll, ref.loglikelihoods(), name + " vs direct", tol=1e-10)
         assert fac.argmin()[1] == ref.argmin()[1]
-        monkeypatch.setenv("COVEST_FACTORED_SHARE", "0")
-        plain = DenseGrid(m, axes)
-        plain.evaluate(kernel="factored")
-        monkeypatch.delenv("COVEST_FACTORED_SHARE")
-        _check(ll, plain.loglikelihoods(), name + " vs the plain order", tol=1e-12)
         # two blocks of the flat range: the same plan, the same bits
         half = fac.total // 2 + 3
         parts = []
@@ -506,7 +597,7 @@ def test_shared_steps_layouts(hip_lib, oracle, monkeypatch):
         slack = _tail_noise(om, pts, want, tail)
         _slack_budget(name, slack)
         _check(ll[sel], want, name + " vs oracle", slack=slack)
-        for g in (fac, ref, plain):
+        for g in (fac, ref):
             g.close()
         m.close()
 
@@ -664,12 +755,13 @@ def test_estimator_fix_and_err_scale_on_gpu(hip_lib, oracle):
     # the search itself: every iterate is a grid point, so the end point must reproduce under the oracle, q2 must
     # still be the fixed value, and no grid point the search saw may beat it
     guess = [10.0, 0.5, 0.65, 0.5, 0.5]
-    res = optimize_grid(est.likelihood_f, guess, bounds=est.bounds, fix=fix)
+    trace = []
+    res = optimize_grid(est.likelihood_f, guess, bounds=est.bounds, fix=fix, trace=trace)
     assert res[3] == 0.5
-    final = optimize_grid.trace[-1]
+    final = trace[-1]
     model_pt = (res[0], res[1] / 10, res[2], 0.5, res[4])
     assert rel_err(final["value"], -om.compute_loglikelihood(*model_pt)) <= TOL
-    assert all(t["grid_size"] <= 6 ** 4 for t in optimize_grid.trace)  # a fixed dimension contributes one value
+    assert all(t["grid_size"] <= 6 ** 4 for t in trace)  # a fixed dimension contributes one value
     assert final["value"] <= est.likelihood_f(guess)
     # the same search without err_scale ends at the same model-space point: the scaling is only a reparametrisation
     plain = CoverageEstimator(m, fix=fix)
@@ -807,13 +899,14 @@ def test_optimize_grid_trace(hip_lib):
     for tr in g["traces"]:
         m = _gpu_model(tr["model"], tr)
         est = CoverageEstimator(m)
-        res = optimize_grid(est.likelihood_f, list(tr["initial_guess"]), bounds=est.bounds)
+        trace = []
+        res = optimize_grid(est.likelihood_f, list(tr["initial_guess"]), bounds=est.bounds, trace=trace)
         sizes = [int(line.split("Grid size:")[1]) for line in tr["log"] if "Grid size" in line]
-        assert [t["grid_size"] for t in optimize_grid.trace] == sizes
+        assert [t["grid_size"] for t in trace] == sizes
         assert list(res) == tr["result"], (tr["model"], res, tr["result"])
 
 
-@pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("COVEST_FUZZ_SEEDS", "10")))))
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("COVEST_FUZZ_SEEDS", "50")))))
 def test_fuzz_random_histograms(hip_lib, oracle, seed):
     """Random histograms (gapped keys, zero counts, huge counts, tail or not) and random points incl.
     the bound corners: every kernel that accepts the request against the oracle."""
@@ -854,4 +947,6 @@ def test_fuzz_random_histograms(hip_lib, oracle, seed):
         k_ref, _ = oracle.first_min(-gref)
         val, arg = grid.argmin()
         assert arg == k_ref or rel_err(float(ll[arg]), float(gref[k_ref])) <= TOL
-    _check(rm.loglikelihood_points(gp[::7]), gref[::7], "fuzz repeats list seed %d" % seed, slack=gslack[::7])
+    sub = _Slack(gslack[::7])
+    sub.classes, sub.unit = gslack.classes[::7], gslack.unit[::7]
+    _check(rm.loglikelihood_points(gp[::7]), gref[::7], "fuzz repeats list seed %d" % seed, slack=sub)

@@ -87,13 +87,14 @@ def test_optimize_grid_reproduces_reference_trace(oracle, which):
     tr = load_golden("grid_trace.json")["traces"][which]
     hist = load_hist(tr["hist"])
     om = oracle.OracleModel(tr["model"], tr["k"], tr["r"], hist, tr["tail"], max_error=tr["max_error"])
+    trace = []
     res = optimize_grid(_OracleNegLL(om), list(tr["initial_guess"]),
-                        bounds=[tuple(b) for b in tr["bounds"]])
+                        bounds=[tuple(b) for b in tr["bounds"]], trace=trace)
     sizes = [int(line.split("Grid size:")[1]) for line in tr["log"] if "Grid size" in line]
     news = [line for line in tr["log"] if line.startswith("New args")]
-    assert [t["grid_size"] for t in optimize_grid.trace] == sizes
+    assert [t["grid_size"] for t in trace] == sizes
     assert list(res) == tr["result"]
-    last = optimize_grid.trace[-1]
+    last = trace[-1]
     assert "ll: %r" % last["value"] in news[-1] or "ll: %s" % last["value"] in news[-1]
 
 

@@ -101,6 +101,40 @@ def test_config3_sample_cheapest(oracle):
         assert rel_err(float(a), g["ll"][i]) <= TIGHT, (g["points"][i], a, g["ll"][i])
 
 
+def test_config3_trimmed_fixture(oracle):
+    """tests/golden/c3_trim.json (the reference on H10k_rep trimmed by its own trim_hist, tail = the trimmed mass):
+    the trimmed histogram is what this repository's trim_hist makes of H10k_rep, and the oracle reproduces the
+    reference's LL and sp_j on every 24th sample point and on the arg-min candidates' winner -- bit-tight, tail
+    term included (the same fsum, the same log)."""
+    from covest_amd import hist_steps
+    g = load_golden("c3_trim.json")
+    src = load_hist(g["source_hist"])
+    trim = hist_steps.get_trim(src, ignore_last=True)
+    thist, tail = hist_steps.trim_hist(src, trim)
+    assert trim == g["trim"] and tail == g["tail"] and thist == load_hist(g["hist"])
+    m = oracle.OracleModel("repeats", g["k"], g["r"], thist, tail, max_error=g["max_error"])
+    q1s, qs = g["axes"][2], g["axes"][3]
+
+    def point(i):
+        return (g["axes"][0][i // 8192], g["axes"][1][(i // 256) % 32], q1s[(i // 16) % 16], g["q2"], qs[i % 16])
+
+    sel = list(range(0, len(g["flat_index"]), 24))
+    got = m.compute_loglikelihood_many(np.array([point(g["flat_index"][k]) for k in sel]), n_threads=8)
+    for k, a in zip(sel, got):
+        assert rel_err(float(a), g["ll"][k]) <= TIGHT, (k, a, g["ll"][k])
+    for k in sel[::8]:
+        if math.isfinite(g["ll"][k]):
+            sp = math.fsum(m.compute_probabilities(*point(g["flat_index"][k])).values())
+            assert abs(sp - g["sp"][k]) <= 4e-16, (k, sp, g["sp"][k])
+    c = g["candidates"]
+    w = c["flat_index"].index(c["reference_argmin_flat"])
+    assert rel_err(m.compute_loglikelihood(*point(c["reference_argmin_flat"])), c["ll"][w]) <= TIGHT
+    assert -c["ll"][w] == c["reference_min_negll"] == min(-v for v in c["ll"] if v == v)
+    # well conditioned where it matters: at the best points 1 - sp_j ~ tail / N = 1e-4 -- or sp_j > 1 by as much
+    # (the 200-chunk normaliser of the reference makes some pmfs too large, DESIGN.md 2; the term is then 0)
+    assert all(abs(1.0 - sp) > 1e-6 for sp in c["sp"])
+
+
 def test_synthetic_histograms_match_survey():
     # SURVEY 8(d): H256 has 73 non-zero bins and sum 10 000 003; H10k_basic 367 non-zero bins
     h = load_hist("H256")

@@ -124,3 +124,20 @@ def test_degenerate_files(tmp_path):
     lone = tmp_path / "lone.fq"
     lone.write_text("@r\nACGT")
     assert list(kh.load_reads(str(lone), kh.NS_IGNORE)) == ["acgt"]
+
+
+def test_fastq_blank_lines_and_malformed_records(tmp_path):
+    """Blank lines between records and at the end of the file are skipped (they used to shift the 4-line framing and
+    to add an empty read, i.e. k-mer 0); a record that breaks the framing is an error naming its byte offset, never
+    garbage that gets counted."""
+    fq = tmp_path / "blank.fq"
+    fq.write_text("@a\nACGT\n+\nIIII\n\n\n@b\nTTGA\n+\n@III\n\r\n@c\nGG\n+\nII\n\n\n\n")
+    assert list(kh.load_reads(str(fq), kh.NS_IGNORE)) == ["acgt", "ttga", "gg"]
+    for name, text in (("wrapped.fq", "@a\nACGT\nACGT\n+\nIIIIIIII\n"),    # a wrapped sequence line: not supported
+                       ("nohead.fq", "ACGT\n+\nIIII\n"),
+                       ("noplus.fq", "@a\nACGT\n\nIIII\n")):
+        f = tmp_path / name
+        f.write_text(text)
+        with pytest.raises(Exception) as err:
+            list(kh.load_reads(str(f), kh.NS_IGNORE))
+        assert "malformed FASTQ record at byte" in str(err.value)
