@@ -14,7 +14,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcovest_amd.so")
-SOURCES = ["capi.cpp", "reads_io.cpp", "ll_direct.hip", "ll_basic.hip", "ll_factored.hip", "argmin.hip", "kmer_count.hip", "thin_hist.hip"]
+# (source, extra flags, object name).  K-factored is compiled once per template variant, each into a translation unit
+# of its own (csrc/ll_factored.hip, COVEST_FACTORED_VARIANT): the HIP runtime loads a translation unit's code object
+# when one of its kernels is first launched, so a process only pays for the variants it uses.
+SOURCES = [("capi.cpp", (), "capi"), ("reads_io.cpp", (), "reads_io"), ("ll_direct.hip", (), "ll_direct"),
+           ("ll_basic.hip", (), "ll_basic"), ("ll_factored.hip", (), "ll_factored"), ("argmin.hip", (), "argmin"),
+           ("kmer_count.hip", (), "kmer_count"), ("thin_hist.hip", (), "thin_hist")]
+SOURCES += [("ll_factored.hip", ("-DCOVEST_FACTORED_VARIANT=%d" % v,), "ll_factored_v%d" % v) for v in range(8)]
+SOURCES += [("ll_basic.hip", ("-DCOVEST_BASIC_VARIANT=%d" % v,), "ll_basic_v%d" % v) for v in range(8)]
+MAX_PARALLEL = 8
 ARCH = "gfx950"
 
 
@@ -47,20 +55,29 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     common = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
               "-x", "hip"] + list(extra_flags)
     objs = []
-    procs = []
-    for src in SOURCES:
-        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
+    pending = list(SOURCES)
+    running = []
+
+    def reap(block_until_below):
+        while len(running) >= block_until_below:
+            src, p = running.pop(0)
+            log, _ = p.communicate()
+            if p.returncode != 0:
+                for _, q in running:
+                    q.kill()
+                raise RuntimeError("hipcc failed on %s:\n%s" % (src, log.decode(errors="replace")))
+            if verbose and log:
+                print(log.decode(errors="replace"))
+
+    for src, flags, name in pending:
+        obj = os.path.join(obj_dir, name + ".o")
+        cmd = [hipcc] + common + list(flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        reap(MAX_PARALLEL)
+        running.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
-    for src, p in procs:
-        log, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s" % (src, log.decode(errors="replace")))
-        if verbose and log:
-            print(log.decode(errors="replace"))
+    reap(1)
     target = LIB_PATH if out is None else out
     link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", target] + objs
     subprocess.check_call(link)

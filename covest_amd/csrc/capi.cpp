@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
 #include <mutex>
 #include <new>
@@ -270,23 +271,36 @@ int resolve_device(int device, const char *who, int *out)
 }
 
 // ln j! = lgamma(j + 1) rounded from long double, for j = 0, 1, 2, ...: a process-wide table grown on demand
-// (lgammal costs ~100 ns; a 10 000-key histogram paid 1 ms of it per model handle).
-double lgamma_of_factorial(int64_t j)
+// (lgammal costs ~100 ns; a 10 000-key histogram paid 1 ms of it per model handle).  A deque: growing it never moves
+// the entries already there, so a caller that has made sure of the first n (lgamma_ensure, under the lock) may read
+// them without it (lgamma_at) -- one lock per histogram instead of one per key.
+std::mutex g_lgamma_lock;
+std::deque<double> g_lgamma_table;
+constexpr int64_t kLgammaTableMax = (int64_t)1 << 22; // beyond any histogram the fast paths accept: not cached
+
+void lgamma_ensure(int64_t j_max)
 {
-    static std::mutex lock;
-    static std::vector<double> table;
+    if (j_max > kLgammaTableMax)
+        j_max = kLgammaTableMax;
+    std::lock_guard<std::mutex> guard(g_lgamma_lock);
+    for (size_t v = g_lgamma_table.size(); v <= (size_t)std::max<int64_t>(j_max, 0); ++v)
+        g_lgamma_table.push_back((double)lgammal((long double)v + 1.0L));
+}
+
+// (after lgamma_ensure(j) or larger)
+inline double lgamma_at(int64_t j)
+{
     if (j < 0)
         j = 0;
-    if (j > (int64_t)1 << 22) // beyond any histogram the fast paths accept: not cached
+    if (j > kLgammaTableMax)
         return (double)lgammal((long double)j + 1.0L);
-    std::lock_guard<std::mutex> guard(lock);
-    if ((size_t)j >= table.size()) {
-        const size_t old = table.size(), want = std::max<size_t>((size_t)j + 1, 2 * old);
-        table.resize(want);
-        for (size_t v = old; v < want; ++v)
-            table[v] = (double)lgammal((long double)v + 1.0L);
-    }
-    return table[(size_t)j];
+    return g_lgamma_table[(size_t)j];
+}
+
+double lgamma_of_factorial(int64_t j)
+{
+    lgamma_ensure(j);
+    return lgamma_at(j);
 }
 
 // One buffer, one copy: [key | lgam | cnt].
@@ -427,7 +441,59 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     m->keys_logged = 0.0;
     for (double c : cnt)
         m->keys_logged += c != 0.0 ? 1.0 : 0.0;
-    const size_t n_dbl = 4 * nt + 2 * nt * kTileBins + ni * kTileBins;
+    // K-factored's view of the rows (tiles.h): the scale of a plain item's rows as a factor (and its reciprocal, for
+    // the clamp in the row's units) and as the constant it adds to the item's sum of h_j log p_j
+    std::vector<double> item_scal(ni * kTileBins, 0.0), item_iscal(ni * kTileBins, 0.0), item_lconst(ni, 0.0);
+    for (size_t i2 = 0; i2 < ni; ++i2) {
+        if (item_sum[i2]) {
+            for (int b = 0; b < kTileBins; ++b)
+                item_scal[i2 * kTileBins + (size_t)b] = 1.0;
+            continue;
+        }
+        const size_t t = (size_t)item_first[i2];
+        long double lc = 0.0L, lratio = 0.0L; // ln((k0-1)!/(k0+b)!) = -sum_{i=k0}^{k0+b} ln i
+        for (int b = 0; b < tiles[t].nb; ++b) {
+            lratio -= logl((long double)(tiles[t].k0 + b));
+            const double sv = scal[t * kTileBins + (size_t)b];
+            if (sv == 0.0)
+                continue; // filler key
+            item_scal[i2 * kTileBins + (size_t)b] = sv;
+            if (cnt[t * kTileBins + (size_t)b] != 0.0) // (a row without a count takes no log and is never "low": 0)
+                item_iscal[i2 * kTileBins + (size_t)b] = 1.0 / sv;
+            lc += (long double)cnt[t * kTileBins + (size_t)b] * lratio;
+        }
+        item_lconst[i2] = (double)lc;
+    }
+    // K-basic's closed form (ll_basic.hip): suffix sums over the counted keys of the tiles t .. nt - 1
+    std::vector<double> suf(5 * (nt + 1) + 2, 0.0);
+    {
+        long double s_h = 0.0L, s_jh = 0.0L, s_lgh = 0.0L;
+        double first_key = 0.0, first_lg = 0.0;
+        for (size_t t = nt; t-- > 0;) {
+            for (int b = tiles[t].nb - 1; b >= 0; --b) {
+                const double h = cnt[t * kTileBins + (size_t)b];
+                if (h == 0.0)
+                    continue;
+                const int key = tiles[t].k0 + b;
+                const double lg = lgamma_at(key);
+                s_h += (long double)h;
+                s_jh += (long double)h * (long double)key;
+                s_lgh += (long double)h * (long double)lg;
+                first_key = (double)key;
+                first_lg = lg;
+                if (suf[5 * (nt + 1)] == 0.0) { // the first one met from the end: the last counted key
+                    suf[5 * (nt + 1)] = (double)key;
+                    suf[5 * (nt + 1) + 1] = lg;
+                }
+            }
+            suf[t] = (double)s_h;
+            suf[(nt + 1) + t] = (double)s_jh;
+            suf[2 * (nt + 1) + t] = (double)s_lgh;
+            suf[3 * (nt + 1) + t] = first_key;
+            suf[4 * (nt + 1) + t] = first_lg;
+        }
+    }
+    const size_t n_dbl = 4 * nt + 2 * nt * kTileBins + 3 * ni * kTileBins + ni + suf.size();
     std::vector<int32_t> tile_zero(nt, 0);
     for (size_t i2 = 0; i2 < ni; ++i2)
         if (item_sum[i2])
@@ -447,6 +513,10 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     put(scal.data(), nt * kTileBins * sizeof(double));
     put(cnt.data(), nt * kTileBins * sizeof(double));
     put(item_cnt.data(), ni * kTileBins * sizeof(double));
+    put(item_scal.data(), ni * kTileBins * sizeof(double));
+    put(item_iscal.data(), ni * kTileBins * sizeof(double));
+    put(item_lconst.data(), ni * sizeof(double));
+    put(suf.data(), suf.size() * sizeof(double));
     put(ints.data(), 2 * nt * sizeof(int32_t));
     put(tile_zero.data(), nt * sizeof(int32_t));
     put(item_first.data(), ni * sizeof(int32_t));
@@ -543,7 +613,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     const int n_columns = n_pass == 1 ? max_o : n_pass * pass_stride;
     // ---- deal (q-tile, half) units to the waves of a workgroup (tiles.h) ----
     const int ld = ((n_columns + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 11776 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 13440 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records, row constants)
     const int n_units = 2 * n_qtiles;
     const int hu = kHalfUnits; // (768 threads with 2 slots per half, 3 waves/SIMD, was measured: +1 %)
     const int mu = 2 * hu;
@@ -610,6 +680,8 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
                 if (lb < bb || (lb == bb && wave_load[(size_t)w] < wave_load[(size_t)best_wave]))
                     best_wave = w;
             }
+            if (best_wave < 0)
+                return fail(COVEST_E_INVALID, "K-factored plan: no wave has room for a unit (internal)");
             held[(size_t)best_wave].push_back(u);
             bin_load[(size_t)(best_wave % n_bins)] += u.cost;
             wave_load[(size_t)best_wave] += u.cost;
@@ -655,7 +727,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         }
     }
     // weights of every slot's first two MFMA steps, per lane (lane = 16 * (o mod 4) + column)
-    std::vector<double> piece_w(n_unit * 64 * 2, 0.0), unit_rho(n_unit * 2, 1.0);
+    std::vector<double> piece_w(n_unit * 64 * 2, 0.0), unit_rho(n_unit * 4, 1.0);
     // (eight consecutive copy numbers per slot and column: one libm pow, the rest by multiplication -- the kernel
     // advances the weights the same way from the third step on; a grid with few (c, e) pairs has many slots)
     for (size_t at = 0; at < n_unit; ++at) {
@@ -690,9 +762,14 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
                     piece_w[(at * 64 + (size_t)((d & 3) * 16 + colx)) * 2 + (size_t)(d >> 2)] = w;
             }
             if (unit_nsh[at] > 0) {
-                // (one q per tile: every live column writes the same two values)
-                unit_rho[2 * at] = 1.0 / std::pow(base, 4.0);
-                unit_rho[2 * at + 1] = std::pow(unit_rho[2 * at], 4.0);
+                // (one q per tile: every live column writes the same values) -- the shared steps are summed with
+                // weights RELATIVE TO THE FIRST of them, (1-q)^(4 (i - 1)) <= 1 (Horner in (1-q)^4, four chains in
+                // (1-q)^16), and the MFMA that brings the sum in multiplies by b_o of that first step, which the kernel
+                // makes from the weight it holds anyway -- b_o of the first step AFTER them -- times (1-q)^(-4 nsh)
+                // (<= 1e10: the cut-off is where b_o reaches 1e-8)
+                unit_rho[4 * at] = std::pow(base, 16.0);
+                unit_rho[4 * at + 2] = std::pow(base, 4.0);
+                unit_rho[4 * at + 3] = 1.0 / std::pow(base, 4.0 * (double)unit_nsh[at]);
             }
             if (unit_nsh[at] > 0) { // the first step after the shared ones: o = 5 + 4 nsh .. 8 + 4 nsh
                 const int o_after = o_first + 4 * (unit_nsh[at] + 1);
@@ -953,7 +1030,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     for (int64_t i = 0; i < n; ++i)
         t_max = std::max(t_max, std::min(513, (int)t_list[(size_t)i] - o_base_of(i)));
     const int ld = ((t_max - 1 + 31) / 32) * 32 + 2;
-    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 11776 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records)
+    const int n_buf = (2 * (size_t)kTileBins * ld + 64) * sizeof(double) + 13440 <= 160 * 1024 ? 2 : 1; // (+ the kernel's static LDS: log table, hand-back records, row constants)
     const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
     std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 64 * 2, 0.0);
     std::vector<int32_t> q_t(n_slots, 0), q_orig(n_slots, -1), unit_tile(n_unit, -1), unit_half(n_unit, 0),
@@ -1139,19 +1216,27 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
     // bins with h_j == 0 influence nothing and are dropped from the evaluated view.
     std::vector<double> key_a, lg_a, cnt_a, key_e, lg_e, cnt_e;
     std::vector<HostBin> eval_bins;
-    key_a.reserve(d->n_keys);
+    const bool keep_all = d->tail == 0.0; // (with a tail the evaluated view IS the full view)
+    if (keep_all) {
+        key_a.reserve((size_t)d->n_keys);
+        lg_a.reserve((size_t)d->n_keys);
+        cnt_a.reserve((size_t)d->n_keys);
+    }
     int hist_max = std::numeric_limits<int>::min();
+    for (int64_t b = 0; b < d->n_keys; ++b)
+        hist_max = std::max(hist_max, (int)d->keys[b]);
+    lgamma_ensure(hist_max); // one lock for the whole histogram
     for (int64_t b = 0; b < d->n_keys; ++b) {
         const int j = d->keys[b];
-        if (j > hist_max)
-            hist_max = j;
         const int je = j > 0 ? j : 0; // the product loop of the C extension is empty for j <= 0
         const double kd = (double)je;
-        const double lg = lgamma_of_factorial(je);
+        const double lg = lgamma_at(je);
         const double h = d->counts[b];
-        key_a.push_back(kd);
-        lg_a.push_back(lg);
-        cnt_a.push_back(h);
+        if (keep_all) {
+            key_a.push_back(kd);
+            lg_a.push_back(lg);
+            cnt_a.push_back(h);
+        }
         if (d->tail != 0.0 || h != 0.0) {
             key_e.push_back(kd);
             lg_e.push_back(lg);

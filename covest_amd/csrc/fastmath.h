@@ -108,4 +108,53 @@ __device__ __forceinline__ void fast_log_n(const double (&x)[N], double (&out)[N
         out[k] = fma((double)e[k], 0.693147180559945309417232121458, ent[k].y) + lp[k];
 }
 
+// N logs of POSITIVE doubles scaled by 2^SC, log(x 2^-SC): fast_log_n with the 2^-SC folded into the exponent
+// arithmetic -- the exponent comes off the bits with a shift and an add (two half-rate integer instructions, the
+// price of v_frexp_exp_i32_f64 alone), so the scale costs nothing; x must be a NORMAL double (the callers clamp).
+// (Taking the mantissa off the bits too -- and, or -- was tried: the compiler copies the low word into a fresh
+// register pair for it, v_frexp_mant_f64 is cheaper.)  DEG: log1p(r) to r^DEG, |r| <= 2^-9: 5 -> truncation 9e-18
+// (as fast_log); 4 -> r^5 / 5 <= 5.7e-15, zero-mean over the mantissa (odd in r) -- one FMA less per log, for
+// dense grids (ll_factored.hip).
+template <int N, int DEG, int SC>
+__device__ __forceinline__ void fast_log_bits_n(const double (&x)[N], double (&out)[N], const double *tab_lds)
+{
+    static_assert(kLogTableBits == 8, "table offset below takes the top 8 mantissa bits");
+    static_assert(DEG == 4 || DEG == 5, "log1p degree");
+    double m[N], r[N], q[N], lp[N];
+    int e[N];
+    double2 ent[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int hi = __double2hiint(x[k]);
+        e[k] = (hi >> 20) - (1022 + SC);
+        m[k] = __builtin_amdgcn_frexp_mant(x[k]); // [0.5, 1): the mantissa bits are x's own
+        const unsigned off = ((unsigned)hi >> 8) & 0xFF0u;
+        ent[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab_lds) + off);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        r[k] = fma(m[k], ent[k].x, -1.0);
+    if (DEG == 5) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            q[k] = fma_vvs(r[k], 0.2, -0.25);
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            q[k] = fma_vvs(r[k], q[k], 1.0 / 3.0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            q[k] = fma_vvs(r[k], -0.25, 1.0 / 3.0);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        q[k] = fma(r[k], q[k], -0.5);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        lp[k] = fma(r[k] * r[k], q[k], r[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        out[k] = fma((double)e[k], 0.693147180559945309417232121458, ent[k].y) + lp[k];
+}
+
 } // namespace covest

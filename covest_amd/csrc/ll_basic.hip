@@ -162,10 +162,49 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     // histogram whose counted keys lie in the hundreds and thousands -- is walked with that one stream, in a loop of
     // its own so that the other streams' registers are free there.  Their terms are exact zeros: no bit changes.
     int t = 0;
-    for (; t < tv.n_tiles && !st.only_first_left(); ++t)
+    for (; t < tv.n_tiles; ++t) {
+        if (tv.run_start[t] != 0 && t > 0) { // (wave-uniform) a gap in the keys: who is left on the far side of it?
+            const double k0 = tv.first_key[t];
+            st.retire_at_run_start(k0 - 1.0, k0 + (double)(tv.n_bins[t] - 1), tv.lgam_prev[t], tv.lgam_last[t]);
+        }
+        if (st.only_first_left())
+            break;
         do_tile(std::integral_constant<int, S>{}, t);
-    for (; t < tv.n_tiles; ++t)
-        do_tile(std::integral_constant<int, 1>{}, t);
+    }
+    // CLOSED FORM for the rest (round 3).  With one stream left and no tail, p_j = a_0 TP(x_0, j) for every later key
+    // -- the other classes' terms are below e^-760, exact zeros in the reference's doubles too -- so
+    //     log p_j = c_0 + j ln x_0 - ln j!        (c_0 = ln a_0 - D(x_0): the stream's anchor constants, streams.h)
+    // and the rest of the sum over the counted keys is three multiply-adds against sums the host made once per
+    // histogram (tiles.h suf_*):  c_0 sum h_j + ln x_0 sum j h_j - sum h_j ln j!.  It stands where every p_j is an
+    // ordinary double: log p_j is concave in j, so its smallest value over the remaining counted keys is at the first
+    // or the last of them, and that is compared with the clamp of direct_point.h.  Below e^-746 at either end p_j is 0
+    // in the reference (its cast to double flushes below 2^-1075 = e^-745.13, c_src/covest_poissonmodule.c:32, and
+    // a_0 <= 1) and the sum -inf (utils.safe_log).  A lane in between -- a p_j near or in the subnormal range -- sends
+    // its WAVE through the key-by-key walk, which names the rows for the strict evaluation; in a grid that is a band
+    // a few points wide.  C2 spends 330 of its 367 keys here.
+    bool walk_rest = t < tv.n_tiles;
+    if (!TAIL && walk_rest) {
+        const double first = tv.suf_first[t];
+        if (first == 0.0) {
+            walk_rest = false; // (wave-uniform) no counted key is left
+        } else {
+            const double lx0 = st.an.lx(0), c0 = st.an.c(0);
+            const double lp_first = fma(first, lx0, c0 - tv.suf_first_lg[t]);
+            const double lp_last = fma(tv.last_key[0], lx0, c0 - tv.last_key[1]);
+            const double lp_min = fmin(lp_first, lp_last);
+            const bool fine = lp_min > sub_list.log_p_clamp + 0.5;
+            const bool none = lp_first < -746.5 || lp_last < -746.5; // (a stream that is off has c_0 = -inf)
+            if (!__any(finite && !fine && !none)) { // wave-uniform
+                walk_rest = false;
+                dead |= __ballot(none && !fine);
+                if (fine)
+                    acc_ll += fma(c0, tv.suf_h[t], fma(lx0, tv.suf_jh[t], -tv.suf_lgh[t]));
+            }
+        }
+    }
+    if (walk_rest)
+        for (; t < tv.n_tiles; ++t)
+            do_tile(std::integral_constant<int, 1>{}, t);
 
     double tail_term = 0.0;
     if (TAIL) {
@@ -212,19 +251,49 @@ __global__ __launch_bounds__(64) void ll_basic_wide_kernel(const DevModel m, con
     ll_basic_body<S, TAIL, 64>(m, n_tiles, n_items, tile_dbl, tile_int, src, n, out_ll, sub_list);
 }
 
-template <int S>
-void launch_wide(bool tail, dim3 grid, hipStream_t stream, const DevModel &m, const TileView &tv, const PointSource &part,
-                 int64_t cnt, double *out, const SubList &sl)
+} // namespace
+
+// One (S, TAIL) variant per translation unit (COVEST_BASIC_VARIANT, as ll_factored.hip: the HIP runtime loads a
+// translation unit's code object on the first launch of one of its kernels; all eight together are 1.5 MB of code).
+template <int S, bool TAIL>
+void launch_ll_basic_variant(dim3 grid, hipStream_t stream, const DevModel &m, const TileView &tv, const PointSource &part,
+                             int64_t cnt, double *out, const SubList &sl)
 {
-    const size_t lds = (size_t)2 * S * 64 * sizeof(double);
-    if (tail)
-        hipLaunchKernelGGL((ll_basic_wide_kernel<S, true>), grid, dim3(64), lds, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+    if (S == 8) {
+        const size_t lds8 = (size_t)2 * 8 * 256 * sizeof(double);
+        hipLaunchKernelGGL((ll_basic_kernel<TAIL>), grid, dim3(256), lds8, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
                            tv.int_base, part, cnt, out, sl);
-    else
-        hipLaunchKernelGGL((ll_basic_wide_kernel<S, false>), grid, dim3(64), lds, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
-                           tv.int_base, part, cnt, out, sl);
+    } else {
+        const size_t lds = (size_t)2 * S * 64 * sizeof(double);
+        hipLaunchKernelGGL((ll_basic_wide_kernel<S, TAIL>), grid, dim3(64), lds, stream, m, tv.n_tiles, tv.n_items,
+                           tv.dbl_base, tv.int_base, part, cnt, out, sl);
+    }
 }
 
+#define COVEST_BASIC_ARGS dim3, hipStream_t, const DevModel &, const TileView &, const PointSource &, int64_t, double *, const SubList &
+#ifdef COVEST_BASIC_VARIANT
+// this translation unit holds ONE variant: bits 2..1 = 0: 8 streams, 1: 16, 2: 24, 3: 32; bit 0 = TAIL
+template void launch_ll_basic_variant<8 * ((COVEST_BASIC_VARIANT >> 1) + 1), (COVEST_BASIC_VARIANT & 1) != 0>(COVEST_BASIC_ARGS);
+#else
+extern template void launch_ll_basic_variant<8, false>(COVEST_BASIC_ARGS);
+extern template void launch_ll_basic_variant<8, true>(COVEST_BASIC_ARGS);
+extern template void launch_ll_basic_variant<16, false>(COVEST_BASIC_ARGS);
+extern template void launch_ll_basic_variant<16, true>(COVEST_BASIC_ARGS);
+extern template void launch_ll_basic_variant<24, false>(COVEST_BASIC_ARGS);
+extern template void launch_ll_basic_variant<24, true>(COVEST_BASIC_ARGS);
+extern template void launch_ll_basic_variant<32, false>(COVEST_BASIC_ARGS);
+extern template void launch_ll_basic_variant<32, true>(COVEST_BASIC_ARGS);
+
+namespace {
+template <int S>
+void launch_s(bool tail, dim3 grid, hipStream_t stream, const DevModel &m, const TileView &tv, const PointSource &part,
+              int64_t cnt, double *out, const SubList &sl)
+{
+    if (tail)
+        launch_ll_basic_variant<S, true>(grid, stream, m, tv, part, cnt, out, sl);
+    else
+        launch_ll_basic_variant<S, false>(grid, stream, m, tv, part, cnt, out, sl);
+}
 } // namespace
 
 hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSource &src, int64_t n,
@@ -237,7 +306,6 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
     const int s_pad = ((m.n_err + 7) / 8) * 8;
     const int bd = s_pad == 8 ? 256 : 64;
     // HIP wraps a grid of more than 2^32 threads silently: at most 2^23 workgroups per launch
-    const dim3 block(bd);
     const int64_t per_launch = (int64_t)bd << 23;
     for (int64_t first = 0; first < n; first += per_launch) {
         const int64_t cnt = n - first < per_launch ? n - first : per_launch;
@@ -249,21 +317,18 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
             part.flat_begin = src.flat_begin + first;
         else
             part.params = src.params + first * 2;
-        const size_t lds8 = (size_t)2 * 8 * 256 * sizeof(double);
+        const bool tail = m.tail != 0.0;
         if (s_pad == 16)
-            launch_wide<16>(m.tail != 0.0, grid, stream, m, tv, part, cnt, out_ll + first, sl);
+            launch_s<16>(tail, grid, stream, m, tv, part, cnt, out_ll + first, sl);
         else if (s_pad == 24)
-            launch_wide<24>(m.tail != 0.0, grid, stream, m, tv, part, cnt, out_ll + first, sl);
+            launch_s<24>(tail, grid, stream, m, tv, part, cnt, out_ll + first, sl);
         else if (s_pad == 32)
-            launch_wide<32>(m.tail != 0.0, grid, stream, m, tv, part, cnt, out_ll + first, sl);
-        else if (m.tail != 0.0)
-            hipLaunchKernelGGL((ll_basic_kernel<true>), grid, block, lds8, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
-                               tv.int_base, part, cnt, out_ll + first, sl);
+            launch_s<32>(tail, grid, stream, m, tv, part, cnt, out_ll + first, sl);
         else
-            hipLaunchKernelGGL((ll_basic_kernel<false>), grid, block, lds8, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
-                               tv.int_base, part, cnt, out_ll + first, sl);
+            launch_s<8>(tail, grid, stream, m, tv, part, cnt, out_ll + first, sl);
     }
     return hipGetLastError();
 }
+#endif // COVEST_BASIC_VARIANT
 
 } // namespace covest

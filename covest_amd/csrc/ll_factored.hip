@@ -12,8 +12,9 @@
 // takes one (c, e) and all Q of them, key tile by key tile (32 keys):
 //
 //   phase A  lane = copy number o: the 8 error-class streams of streams.h walk the
-//            32 keys (2 fp64 instr per pmf term) and store G[key][o] to LDS.  Waves
-//            whose lanes are all beyond Tmax skip it.
+//            32 keys (2 fp64 instr per pmf term) and store G'[key][o] -- their sum, without
+//            the key's scale (round 3, see the kernel) -- to LDS.  Waves whose lanes are
+//            all beyond Tmax skip it.
 //   phase B  P[key][q] = sum_o G[key][o] * b_o(q) on the fp64 matrix pipe:
 //            v_mfma_f64_16x16x4_f64, A = 16 keys x 4 o from LDS (conflict-free
 //            ds_read_b64: row stride = 4 dwords mod 64), B = 4 o x 16 q generated
@@ -70,6 +71,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // slots are always a prefix): all A fragments first -- N independent LDS reads in flight -- then per
 // slot the weight b_o (advanced by (1-q)^4, cut off at o >= T: models.py:198-206,239) and the MFMA.
 // Straight-line code: no per-slot branch separates the reads from their MFMAs.
+// (Measured and not kept, round 3: the fragments of step i + 1 read during step i -- 0.896 against 0.864 ms: the
+// registers of the second set are spilled elsewhere.)
 template <int N, int MU>
 __device__ __forceinline__ void contract_step(int i, const double *cur, const int (&a_off)[MU], const int (&cut)[MU],
                                               const double (&r4)[MU], double (&wrun)[MU], d4 (&acc)[MU])
@@ -88,6 +91,15 @@ __device__ __forceinline__ void contract_step(int i, const double *cur, const in
 
 // PLAIN: the shape every dense grid of the reference's own set-up has -- list_mode 0, at most 8 error classes (one
 // lane per copy number) -- compiled on its own so that the other modes' code costs it no registers.
+//
+// Round 3: the rows of a plain item stay UNSCALED in LDS and in the accumulators -- G' = the sum of the streams'
+// scaled terms (streams.h), P'_j = p_j / scal_j -- because the per-key scale is the same for every copy number and
+// every weight vector: log p_j = log(P'_j 2^-SC) + ln((k0-1)!/(k0+b)!), and the second term, weighted by h_j, is a
+// CONSTANT of the histogram (tiles.h item_lconst, long double on the host) added once per point.  Phase A loses two
+// multiplies per key pair and the 64 scalar registers the tile's scales took (the compiler fetched them pair by pair
+// right before their use: an exposed scalar-load latency every two keys); the 2^-SC disappears into the exponent
+// arithmetic of the log (fastmath.h fast_log_bits_n).  Only where p_j itself is needed -- sp_j with a tail, the
+// chunks' shares of p_j in list modes 2 and 3 -- a row is multiplied by its scale, read from LDS.
 template <int NT, int HU, bool TAIL, bool PLAIN>
 __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                          const double *__restrict__ tile_dbl,
@@ -99,6 +111,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     constexpr int NW = NT / kWave;
     constexpr int MU = 2 * HU; // accumulator slots per wave (6: the specialised step loops below assume it)
     static_assert(MU == 6, "contract loops are written for 6 slots");
+    constexpr bool NEED_SCAL = TAIL || !PLAIN; // p_j itself is needed somewhere: sp_j, or the chunks' shares
+    constexpr int LOG_DEG = PLAIN ? 4 : 5;     // (point lists keep the 2e-16 log: refinements difference their values)
     const int LD = plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
     __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
@@ -110,18 +124,22 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         sub_rec[2 * i] = 0xFFFFFFFFu;
         sub_rec[2 * i + 1] = 0;
     }
-    // (1-q)^-4 and (1-q)^-16 of every slot with shared steps (tiles.h): wave-uniform, read back as LDS broadcasts
-    // the counts h_j of the key tile being logged and of the next one: every unit reads the 4 rows of its lanes
-    // from here (LDS, addressed by the unit's half) instead of selecting between two register sets per row
-    __shared__ __attribute__((aligned(16))) double hbuf[2][kTileBins];
-    __shared__ __attribute__((aligned(16))) double rho_tab[PLAIN ? NW * MU * 2 : 2];
-    if (PLAIN && threadIdx.x < NW * MU * 2)
-        rho_tab[threadIdx.x] = plan.unit_rho[(int64_t)blockIdx.y * NW * MU * 2 + threadIdx.x];
+    // per row of the key tile being logged and of the next one: {h_j, p_clamp in the row's units (0: no count -- such
+    // a row is never "low")}, and the row's scale where p_j itself is needed.  Every unit reads the 4 rows of its lanes
+    // from here (LDS, addressed by the unit's half) instead of selecting between two register sets per row.
+    __shared__ __attribute__((aligned(16))) double2 rowc[2][kTileBins];
+    __shared__ __attribute__((aligned(16))) double rows[NEED_SCAL ? 2 : 1][NEED_SCAL ? kTileBins : 2];
+    // {(1-q)^16, -, (1-q)^4, (1-q)^(-4 nsh)} of every slot with shared steps (tiles.h): wave-uniform, read back as LDS broadcasts
+    __shared__ __attribute__((aligned(16))) double rho_tab[PLAIN ? NW * MU * 4 : 4];
+    __shared__ double lconst_s; // the constant the rows' scales add to every point's sum (tiles.h item_lconst)
+    if (PLAIN && threadIdx.x < NW * MU * 4)
+        rho_tab[threadIdx.x] = plan.unit_rho[(int64_t)blockIdx.y * NW * MU * 4 + threadIdx.x];
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const double p_clamp = plan.p_clamp; // direct_point.h
+    const double zero_frac = 0.45 * (4.94065645841246544e-324 / p_clamp); // 0.9 x 2^-1075 in units of p_clamp
     const int list_mode = PLAIN ? 0 : plan.list_mode;
 
     // ---- the (c, e) of this workgroup ----
@@ -147,6 +165,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int n_pass = PLAIN ? 1 : plan.n_pass; // lanes per copy number: one per 8 error classes (1 when max_error <= 8)
     if (tid < 8 * n_pass)
         Gs[tid] = error_class_rate(m, par[0], par[1], tid);
+    if (wave == NW - 1) { // the items' constants: one load per lane and 64 items, added in a fixed order
+        double lc = 0.0;
+        for (int t = t_begin + lane; t < t_end; t += kWave)
+            lc += tv.item_lconst[t];
+        lc = wave_sum(lc);
+        if (lane == 0)
+            lconst_s = lc;
+    }
     __syncthreads();
 
     // ---- phase-A state: lane = (pass, copy number): column pass * pass_stride + (o - o_base - 1) of G ----
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // ---- phase-B/C state: this wave's (q-tile, half) units ----
     const int col = lane & 15; // q column inside a tile / key row of the A fragment
     const int kq = lane >> 4;  // which of the 4 o of an MFMA step
-    int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU], nsh[MU];
+    int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU], a_off0[MU], nsh[MU];
     double r4[MU], llacc[MU];
     uint64_t dead[MU]; // lanes that met a p_j <= 0 with h_j != 0
     CompSum spacc[MU];
@@ -209,7 +235,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // shared steps (tiles.h): steps 1 .. nsh of the unit are summed on the vector unit; the MFMA loops below
         // then run over step 0 and the steps AFTER them, which is what a_off, cut and len are counted in
         nsh[k] = PLAIN ? __builtin_amdgcn_readfirstlane(on ? plan.unit_nsh[at] : 0) : 0;
-        a_off[k] = (16 * uhalf[k] + col) * LD + kq + 4 * (first_step + nsh[k]); // this lane's A fragment inside a G buffer
+        a_off0[k] = (16 * uhalf[k] + col) * LD + kq + 4 * first_step; // this lane's A fragment of the piece's first step
+        a_off[k] = a_off0[k] + 4 * nsh[k];                            // ... counted from the first step after the shared ones
         // iterations of the piece during which this lane's copy number o0 + 4 i + kq (o0: the piece's first one,
         // counted from the chunk's start) is below T (the chunk's local one)
         const int t_lane = on ? plan.q_T[slot] : 0;
@@ -236,18 +263,30 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         }
     };
     load_weights();
+    // A NaN among (q1, q2, q) makes every b_o from the third on a NaN (covest/models.py:193-208; its threshold_o is
+    // max(hist)), and the reference's likelihood with it.  The logs below work on the bits and would turn it into
+    // a finite number: the columns concerned are found here, once, from the weights themselves.
+    uint64_t nan_cols[MU];
+#pragma unroll
+    for (int k = 0; k < MU; ++k) {
+        const uint64_t nm = __ballot(wfirst[k] != wfirst[k] || wrun[k] != wrun[k]);
+        nan_cols[k] = ((nm | (nm >> 16) | (nm >> 32) | (nm >> 48)) & 0xFFFFull) * 0x0001000100010001ull;
+    }
 
-    // ================= phase A: G[key][o] of key tile t into `dst` =================
-    // in-kernel stamps (diagnostic runs only): cycles per wave in build / contract / log / barrier
+    // ================= phase A: G'[key][o] of key tile t into `dst` =================
+    // in-kernel stamps (diagnostic builds only): cycles per wave in build / contract / log / barrier
     long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0, dg_zero = 0;
 #ifdef COVEST_DIAG
     const bool diag = plan.diag != nullptr;
 #else
     constexpr bool diag = false; // (the stamps exist in diagnostic builds only: tiles.h)
 #endif
-    // the 32 keys of a full tile with the streams 0 .. N-1 (the others are zero in every lane of the wave)
-    auto walk_tile = [&](auto n_tag, const double *scal, double *colp, double renorm) __attribute__((always_inline)) {
+    // the 32 keys of a full tile with the streams 0 .. N-1 (the others are zero in every lane of the wave).  One
+    // region under the row mask, straight-line inside: the sums go to LDS as they stand (no scale, see above)
+    auto walk_tile = [&](auto n_tag, double *colp, double renorm) __attribute__((always_inline)) {
         constexpr int N = decltype(n_tag)::value;
+        if (!lane_in_row)
+            return; // (lanes past the row hold no copy number: nothing of theirs is ever read)
         // squared rates (the streams advance two keys per step, streams.h step2): N multiplies per tile
         // rather than 16 registers held through phases B and C -- the empty asm keeps the compiler from
         // hoisting them back out of the tile loop (it would spill them)
@@ -266,12 +305,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         for (int b = 0; b < kTileBins; b += 2) {
             double g1, g2;
             st.template step2n<N>(xx, g1, g2);
-            g1 *= scal[b];
-            g2 *= scal[b + 1];
-            if (lane_in_row) {
-                colp[b * LD] = g1;
-                colp[(b + 1) * LD] = g2;
-            }
+            colp[b * LD] = g1;
+            colp[(b + 1) * LD] = g2;
         }
         st.template leave_tile_n<N>(renorm);
     };
@@ -283,17 +318,16 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // n_live: streams above it are zero in every lane of this wave (streams.h) -- most of them, for most tiles
         const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
                                          tv.run_start[t] != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
-        const double *scal = tv.scal + (int64_t)t * kTileBins;
         double *colp = dst + (lane_in_row ? tid : 0);
-        if (nb == kTileBins) { // the common case: straight-line code, scales in SGPRs
+        if (nb == kTileBins) { // the common case: straight-line code
             if (n_live > 4) {
-                walk_tile(std::integral_constant<int, 8>{}, scal, colp, tv.renorm[t]);
+                walk_tile(std::integral_constant<int, 8>{}, colp, tv.renorm[t]);
             } else if (n_live > 2) {
-                walk_tile(std::integral_constant<int, 4>{}, scal, colp, tv.renorm[t]);
+                walk_tile(std::integral_constant<int, 4>{}, colp, tv.renorm[t]);
             } else if (n_live == 2) {
-                walk_tile(std::integral_constant<int, 2>{}, scal, colp, tv.renorm[t]);
+                walk_tile(std::integral_constant<int, 2>{}, colp, tv.renorm[t]);
             } else if (n_live == 1) {
-                walk_tile(std::integral_constant<int, 1>{}, scal, colp, tv.renorm[t]);
+                walk_tile(std::integral_constant<int, 1>{}, colp, tv.renorm[t]);
             } else if (lane_in_row) { // nothing is on: G = 0 for this wave's copy numbers
                 if (diag)
                     dg_zero += 1;
@@ -303,8 +337,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
             return;
         }
-        for (int b = 0; b < kTileBins; ++b) {
-            const double g = b < nb ? st.step() * scal[b] : 0.0;
+        for (int b = 0; b < kTileBins; ++b) { // (rows past the tile's keys: 0 -- they carry no count and no scale)
+            const double g = b < nb ? st.step() : 0.0;
             if (lane_in_row)
                 colp[b * LD] = g;
         }
@@ -312,7 +346,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     };
     // The same walk over a tile WITHOUT counts (tail != 0 only): sum_j G[o][j] over its keys stays in a register
     // -- 32 terms of one sign added plainly, the compensated accumulator of phase C gets their contraction --
-    // and is returned instead of 32 stores.
+    // and is returned instead of 32 stores.  These rows ARE scaled (a sum over keys needs every key's own scale).
     auto sum_tile = [&](auto n_tag, const double *scal, double renorm) __attribute__((always_inline)) -> double {
         constexpr int N = decltype(n_tag)::value; // the live streams, as in walk_tile
         double xx[8];
@@ -379,7 +413,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         }
     };
 
-    // in-kernel stamps (diagnostic runs only): cycles per wave in build / contract / log / barrier
+    // in-kernel stamps (diagnostic builds only): cycles per wave in build / contract / log / barrier
 #define STAMP(acc)                                    \
     if (diag) {                                       \
         const long long now__ = (long long)clock64(); \
@@ -389,196 +423,234 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     if (diag)
         dg_t0 = (long long)clock64();
 
-    // With two buffers the builders fill tile t+1 while every wave contracts tile t: one
-    // barrier per tile, and the host's unit assignment charges the builders for phase A.
+    // With two buffers the builders fill item t+1 while every wave contracts item t: one barrier per item, and the
+    // host's unit assignment charges the builders for phase A.  ONE loop for both set-ups (and ONE copy of phase A in
+    // the code: three used to be inlined): interval t builds item `tb` and contracts item t.
     const bool dbuf = plan.n_buf == 2;
-    if (tid < kTileBins && t_begin < t_end)
-        hbuf[t_begin & 1][tid] = tv.item_cnt[(int64_t)t_begin * kTileBins + tid]; // (a barrier follows before phase C)
-    if (dbuf && t_begin < t_end) {
-        if (wave_builds)
-            build_item(t_begin, Gs + (t_begin & 1) * kTileBins * LD);
-        __syncthreads();
-    }
-    for (int t = t_begin; t < t_end; ++t) {
-        const double *cur = Gs + (dbuf ? (t & 1) * kTileBins * LD : 0);
-        if (tid < kTileBins && t + 1 < t_end) // read after this iteration's closing barrier
-            hbuf[(t + 1) & 1][tid] = tv.item_cnt[(int64_t)(t + 1) * kTileBins + tid];
-        if (!dbuf) {
+    // the rows' constants of the item an interval builds are fetched one interval ahead (32 lanes of wave 0; the two
+    // or three loads are independent and have a whole interval to arrive)
+    double nxt_h = 0.0, nxt_c = 0.0, nxt_s = 0.0;
+    auto fetch_rows = [&](int it) {
+        if (tid < kTileBins && it < t_end) {
+            const int64_t at = (int64_t)it * kTileBins + tid;
+            nxt_h = tv.item_cnt[at];
+            nxt_c = tv.item_iscal[at]; // (0 for a row without a count)
+            if (NEED_SCAL)
+                nxt_s = tv.item_scal[at];
+        }
+    };
+    fetch_rows(t_begin);
+    for (int t = t_begin - (dbuf ? 1 : 0); t < t_end; ++t) {
+        const int tb = dbuf ? t + 1 : t;
+        if (tb < t_end) {
+            if (tid < kTileBins) { // read after the barrier that makes the item readable
+                rowc[tb & 1][tid] = make_double2(nxt_h, p_clamp * nxt_c);
+                if (NEED_SCAL)
+                    rows[tb & 1][tid] = nxt_s;
+            }
+            fetch_rows(tb + 1);
             if (wave_builds)
-                build_item(t, Gs);
-            __syncthreads();
-        } else if (wave_builds && t + 1 < t_end) {
-            build_item(t + 1, Gs + ((t + 1) & 1) * kTileBins * LD);
+                build_item(tb, Gs + (dbuf ? (tb & 1) * kTileBins * LD : 0));
         }
         STAMP(dg_a)
+        if (!dbuf)
+            __syncthreads();
+        if (t >= t_begin) {
+            const double *cur = Gs + (dbuf ? (t & 1) * kTileBins * LD : 0);
+            // ================= phase B: P' = G' x b on the matrix pipe =================
+            d4 acc[MU];
+            const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
+            // Every slot's accumulator starts from its first MFMA (C = 0 costs nothing; zeroing 8 registers per slot
+            // does); the step-0 fragments of all slots are read first, in flight together.
+            // A unit with shared steps (tiles.h) sums them on the vector unit:
+            //     sum_{i = 1 .. nsh} G'[key][1 + 4 i + kq] r^(i - 1),   r = (1-q)^4 (wave-uniform: the tile has one q)
+            // for this lane's key and o mod 4 -- weights RELATIVE TO THE FIRST shared step, so they only fall (the
+            // unscaled rows reach 1e297; with weights relative to the step AFTER the shared ones, up to 1e10, the sum
+            // could leave the range) -- as four Horner chains in r^4 (chain c: the steps i = 1 + c + 4 m) walked from
+            // the last step down, eight loads in flight per trip.  (Measured and not kept, round 3: the loads issued
+            // three groups ahead of their FMAs through a ring of four register sets, 0.934 against 0.872 ms -- the
+            // registers it takes are spilled elsewhere; and one fused pass over all the wave's units with one chain
+            // each, 1.08 ms.)  ONE MFMA brings the sum in: the four lanes of a key add up inside it,
+            // every column gets its own b_o of that first shared step, made from the weight the slot holds (b_o of
+            // the first step after them) times r^-nsh.
+            double a0[MU];
+#pragma unroll
+            for (int k = 0; k < MU; ++k)
+                a0[k] = cur[a_off0[k]]; // (an idle slot reads a valid address and uses nothing)
+#pragma unroll
+            for (int k = 0; k < MU; ++k) {
+                if (!PLAIN || nsh[k] == 0 || COVEST_SKIP_PHASE(plan, 8)) { // wave-uniform
+                    acc[k] = len[k] > 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], wfirst[k], zero4, 0, 0, 0) : zero4;
+                    continue;
+                }
+                const double rr16 = rho_tab[4 * (wave * MU + k)]; // (LDS broadcasts)
+                const double2 rt = *reinterpret_cast<const double2 *>(&rho_tab[4 * (wave * MU + k) + 2]);
+                const double rr4 = rt.x, rho_n = rt.y;
+                const double *g1 = cur + a_off0[k]; // step 0 of the unit (o = 1 .. 4); step i at g1[4 i]
+                const int n4 = nsh[k] >> 2, rem = nsh[k] & 3;
+                // the top `rem` steps (m = n4) are the heads of chains 0 .. rem - 1
+                const double *top = g1 + 4 * (1 + 4 * n4);
+                double h0 = rem > 0 ? top[0] : 0.0, h1 = rem > 1 ? top[4] : 0.0, h2 = rem > 2 ? top[8] : 0.0, h3 = 0.0;
+                {
+                    const double *q = top - 16; // steps 1 + 4 (n4 - 1) .. 4 n4
+                    int gq = n4;
+                    for (; gq >= 2; gq -= 2, q -= 32) { // eight loads in flight per trip
+                        const double b0 = q[0], b1 = q[4], b2 = q[8], b3 = q[12];
+                        const double c0 = q[-16], c1 = q[-12], c2 = q[-8], c3 = q[-4];
+                        h0 = fma(fma(h0, rr16, b0), rr16, c0);
+                        h1 = fma(fma(h1, rr16, b1), rr16, c1);
+                        h2 = fma(fma(h2, rr16, b2), rr16, c2);
+                        h3 = fma(fma(h3, rr16, b3), rr16, c3);
+                    }
+                    if (gq > 0) {
+                        h0 = fma(h0, rr16, q[0]);
+                        h1 = fma(h1, rr16, q[4]);
+                        h2 = fma(h2, rr16, q[8]);
+                        h3 = fma(h3, rr16, q[12]);
+                    }
+                }
+                const double hs = fma(fma(fma(h3, rr4, h2), rr4, h1), rr4, h0);
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(hs, wrun[k] * rho_n, zero4, 0, 0, 0);
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], wfirst[k], acc[k], 0, 0, 0);
+            }
+            STAMP(dg_b0)
+            // the remaining steps, specialised on the number of slots still running (len is sorted)
+            if (!COVEST_SKIP_PHASE(plan, 2)) {
+                int i = 1;
+                for (; i < len[5]; ++i)
+                    contract_step<6, MU>(i, cur, a_off, cut, r4, wrun, acc);
+                for (; i < len[4]; ++i)
+                    contract_step<5, MU>(i, cur, a_off, cut, r4, wrun, acc);
+                for (; i < len[3]; ++i)
+                    contract_step<4, MU>(i, cur, a_off, cut, r4, wrun, acc);
+                for (; i < len[2]; ++i)
+                    contract_step<3, MU>(i, cur, a_off, cut, r4, wrun, acc);
+                for (; i < len[1]; ++i)
+                    contract_step<2, MU>(i, cur, a_off, cut, r4, wrun, acc);
+                for (; i < len[0]; ++i)
+                    contract_step<1, MU>(i, cur, a_off, cut, r4, wrun, acc);
+            }
+            // pieces of one unit: add the accumulators into the unit's first slot.  A BRANCH per slot (the empty asm
+            // keeps the compiler from turning it into four adds and eight selects for every slot, taken or not)
+#pragma unroll
+            for (int k = MU - 1; k >= 1; --k)
+                if (cont[k]) { // wave-uniform
+                    asm volatile("" ::: "memory");
+                    acc[k - 1] += acc[k];
+                }
+            load_weights(); // for the next key tile
 
-        // ================= phase B: P = G x b on the matrix pipe =================
-        d4 acc[MU];
-        // Every slot's accumulator starts from its first MFMA (C = 0 costs nothing; zeroing 8 registers per slot does).
-        // A unit with shared steps (tiles.h) first sums them: sum_{i = 1 .. nsh} G[key][1 + 4 i + kq] rho^(nsh + 1 - i)
-        // for this lane's key and o mod 4 (rho = (1-q)^-4, wave-uniform: the tile has one q) -- weights RELATIVE TO
-        // THE FIRST STEP AFTER the shared ones, whose b_o the slot holds anyway (wrun) -- and ONE MFMA brings the
-        // sum in: the four lanes of a key add up inside it, every column gets its own b_o.  Then step 0 (o = 1 .. 4;
-        // its weights come masked by the cut-off from the host).
-        const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
+            STAMP(dg_b)
+            // ================= phase C: h_j * log p_j from the accumulators =================
+            const bool item_is_sum = TAIL && tv.item_sum[t] != 0; // wave-uniform
+            // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
-        for (int k = 0; k < MU; ++k) {
-            if (!PLAIN || nsh[k] == 0 || COVEST_SKIP_PHASE(plan, 8)) { // wave-uniform (skip bit 8: profiling aid, tiles.h)
-                acc[k] = len[k] > 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(cur[a_off[k]], wfirst[k], zero4, 0, 0, 0) : zero4;
-                continue;
-            }
-            // Four Horner chains in rho^4 over ascending steps -- eight loads in flight per trip of the loop: a
-            // lane's steps are 4 columns apart in LDS, and one wave in two on this SIMD sits in the same loop,
-            // so nothing else hides their latency.  (rho^(4 nsh) <= 1e10: the cut-off is where b_o reaches 1e-8.)
-            const double rho = rho_tab[2 * (wave * MU + k)], rho4 = rho_tab[2 * (wave * MU + k) + 1]; // (LDS broadcast)
-            const double *g1 = cur + (a_off[k] - 4 * nsh[k]); // step 0 of the unit (o = 1 .. 4); step i at g1[4 i]
-            const int n4 = nsh[k] >> 2, rem = nsh[k] & 3;
-            // chain c: the steps i with (nsh - i) mod 4 == c; the first `rem` steps are the chains' heads
-            double h0 = rem > 0 ? g1[4 * rem] : 0.0, h1 = rem > 1 ? g1[4 * (rem - 1)] : 0.0,
-                   h2 = rem > 2 ? g1[4 * (rem - 2)] : 0.0, h3 = 0.0;
-            const double *q = g1 + 4 * (rem + 1);
-            int gq = 0;
-            for (; gq + 2 <= n4; gq += 2, q += 32) {
-                const double a3 = q[0], a2 = q[4], a1 = q[8], a0 = q[12];
-                const double b3 = q[16], b2 = q[20], b1 = q[24], b0 = q[28];
-                h3 = fma(fma(h3, rho4, a3), rho4, b3);
-                h2 = fma(fma(h2, rho4, a2), rho4, b2);
-                h1 = fma(fma(h1, rho4, a1), rho4, b1);
-                h0 = fma(fma(h0, rho4, a0), rho4, b0);
-            }
-            if (gq < n4) {
-                h3 = fma(h3, rho4, q[0]);
-                h2 = fma(h2, rho4, q[4]);
-                h1 = fma(h1, rho4, q[8]);
-                h0 = fma(h0, rho4, q[12]);
-            }
-            const double hs = rho * fma(fma(fma(h3, rho, h2), rho, h1), rho, h0);
-            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(hs, wrun[k], zero4, 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(g1[0], wfirst[k], acc[k], 0, 0, 0);
-        }
-        STAMP(dg_b0)
-        // the remaining steps, specialised on the number of slots still running (len is sorted)
-        if (!COVEST_SKIP_PHASE(plan, 2)) {
-            int i = 1;
-            for (; i < len[5]; ++i)
-                contract_step<6, MU>(i, cur, a_off, cut, r4, wrun, acc);
-            for (; i < len[4]; ++i)
-                contract_step<5, MU>(i, cur, a_off, cut, r4, wrun, acc);
-            for (; i < len[3]; ++i)
-                contract_step<4, MU>(i, cur, a_off, cut, r4, wrun, acc);
-            for (; i < len[2]; ++i)
-                contract_step<3, MU>(i, cur, a_off, cut, r4, wrun, acc);
-            for (; i < len[1]; ++i)
-                contract_step<2, MU>(i, cur, a_off, cut, r4, wrun, acc);
-            for (; i < len[0]; ++i)
-                contract_step<1, MU>(i, cur, a_off, cut, r4, wrun, acc);
-        }
-        // pieces of one unit: add the accumulators into the unit's first slot
+            for (int k = 0; k < MU; ++k) {
+                if (list_mode == 2) { // a chunk of a point's copy numbers: hand p_j's share on (column 0 only)
+                    if (qslot[k] >= 0 && !cont[k] && col == 0) {
 #pragma unroll
-        for (int k = MU - 1; k >= 1; --k)
-            if (cont[k]) // wave-uniform
-                acc[k - 1] += acc[k];
-        load_weights(); // for the next key tile
-
-        STAMP(dg_b)
-        // ================= phase C: h_j * log p_j from the accumulators =================
-        const bool item_is_sum = TAIL && tv.item_sum[t] != 0; // wave-uniform
-        // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
-#pragma unroll
-        for (int k = 0; k < MU; ++k) {
-            if (list_mode == 2) { // a chunk of a point's copy numbers: hand p_j's share on (column 0 only)
-                if (qslot[k] >= 0 && !cont[k] && col == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        plan.partial[(ce * tv.n_items + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] =
-                            acc[k][r];
+                        for (int r = 0; r < 4; ++r)
+                            plan.partial[(ce * tv.n_items + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] =
+                                acc[k][r] * rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0];
+                    }
+                    continue;
                 }
-                continue;
-            }
-            if (list_mode == 3) { // a chunk of the copy numbers of a dense grid's LONG weight vectors: every
-                                       // column's share of p_j goes to (the first chunk) or is added to the block's
-                                       // buffer in HBM; ll_finish_dense takes the logs.  Each element has one owner.
-                if (qslot[k] >= 0 && !cont[k]) {
-                    double *row = plan.partial + (((ce - plan.ce_first) * plan.n_cols_partial + qslot[k]) * tv.n_items + t) * kTileBins +
-                                  16 * uhalf[k] + kq;
+                if (list_mode == 3) { // a chunk of the copy numbers of a dense grid's LONG weight vectors: every
+                                           // column's share of p_j goes to (the first chunk) or is added to the block's
+                                           // buffer in HBM; ll_finish_dense takes the logs.  Each element has one owner.
+                    if (qslot[k] >= 0 && !cont[k]) {
+                        double *row = plan.partial + (((ce - plan.ce_first) * plan.n_cols_partial + qslot[k]) * tv.n_items + t) * kTileBins +
+                                      16 * uhalf[k] + kq;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        row[4 * r] = plan.o_base == 0 ? acc[k][r] : row[4 * r] + acc[k][r];
+                        for (int r = 0; r < 4; ++r) {
+                            const double share = acc[k][r] * rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0];
+                            row[4 * r] = plan.o_base == 0 ? share : row[4 * r] + share;
+                        }
+                    }
+                    continue;
                 }
-                continue;
-            }
-            if (TAIL && item_is_sum) { // rows are sums over count-less tiles: they only enter sp_j
-                if (qslot[k] >= 0 && !cont[k]) {
+                if (TAIL && item_is_sum) { // rows are sums over count-less tiles (scaled ones): they only enter sp_j
+                    if (qslot[k] >= 0 && !cont[k]) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        spacc[k].add(acc[k][r]);
+                        for (int r = 0; r < 4; ++r)
+                            spacc[k].add(acc[k][r]);
+                    }
+                    continue;
                 }
-                continue;
-            }
-            if (qslot[k] >= 0 && !cont[k] && !COVEST_SKIP_PHASE(plan, 4)) { // wave-uniform: first slot of a unit
-                // Everything out of the ordinary -- p_j <= 0, or deep in the subnormal range (below p_clamp,
-                // direct_point.h), at a key with h_j != 0 -- is caught by ONE compare per row, made BEFORE the logs
-                // (the accumulators are not kept alive for it), and sorted out in a branch the wave takes for one
-                // unit in twenty.  Filler and padding keys have h == 0 (`if h`, covest/models.py:106) and add
-                // 0 * log below.
-                // (the compare does not look at h: rows without a count -- filler keys, a tile's padding -- have
-                // p == 0 and come through here too, in the few tiles that have such rows, and are sorted out inside)
-                const double *hp = &hbuf[t & 1][16 * uhalf[k] + kq]; // h of this lane's rows kq, kq + 4, ...
-                uint64_t low[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    low[r] = __ballot(acc[k][r] < p_clamp);
-                if (__builtin_expect(((low[0] | low[1] | low[2] | low[3]) & ~dead[k]) != 0, 0)) {
-                    // wave-uniform, cold (a lane that is dead already has nothing more to report).  Kept SHORT: a
-                    // wave in here holds up its whole workgroup at the tile's barrier
-                    uint64_t subm = 0, zero = 0;
+                if (qslot[k] >= 0 && !cont[k] && !COVEST_SKIP_PHASE(plan, 4)) { // wave-uniform: first slot of a unit
+                    // Everything out of the ordinary -- p_j <= 0, or deep in the subnormal range (below p_clamp,
+                    // direct_point.h), at a key with h_j != 0 -- is caught by ONE compare per row against the clamp in
+                    // the row's own units (0 for a row without a count: filler keys, a tile's padding, zero counts
+                    // with a tail -- never "low"), made BEFORE the logs, and sorted out in a branch the wave takes
+                    // for one unit in twenty.  Rows without a count add 0 * log below.
+                    const double2 *rc = &rowc[t & 1][16 * uhalf[k] + kq]; // {h, clamp} of this lane's rows kq, kq + 4, ...
+                    double h4[4], c4[4], x4[4], lg4[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const double h = hp[4 * r];
-                        low[r] &= __ballot(h != 0.0);
-                        const uint64_t z = __ballot(acc[k][r] <= 0.0) & low[r];
-                        zero |= z;
-                        subm |= low[r] & ~z;
+                        const double2 hc = rc[4 * r];
+                        h4[r] = hc.x;
+                        c4[r] = hc.y;
                     }
-                    // utils.safe_log: p_j <= 0 with h_j != 0 makes the sum -inf; kept as a lane mask in SGPRs -- for
-                    // all four row groups of the weight vector (column) at once: its sum is -inf whichever of them
-                    // met the zero, and the other three need not come through here for it
-                    const uint64_t zc = (zero | (zero >> 16) | (zero >> 32) | (zero >> 48)) & 0xFFFFull;
-                    dead[k] |= zc * 0x0001000100010001ull;
-                    // p_j DEEP IN THE SUBNORMAL RANGE: the unit (this half tile) is recorded for every weight vector
-                    // (column) concerned -- first and last unit met; one writer per entry, the lane of row group 0.
-                    // The strict evaluation of its counted rows follows in ll_fix_list_kernel (argmin.hip)
-                    const uint64_t cm = (subm | (subm >> 16) | (subm >> 32) | (subm >> 48)) & 0xFFFFull;
-                    if (kq == 0 && ((cm >> col) & 1)) {
-                        const unsigned u = 2u * (unsigned)(TAIL ? tv.item_first[t] : t) + (unsigned)uhalf[k];
-                        unsigned *rec = &sub_rec[((wave * MU + k) * 16 + col) * 2];
-                        rec[0] = min(rec[0], u);
-                        rec[1] = max(rec[1], u + 1);
+                    if (TAIL) { // sp_j needs p_j itself (filler and padding keys: scale 0), before the clamp
+                        const double *sr = &rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq : 0];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            spacc[k].add(acc[k][r] * sr[NEED_SCAL ? 4 * r : 0]);
                     }
+                    uint64_t low[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        low[r] = __ballot(acc[k][r] < c4[r]);
+                    if (__builtin_expect(((low[0] | low[1] | low[2] | low[3]) & ~dead[k]) != 0, 0)) {
+                        // wave-uniform, cold (a lane that is dead already has nothing more to report).  Kept SHORT: a
+                        // wave in here holds up its whole workgroup at the tile's barrier
+                        uint64_t subm = 0, zero = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // p_j = 0 in the reference: every term of its sum is at most the sum, and a term below
+                            // 2^-1075 is flushed by the extension's cast to double (c_src/covest_poissonmodule.c:32) --
+                            // so a row whose p_j (row value x scale) is safely below 2^-1075 is a zero, not a candidate
+                            // for the strict evaluation.  (The unscaled row value itself never underflows: half of the
+                            // C3 grid is -inf this way, and would otherwise queue up for the strict kernel.)
+                            const uint64_t z = __ballot(acc[k][r] <= c4[r] * zero_frac) & low[r];
+                            zero |= z;
+                            subm |= low[r] & ~z;
+                            // log(max(p_j, p_clamp)): what a p_j deep in the subnormal range contributes is then a
+                            // known constant, which the strict evaluation of that key replaces (direct_point.h).  In
+                            // place: the accumulator is of no further use, and a copy would cost every unit a move.
+                            acc[k][r] = max_raw(acc[k][r], c4[r]);
+                        }
+                        // utils.safe_log: p_j <= 0 with h_j != 0 makes the sum -inf; kept as a lane mask in SGPRs -- for
+                        // all four row groups of the weight vector (column) at once: its sum is -inf whichever of them
+                        // met the zero, and the other three need not come through here for it
+                        const uint64_t zc = (zero | (zero >> 16) | (zero >> 32) | (zero >> 48)) & 0xFFFFull;
+                        dead[k] |= zc * 0x0001000100010001ull;
+                        // p_j DEEP IN THE SUBNORMAL RANGE: the unit (this half tile) is recorded for every weight vector
+                        // (column) concerned -- first and last unit met; one writer per entry, the lane of row group 0.
+                        // The strict evaluation of its counted rows follows in ll_fix_list_kernel (argmin.hip)
+                        const uint64_t cm = (subm | (subm >> 16) | (subm >> 32) | (subm >> 48)) & 0xFFFFull;
+                        if (kq == 0 && ((cm >> col) & 1)) {
+                            const unsigned u = 2u * (unsigned)(TAIL ? tv.item_first[t] : t) + (unsigned)uhalf[k];
+                            unsigned *rec = &sub_rec[((wave * MU + k) * 16 + col) * 2];
+                            rec[0] = min(rec[0], u);
+                            rec[1] = max(rec[1], u + 1);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        x4[r] = acc[k][r];
+                    // no branch on h (it differs between the lanes' rows): the four logs of a unit go through
+                    // fast_log_bits_n stage by stage, their table reads in flight together.  (A dead lane's row may be
+                    // 0 here: the log of those bits is a finite number nobody uses.)
+                    fast_log_bits_n<4, LOG_DEG, kScaleBits>(x4, lg4, log_tab);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        llacc[k] = fma(h4[r], lg4[r], llacc[k]);
+                    __builtin_amdgcn_sched_barrier(0); // ... one unit at a time: registers
                 }
-                // no branch on h (it differs between the lanes' rows): the four logs of a unit go through fast_log_n
-                // stage by stage, their table reads in flight together.  log(max(p_j, p_clamp)): what a p_j deep in
-                // the subnormal range contributes is then a known constant, which the strict evaluation of that key
-                // replaces (direct_point.h)
-                double pc4[4], lg4[4], h4[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    h4[r] = hp[4 * r]; // (LDS: in flight under the logs)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double p = acc[k][r];
-                    if (TAIL)
-                        spacc[k].add(p); // (filler and padding keys: p == 0)
-                    pc4[r] = max_raw(p, p_clamp);
-                }
-                fast_log_n<4>(pc4, lg4, log_tab);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    llacc[k] = fma(h4[r], lg4[r], llacc[k]);
-                __builtin_amdgcn_sched_barrier(0); // ... one unit at a time: registers
             }
+            STAMP(dg_c)
         }
-        STAMP(dg_c)
         __syncthreads(); // the tile just contracted may be overwritten, the one just built may be read
         STAMP(dg_w)
     }
@@ -597,12 +669,15 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         return; // (wave-uniform for the whole workgroup) the chunks are combined by ll_finish_partials / _dense
     // ---- per-q results: sum the 4 row groups of the accumulator layout, then the two
     //      halves of each q-tile (they may live on different waves) through LDS ----
+    const double lconst = lconst_s; // (read before the buffer below is reused: lconst_s is static LDS of its own)
     double *part_ll = Gs;                               // [NW][MU][16]
     double *part_hi = Gs + (size_t)NW * MU * 16; // compensated sp_j parts
     double *part_lo = part_hi + (size_t)NW * MU * 16;
 #pragma unroll
     for (int k = 0; k < MU; ++k) {
         double ll = llacc[k];
+        if ((nan_cols[k] >> lane) & 1)
+            ll = NAN; // a NaN weight vector: math.log(nan), covest/models.py:105
         if ((dead[k] >> lane) & 1)
             ll = isnan(ll) ? ll : -INFINITY; // h * -inf summed with finite terms
         ll += __shfl_xor(ll, 16, kWave);
@@ -644,7 +719,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     break;
                 }
             }
-        const double ll = part_ll[e] + (pe >= 0 ? part_ll[pe] : 0.0);
+        // + the constant of the rows' scales (see the kernel's header): sum_j h_j ln((k0-1)!/(k0+b)!) over this
+        // workgroup's items
+        const double ll = (part_ll[e] + (pe >= 0 ? part_ll[pe] : 0.0)) + lconst;
         // the units handed back for this weight vector: this half-0 slot's record and its half-1 partner's
         unsigned u_first = sub_rec[2 * e], u_end = sub_rec[2 * e + 1];
         if (pe >= 0) {
@@ -693,6 +770,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
 }
 
+#ifndef COVEST_FACTORED_VARIANT // (the finishing kernels live in the common translation unit only)
 // One wave finishes ONE point whose p_j lie in HBM, summed over chunks of copy numbers (tiles.h list modes 2, 3):
 // LL = sum_j h_j log p_j + tail log(1 - sp), covest/models.py:100-107.  read_pj(row): the p_j of row `row` of the
 // items (tiles.h: a key, or the sum over a count-less tile).  A subnormal p_j at a key with h_j != 0 is replaced on
@@ -806,10 +884,18 @@ __global__ __launch_bounds__(kWave) void ll_finish_dense(const DevModel m, const
         out_ll[flat - src.flat_begin] = v;
 }
 
-template <int NT, int HU, bool TAIL, bool PLAIN>
-hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
-                          double *out_ll, const SubList &sub_list, hipStream_t stream)
+#endif // COVEST_FACTORED_VARIANT
+
+} // namespace
+
+// One instantiation per translation unit (COVEST_FACTORED_VARIANT, see the end of this file): the HIP runtime
+// loads a translation unit's code object when one of its kernels is first launched, and a process that evaluates a
+// plain dense grid should not pay for the seven other variants (75-98 KB of code each).
+template <int NT, bool TAIL, bool PLAIN>
+hipError_t launch_ll_factored_variant(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
+                                      double *out_ll, const SubList &sub_list, hipStream_t stream)
 {
+    constexpr int HU = kHalfUnits;
     // + 64 zeroed doubles: the last piece of a unit may run a few (masked, weight 0) steps past the end
     // of a G row; what it reads there must be finite
     // (the per-q combine at the end reuses the buffer for three [waves][slots][16] arrays)
@@ -843,16 +929,35 @@ hipError_t launch_nt_tail(const DevModel &m, const TileView &tv, const FactoredP
     return hipGetLastError();
 }
 
-template <int NT, int HU>
+#ifdef COVEST_FACTORED_VARIANT
+// this translation unit holds ONE variant: bit 2 = 512 threads (else 256), bit 1 = TAIL, bit 0 = PLAIN
+template hipError_t launch_ll_factored_variant<(COVEST_FACTORED_VARIANT & 4) ? 512 : 256, (COVEST_FACTORED_VARIANT & 2) != 0,
+                                               (COVEST_FACTORED_VARIANT & 1) != 0>(const DevModel &, const TileView &,
+                                                                                   const FactoredPlan &, double *,
+                                                                                   const SubList &, hipStream_t);
+#else
+// the common translation unit: the finishing kernels and the dispatcher; the variants are linked in
+extern template hipError_t launch_ll_factored_variant<256, false, false>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+extern template hipError_t launch_ll_factored_variant<256, false, true>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+extern template hipError_t launch_ll_factored_variant<256, true, false>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+extern template hipError_t launch_ll_factored_variant<256, true, true>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+extern template hipError_t launch_ll_factored_variant<512, false, false>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+extern template hipError_t launch_ll_factored_variant<512, false, true>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+extern template hipError_t launch_ll_factored_variant<512, true, false>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+extern template hipError_t launch_ll_factored_variant<512, true, true>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+
+namespace {
+
+template <int NT>
 hipError_t launch_nt(const DevModel &m, const TileView &tv, const FactoredPlan &plan, double *out_ll,
                      const SubList &sub_list, hipStream_t stream)
 {
     const bool plain = plan.list_mode == 0 && plan.n_pass == 1;
     if (m.tail != 0.0)
-        return plain ? launch_nt_tail<NT, HU, true, true>(m, tv, plan, out_ll, sub_list, stream)
-                     : launch_nt_tail<NT, HU, true, false>(m, tv, plan, out_ll, sub_list, stream);
-    return plain ? launch_nt_tail<NT, HU, false, true>(m, tv, plan, out_ll, sub_list, stream)
-                 : launch_nt_tail<NT, HU, false, false>(m, tv, plan, out_ll, sub_list, stream);
+        return plain ? launch_ll_factored_variant<NT, true, true>(m, tv, plan, out_ll, sub_list, stream)
+                     : launch_ll_factored_variant<NT, true, false>(m, tv, plan, out_ll, sub_list, stream);
+    return plain ? launch_ll_factored_variant<NT, false, true>(m, tv, plan, out_ll, sub_list, stream)
+                 : launch_ll_factored_variant<NT, false, false>(m, tv, plan, out_ll, sub_list, stream);
 }
 
 } // namespace
@@ -891,10 +996,11 @@ hipError_t launch_ll_factored(const DevModel &m, const TileView &tv, const Facto
     if (m.kind != 1 || plan.n_columns > plan.n_threads || 8 * plan.n_pass < m.n_err)
         return hipErrorInvalidValue;
     if (plan.n_threads == 256 && plan.half_units == 3)
-        return launch_nt<256, 3>(m, tv, plan, out_ll, sub_list, stream);
+        return launch_nt<256>(m, tv, plan, out_ll, sub_list, stream);
     if (plan.n_threads == 512 && plan.half_units == 3)
-        return launch_nt<512, 3>(m, tv, plan, out_ll, sub_list, stream);
+        return launch_nt<512>(m, tv, plan, out_ll, sub_list, stream);
     return hipErrorInvalidValue;
 }
+#endif // COVEST_FACTORED_VARIANT
 
 } // namespace covest

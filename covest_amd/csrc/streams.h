@@ -156,6 +156,27 @@ struct StreamSet {
         return n_live;
     }
 
+    // At a RUN START (every stream is re-anchored there: what is left of the run before means nothing) -- the test of
+    // enter_tile for "gone", on its own: a stream whose log-term is outside the window over the whole tile, in every
+    // lane, and past its mode cannot come on again.  Lets a caller see BEFORE it walks the tile that only the first
+    // stream is left (ll_basic.hip: the closed form starts there).  Changes nothing but `gone`.
+    __device__ __forceinline__ void retire_at_run_start(double km1, double klast, double lgam_prev, double lgam_last)
+    {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if ((gone >> s) & 1u)
+                continue;
+            const double lx = an.lx(s), c = an.c(s);
+            const double a0 = fma(km1, lx, c - lgam_prev);
+            const double a1 = fma(klast, lx, c - lgam_last);
+            const bool in_window = fmax(a0, a1) > kWindowLn;
+            if (!__any(in_window || !(km1 >= x[s]))) {
+                gone |= 1u << s;
+                v[s] = 0.0; // (what enter_tile does at a run start before it looks: a gone stream is skipped there)
+            }
+        }
+    }
+
     // Advance every stream by one key and return the sum of the scaled terms.  (Splitting
     // the sum into two interleaved chains was measured: no gain on gfx950.)
     __device__ __forceinline__ double step()

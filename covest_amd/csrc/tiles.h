@@ -24,7 +24,7 @@ constexpr double kWindowLn = -760.0; // terms below e^-760 are 0 in double
 struct TileView {
     int32_t n_tiles;
     int32_t n_items;
-    // raw buffers behind the views below: [4*nt + 2*nt*32 + ni*32] doubles, [3*nt + 3*ni + 32*nt] int32.  The fast
+    // raw buffers behind the views below: [4*nt + 2*nt*32 + 3*ni*32 + ni + 5*(nt+1) + 2] doubles, [3*nt + 3*ni + 32*nt] int32.  The fast
     // kernels take these two as separate `const __restrict__` kernel arguments and rebuild the
     // view from them (tile_view_from): only then does hipcc know the table is read-only and
     // never aliased, and fetches the wave-uniform entries with s_load into SGPRs.
@@ -41,6 +41,19 @@ struct TileView {
                                //   recurrence walks through) and padding: their p_j is exactly 0, so they add nothing to sp_j
     const double *cnt;         // [n_tiles][32] h_j (0 for padding and filler keys)
     const double *item_cnt;    // [n_items][32] the counts of an item's 32 rows: its tile's for a plain item, 0 for a sum item
+    // K-factored keeps the rows of a PLAIN item UNSCALED (ll_factored.hip: G' = sum of the streams' scaled terms,
+    // p_j = P'_j * scal_j): the scale enters the logs as a constant, log p_j = log(P'_j 2^-SC) + ln((k0-1)!/(k0+b)!)
+    const double *item_scal;   // [n_items][32] scal of the row (0: filler / padding); 1 for the rows of a sum item (they ARE scaled)
+    const double *item_iscal;  // [n_items][32] 1 / scal of a row WITH a count (0: filler / padding / zero count / sum item): p_clamp in the row's units
+    const double *item_lconst; // [n_items] sum over the item's rows of h_j ln((k0-1)!/(k0+b)!) (long double on the host)
+    // K-basic's closed form over the tiles t .. n_tiles - 1 (ll_basic.hip: one stream left, no tail): sums over their
+    // COUNTED keys, long double on the host
+    const double *suf_h;       // [n_tiles + 1] sum h_j
+    const double *suf_jh;      // [n_tiles + 1] sum j h_j
+    const double *suf_lgh;     // [n_tiles + 1] sum h_j ln j!
+    const double *suf_first;   // [n_tiles + 1] the first counted key of those tiles (0: none) and
+    const double *suf_first_lg; // [n_tiles + 1]   its ln j!
+    const double *last_key;    // [2] the last counted key of the table and its ln j!
     const int32_t *item_first; // [n_items] first tile of the item
     const int32_t *item_ntiles; // [n_items] 1 for a plain item, 1..32 (rows in use) for a sum item
     const int32_t *item_sum;   // [n_items] 1 = sum item
@@ -63,6 +76,15 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, int32_t ni, const
     tv.scal = dbl + 4 * (int64_t)nt;
     tv.cnt = tv.scal + (int64_t)nt * kTileBins;
     tv.item_cnt = tv.cnt + (int64_t)nt * kTileBins;
+    tv.item_scal = tv.item_cnt + (int64_t)ni * kTileBins;
+    tv.item_iscal = tv.item_scal + (int64_t)ni * kTileBins;
+    tv.item_lconst = tv.item_iscal + (int64_t)ni * kTileBins;
+    tv.suf_h = tv.item_lconst + ni;
+    tv.suf_jh = tv.suf_h + (nt + 1);
+    tv.suf_lgh = tv.suf_jh + (nt + 1);
+    tv.suf_first = tv.suf_lgh + (nt + 1);
+    tv.suf_first_lg = tv.suf_first + (nt + 1);
+    tv.last_key = tv.suf_first_lg + (nt + 1);
     tv.n_bins = ints;
     tv.run_start = ints + nt;
     tv.all_zero = ints + 2 * (int64_t)nt;
@@ -119,7 +141,7 @@ struct FactoredPlan {
                                    //   unit's end are masked by the T cut-off)
     const int32_t *unit_cont;      // 1 = this slot continues the unit of the slot before it
     const int32_t *unit_nsh;       // SHARED steps of the slot's unit (0: none), see below
-    const double *unit_rho;        // [slots][2] (1-q)^-4 and (1-q)^-16 of the unit's q-tile (units with unit_nsh > 0)
+    const double *unit_rho;        // [slots][4] units with unit_nsh > 0: {(1-q)^16, unused, (1-q)^4, (1-q)^(-4 nsh)} of the unit's q-tile
     const double *piece_w;         // [slots][64 lanes][2] b_o at the piece's first step (masked by the column's
                                    //   cut-off) and at its second (o = 1 + 4 step + lane/16, column lane%16), libm
                                    //   pow on the host; units with unit_nsh > 0: second = the first step AFTER the
@@ -128,9 +150,9 @@ struct FactoredPlan {
     // (the host sorts the product that way when it pays): then b_o = beta_col (1-q)^(o-3) for o >= 3, and for
     // the copy numbers below EVERY column's cut-off the contraction  sum_o G[key][o] b_o(col)  is beta_col times a
     // sum that does not depend on the column.  Steps 1 .. unit_nsh of such a unit (o = 5 .. 4 + 4 nsh, all below
-    // the tile's smallest T) are therefore summed ONCE per key, on the vector unit (Horner in (1-q)^-4, lane =
-    // (key, o mod 4), weights relative to the first step after them), and enter the accumulator through one MFMA whose
-    // B is b_o of that step; step 0 (o = 1 .. 4, the weights that are not geometric) and the steps after the shared
+    // the tile's smallest T) are therefore summed ONCE per key, on the vector unit (Horner in (1-q)^4, lane =
+    // (key, o mod 4), weights relative to the FIRST shared step: they only fall), and enter the accumulator through one
+    // MFMA whose B is b_o of that step; step 0 (o = 1 .. 4, the weights that are not geometric) and the steps after the shared
     // ones (where the columns' cut-offs differ) are MFMA steps as before.  unit_len counts step 0 and the steps after
     // the shared ones.
     const int32_t *qtile_nsteps;   // [n_qtiles] ceil((max T in tile - 1) / 4): MFMA steps of the tile

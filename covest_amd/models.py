@@ -24,11 +24,17 @@ MODEL_CLASS_SUFFIX = 'Model'
 _DP = ctypes.POINTER(ctypes.c_double)
 
 
+_COMB_TABLES = {}
+
+
 def _comb_table(k):
     # covest/models.py:25 -- scipy.misc.comb of the reference's era is today's
-    # scipy.special.comb (float result, exact=False).
-    from scipy.special import comb
-    return [comb(k, s) * (3 ** s) for s in range(k + 1)]
+    # scipy.special.comb (float result, exact=False).  One table per k and process: the k + 1 scipy calls cost
+    # 0.3 ms, which a model built per search (time-to-argmin) should pay once.
+    if k not in _COMB_TABLES:
+        from scipy.special import comb
+        _COMB_TABLES[k] = tuple(comb(k, s) * (3 ** s) for s in range(k + 1))
+    return list(_COMB_TABLES[k])
 
 
 def _as_dp(a):
@@ -47,7 +53,18 @@ class BasicModel:
         self.bounds = ((0.01, max_cov), (0, 0.5))
         self.defaults = (1, self._default_param(1))
         self.comb = _comb_table(k)
-        self.hist = hist
+        # `hist`: the reference's dict {j: count} (covest/models.py:26) -- or, for callers that hold the histogram as
+        # arrays already (a 10 000-key dict costs 0.3 ms to walk, a third of a warm C3 search), a pair
+        # (keys, counts) of equal-length sequences in dict order; `self.hist` then builds the dict on first use
+        if isinstance(hist, tuple) and len(hist) == 2 and not isinstance(hist[0], (int, float)):
+            self._keys = np.ascontiguousarray(hist[0], dtype=np.int32)
+            self._counts = np.ascontiguousarray(hist[1], dtype=np.float64)
+            if self._keys.shape != self._counts.shape or self._keys.ndim != 1:
+                raise ValueError('hist as arrays: (keys, counts) of one length')
+            self._hist = None
+        else:
+            self._keys = self._counts = None
+            self._hist = hist
         self.tail = tail
         if max_error is None:
             self.max_error = self.k + 1
@@ -57,6 +74,18 @@ class BasicModel:
         self._handle = None
 
     # ------------------------------------------------------------------ surface
+    @property
+    def hist(self):
+        if self._hist is None:
+            self._hist = {int(j): (int(v) if float(v).is_integer() else float(v))
+                          for j, v in zip(self._keys.tolist(), self._counts.tolist())}
+        return self._hist
+
+    @hist.setter
+    def hist(self, value):
+        self._hist = value
+        self._keys = self._counts = None
+
     @classmethod
     def short_name(cls):
         name = cls.__name__
@@ -104,8 +133,12 @@ class BasicModel:
         return None
 
     def _desc(self):
-        keys = np.asarray(list(self.hist.keys()), dtype=np.int32)
-        counts = np.asarray([float(v) for v in self.hist.values()], dtype=np.float64)
+        if self._keys is not None:
+            keys, counts = self._keys, self._counts
+        else:
+            n = len(self._hist)
+            keys = np.fromiter(self._hist.keys(), dtype=np.int32, count=n)  # (dict order: covest/models.py:92-97 walks it)
+            counts = np.fromiter(self._hist.values(), dtype=np.float64, count=n)
         comb = np.asarray(self.comb[:self.max_error], dtype=np.float64)
         d = _capi.ModelDesc()
         d.kind = self._kind
@@ -258,7 +291,7 @@ class RepeatsModel(BasicModel):
         thr = self.threshold
         _capi.check(_capi.lib().covest_threshold_o(
             len(q), _as_dp(q), 0.0 if thr is None else float(thr), 0 if thr is None else 1,
-            int(max(self.hist)), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))),
+            int(self._keys.max()) if self._keys is not None else int(max(self.hist)), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))),
             "covest_threshold_o")
         return out
 
