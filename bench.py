@@ -673,6 +673,10 @@ def main():
     on_device = world > 1 and args.backend == "nccl"  # the exchange consumes the arg-min kernel's output in HBM
 
     # ---- time-to-argmin: host axes + histogram -> global (min, index) on the host ----
+    # (the HIP runtime creates its queue and staging buffers on a process's first device operation, 80 ms that are
+    # not this library's: one torch fill kernel and one 8-byte copy before the clock starts.  What is left in the
+    # first call is the library's own first use: its code objects, its first allocations, the ln j! table.)
+    torch.zeros(8, device=device).cpu()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     model = cls(21, 100, hist, 0, max_error=8, device=local_rank)

@@ -634,6 +634,10 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     // (the assignment fixes the order of a point's sums: the shipped library takes the constants of tiles.h, only a
     // diagnostic build -- tiles.h -- lets the environment override them for tuning sweeps)
     int unit_overhead = kUnitOverhead, build_cost = kBuildCost, shared_div = kSharedStepsPerMfma;
+    // (with a tail an item may stand for up to 32 count-less tiles, tiles.h: the builders walk every one of them
+    // while the contraction sees one item -- charge them for the tiles an item holds on average)
+    if (m->has_tiles && m->tv.n_items > 0)
+        build_cost = (int)std::lround((double)kBuildCost * (double)m->tv.n_tiles / (double)m->tv.n_items);
 #ifdef COVEST_DIAG
     if (const char *v = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD"))
         unit_overhead = std::atoi(v);
@@ -2051,6 +2055,8 @@ struct covest_kmer {
     int device = 0;
     int k = 20;
     int canonical = 0;
+    int wide = 0;          // 0: k <= 31, `table`; else the words per key of `wtable` (kmer_wide.hip)
+    KmerWideTable wtable{};
     KmerTable table{};
     DevBuf slots, flag, stats, hist, ws_bases, ws_offsets;
     std::mutex lock;
@@ -2073,6 +2079,22 @@ int kmer_alloc_table(covest_kmer *c, int64_t min_slots, KmerTable &t, DevBuf &sl
     return COVEST_OK;
 }
 
+int kmer_alloc_wide(covest_kmer *c, int64_t min_slots, KmerWideTable &t, DevBuf &slots)
+{
+    int lg = 10;
+    while (((int64_t)1 << lg) < min_slots && lg < 38)
+        ++lg;
+    t.w = c->wide;
+    t.stride = 2 * c->wide; // 1 + w words, rounded up to a power of two
+    t.k = c->k;
+    t.log2_slots = lg;
+    t.mask = ((unsigned long long)1 << lg) - 1;
+    HIP_TRY(slots.reserve(((size_t)1 << lg) * (size_t)t.stride * sizeof(unsigned long long)));
+    t.words = slots.as<unsigned long long>();
+    HIP_TRY(launch_kmer_wide_clear(t, nullptr));
+    return COVEST_OK;
+}
+
 int kmer_check_overflow(covest_kmer *c)
 {
     int flag = 0;
@@ -2091,8 +2113,8 @@ int covest_kmer_create(int32_t k, int32_t canonical, int64_t min_slots, int32_t 
     if (!out)
         return fail(COVEST_E_INVALID, "covest_kmer_create: null argument");
     *out = nullptr;
-    if (k < 1 || k > 31)
-        return fail(COVEST_E_INVALID, "covest_kmer_create: k must be in 1..31 (2k bits + an empty marker in 64)");
+    if (k < 1 || k > 255)
+        return fail(COVEST_E_INVALID, "covest_kmer_create: k must be in 1..255 (keys of up to eight 64-bit words)");
     {
         const int drc = resolve_device(device, "covest_kmer_create", &device);
         if (drc != COVEST_OK)
@@ -2104,11 +2126,12 @@ int covest_kmer_create(int32_t k, int32_t canonical, int64_t min_slots, int32_t 
     c->device = device;
     c->k = k;
     c->canonical = canonical != 0;
+    c->wide = k <= 31 ? 0 : k <= 63 ? 2 : k <= 127 ? 4 : 8;
     DeviceGuard dev_guard(device);
     hipError_t e = hipSuccess;
     int rc = dev_guard.status();
     if (rc == COVEST_OK)
-        rc = kmer_alloc_table(c, min_slots, c->table, c->slots);
+        rc = c->wide ? kmer_alloc_wide(c, min_slots, c->wtable, c->slots) : kmer_alloc_table(c, min_slots, c->table, c->slots);
     if (rc == COVEST_OK) {
         e = c->flag.reserve(sizeof(int));
         if (e == hipSuccess)
@@ -2140,7 +2163,10 @@ void covest_kmer_destroy(covest_kmer *c)
     delete c;
 }
 
-int64_t covest_kmer_slots(const covest_kmer *c) { return c ? (int64_t)(c->table.mask + 1) : COVEST_E_INVALID; }
+int64_t covest_kmer_slots(const covest_kmer *c)
+{
+    return c ? (int64_t)((c->wide ? c->wtable.mask : c->table.mask) + 1) : COVEST_E_INVALID;
+}
 
 int covest_kmer_clear(covest_kmer *c, void *stream)
 {
@@ -2150,7 +2176,10 @@ int covest_kmer_clear(covest_kmer *c, void *stream)
     DeviceGuard dev_guard(c->device);
     if (dev_guard.status() != COVEST_OK)
         return dev_guard.status();
-    HIP_TRY(launch_kmer_fill_empty(c->table, static_cast<hipStream_t>(stream)));
+    if (c->wide)
+        HIP_TRY(launch_kmer_wide_clear(c->wtable, static_cast<hipStream_t>(stream)));
+    else
+        HIP_TRY(launch_kmer_fill_empty(c->table, static_cast<hipStream_t>(stream)));
     HIP_TRY(hipMemsetAsync(c->flag.ptr, 0, sizeof(int), static_cast<hipStream_t>(stream)));
     return COVEST_OK;
 }
@@ -2160,7 +2189,7 @@ int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
     if (!c)
         return fail(COVEST_E_INVALID, "covest_kmer_reserve: null counter");
     std::lock_guard<std::mutex> guard(c->lock);
-    if ((int64_t)(c->table.mask + 1) >= min_slots)
+    if ((int64_t)((c->wide ? c->wtable.mask : c->table.mask) + 1) >= min_slots)
         return COVEST_OK;
     DeviceGuard dev_guard(c->device);
     if (dev_guard.status() != COVEST_OK)
@@ -2176,11 +2205,13 @@ int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
             return rc;
     }
     KmerTable bigger{};
+    KmerWideTable wbigger{};
     DevBuf slots;
-    int rc = kmer_alloc_table(c, min_slots, bigger, slots);
+    int rc = c->wide ? kmer_alloc_wide(c, min_slots, wbigger, slots) : kmer_alloc_table(c, min_slots, bigger, slots);
     hipError_t e = hipSuccess;
     if (rc == COVEST_OK) { // (the flag is known to be clean here: whatever it holds afterwards is the rehash's)
-        e = launch_kmer_rehash(c->table, bigger, c->flag.as<int>(), nullptr);
+        e = c->wide ? launch_kmer_wide_rehash(c->wtable, wbigger, c->flag.as<int>(), nullptr)
+                    : launch_kmer_rehash(c->table, bigger, c->flag.as<int>(), nullptr);
         if (e == hipSuccess)
             e = hipDeviceSynchronize();
         if (e != hipSuccess)
@@ -2193,6 +2224,7 @@ int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
     c->slots.release();
     c->slots = slots;
     c->table = bigger;
+    c->wtable = wbigger;
     return kmer_check_overflow(c);
 }
 
@@ -2205,8 +2237,12 @@ int covest_kmer_add_device(covest_kmer *c, const uint8_t *d_bases, const int64_t
     DeviceGuard dev_guard(c->device);
     if (dev_guard.status() != COVEST_OK)
         return dev_guard.status();
-    HIP_TRY(launch_kmer_count(d_bases, d_offsets, n_reads, read_len, c->k, c->canonical, c->table,
-                              c->flag.as<int>(), static_cast<hipStream_t>(stream)));
+    if (c->wide)
+        HIP_TRY(launch_kmer_wide_count(d_bases, d_offsets, n_reads, read_len, c->canonical, c->wtable, c->flag.as<int>(),
+                                       static_cast<hipStream_t>(stream)));
+    else
+        HIP_TRY(launch_kmer_count(d_bases, d_offsets, n_reads, read_len, c->k, c->canonical, c->table,
+                                  c->flag.as<int>(), static_cast<hipStream_t>(stream)));
     return COVEST_OK;
 }
 
@@ -2255,7 +2291,10 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
         return rc;
     unsigned long long stats[2] = {0, 0};
     HIP_TRY(hipMemset(c->stats.ptr, 0, sizeof(stats)));
-    HIP_TRY(launch_kmer_stats(c->table, c->stats.as<unsigned long long>(), nullptr));
+    if (c->wide)
+        HIP_TRY(launch_kmer_wide_stats(c->wtable, c->stats.as<unsigned long long>(), nullptr));
+    else
+        HIP_TRY(launch_kmer_stats(c->table, c->stats.as<unsigned long long>(), nullptr));
     HIP_TRY(hipMemcpy(stats, c->stats.ptr, sizeof(stats), hipMemcpyDeviceToHost));
     const int64_t need = (int64_t)stats[0] + 1; // index 0 .. max count (bin/kmer_hist.py:64)
     if (needed_len)
@@ -2268,7 +2307,10 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
         return fail(COVEST_E_INVALID, "covest_kmer_histogram: output shorter than max count + 1");
     HIP_TRY(c->hist.reserve((size_t)need * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->hist.ptr, 0, (size_t)need * sizeof(unsigned long long)));
-    HIP_TRY(launch_kmer_histogram(c->table, c->hist.as<unsigned long long>(), (unsigned long long)need, nullptr));
+    if (c->wide)
+        HIP_TRY(launch_kmer_wide_histogram(c->wtable, c->hist.as<unsigned long long>(), (unsigned long long)need, nullptr));
+    else
+        HIP_TRY(launch_kmer_histogram(c->table, c->hist.as<unsigned long long>(), (unsigned long long)need, nullptr));
     HIP_TRY(hipMemcpy(out, c->hist.ptr, (size_t)need * sizeof(int64_t), hipMemcpyDeviceToHost));
     return COVEST_OK;
 }

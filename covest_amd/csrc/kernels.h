@@ -84,6 +84,23 @@ hipError_t launch_kmer_stats(const KmerTable &t, unsigned long long *stats, hipS
 hipError_t launch_kmer_histogram(const KmerTable &t, unsigned long long *hist, unsigned long long hist_len,
                                  hipStream_t stream);
 
+// ---- K-kmer for k > 31 (kmer_wide.hip): keys of w = 2, 4 or 8 words, slots of `stride` words {state/count, key[w]} ----
+struct KmerWideTable {
+    unsigned long long *words;
+    unsigned long long mask; // slots - 1
+    int log2_slots;
+    int k;
+    int w;      // 64-bit words per key
+    int stride; // words per slot: 4, 8 or 16
+};
+hipError_t launch_kmer_wide_clear(const KmerWideTable &t, hipStream_t stream);
+hipError_t launch_kmer_wide_count(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, int64_t fixed_len,
+                                  int canonical, const KmerWideTable &t, int *overflow, hipStream_t stream);
+hipError_t launch_kmer_wide_rehash(const KmerWideTable &src, const KmerWideTable &dst, int *overflow, hipStream_t stream);
+hipError_t launch_kmer_wide_stats(const KmerWideTable &t, unsigned long long *stats, hipStream_t stream);
+hipError_t launch_kmer_wide_histogram(const KmerWideTable &t, unsigned long long *hist, unsigned long long hist_len,
+                                      hipStream_t stream);
+
 // ---- K-thin: expected histogram after down-sampling by `factor` (thin_hist.hip), SURVEY 8(f) row F3 ----
 struct ThinSource {
     int32_t i;     // source count

@@ -361,12 +361,22 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
         }
         double gsum = 0.0;
+        // two halves of 16 keys, each half's scales fetched into scalar registers up front (one s_load_dwordx16 pair,
+        // as K-basic does): fetched pair by pair right before their use, every second key waited for the scalar cache
 #pragma unroll
-        for (int b = 0; b < kTileBins; b += 2) {
-            double g1, g2;
-            st.template step2n<N>(xx, g1, g2);
-            gsum = fma(g1, scal[b], gsum);
-            gsum = fma(g2, scal[b + 1], gsum);
+        for (int half = 0; half < 2; ++half) {
+            double sc[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                sc[b] = scal[16 * half + b];
+            asm volatile("" ::: "memory"); // (keeps the loads above the half's arithmetic)
+#pragma unroll
+            for (int b = 0; b < 16; b += 2) {
+                double g1, g2;
+                st.template step2n<N>(xx, g1, g2);
+                gsum = fma(g1, sc[b], gsum);
+                gsum = fma(g2, sc[b + 1], gsum);
+            }
         }
         st.template leave_tile_n<N>(renorm);
         return gsum;

@@ -109,7 +109,7 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, int32_t ni, const
 // on their number (no per-slot branches inside it).
 constexpr int kMaxUnits = 6;       // accumulator slots per wave
 constexpr int kHalfUnits = 3;      // (kept for the 256-thread capacity rule: 4 waves x 6 slots)
-constexpr int kBuildCost = 36;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3)
+constexpr int kBuildCost = 18;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3; 36 before round 3 took the scales and the scalar-load stalls out of phase A)
 constexpr int kListSegments = 8;   // key segments of a point-list evaluation (list mode): latency of ONE point
 constexpr int kMinPieceSteps = 6;  // pieces are not made shorter than this
 constexpr int kSharedStepsPerMfma = 5; // cost of the shared steps in the assignment: this many weigh one MFMA step

@@ -11,7 +11,8 @@ Differences from the reference, all deliberate and listed in DESIGN.md:
   * `main` passes its `k` on (the reference's main ignores -k and always counts 20-mers, :81);
   * `canonical=True` (jellyfish -C: a k-mer and its reverse complement are one key) is offered
     because BASELINE.json's config 5 asks for it; the default is the reference's forward strand;
-  * k <= 31 (2k bits and an empty marker in one 64-bit word); counts are 64-bit.
+  * k <= 255: k <= 31 packs key and empty marker into one 64-bit word (kmer_count.hip, the fast path); larger k takes
+    keys of 2, 4 or 8 words (kmer_wide.hip) -- the reference's Python integers have no limit; counts are 64-bit.
 """
 import ctypes
 import random

@@ -27,13 +27,33 @@ _DP = ctypes.POINTER(ctypes.c_double)
 _COMB_TABLES = {}
 
 
+def _comb_float(n, k):
+    """scipy.special.comb(n, k) (exact=False) -- what the reference's `comb` returns today (covest/models.py:10,25).
+    For integer arguments with min(k, n - k) < 20, which is every entry a model with k <= 39 has and the first 20 of
+    any model, scipy's routine (xsf binom) is a short product loop in double precision; restated here so that a model
+    does not import scipy.special -- 0.2 to 0.7 s, most of a first search's time-to-argmin.  Bit-equal to scipy for
+    every n < 200 (checked when this was written; tests/test_host_logic.py keeps checking).  Other arguments go to
+    scipy itself."""
+    kx = k
+    if n > 0 and kx > n // 2:
+        kx = n - kx
+    if 0 <= kx < 20:
+        num, den = 1.0, 1.0
+        for i in range(1, kx + 1):
+            num *= i + n - kx
+            den *= i
+            if abs(num) > 1e50:
+                num /= den
+                den = 1.0
+        return num / den
+    from scipy.special import comb
+    return float(comb(n, k))
+
+
 def _comb_table(k):
-    # covest/models.py:25 -- scipy.misc.comb of the reference's era is today's
-    # scipy.special.comb (float result, exact=False).  One table per k and process: the k + 1 scipy calls cost
-    # 0.3 ms, which a model built per search (time-to-argmin) should pay once.
+    # covest/models.py:25 -- comb(k, s) * 3 ** s for s = 0 .. k; one table per k and process
     if k not in _COMB_TABLES:
-        from scipy.special import comb
-        _COMB_TABLES[k] = tuple(comb(k, s) * (3 ** s) for s in range(k + 1))
+        _COMB_TABLES[k] = tuple(_comb_float(k, s) * (3 ** s) for s in range(k + 1))
     return list(_COMB_TABLES[k])
 
 

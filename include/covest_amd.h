@@ -180,7 +180,8 @@ int covest_grid_kernel_ms(covest_grid *g, double *total_ms, int64_t *launches);
 
 /* ---- k-mer abundance histogram: bin/kmer_hist.py (BASELINE config 5) ----
  * The counter is the `counts` dict of compute_counts (bin/kmer_hist.py:34-41) as an
- * open-addressing hash table in HBM.  k <= 31.  canonical != 0 counts a k-mer and its reverse
+ * open-addressing hash table in HBM.  k <= 255 (the reference's Python integers have no limit: k <= 31 is the fast
+ * path, one 64-bit word per key; 32..63, ..127, ..255 take keys of 2, 4, 8 words).  canonical != 0 counts a k-mer and its reverse
  * complement as one key (jellyfish -C; NOT reference behaviour, the reference is forward-strand). */
 typedef struct covest_kmer covest_kmer; /* opaque */
 

@@ -107,3 +107,14 @@ def test_initial_grid_shape():
     assert initial_grid([1.0, 0.1], count=0) == []
     pts = initial_grid([10.0, 0.05], count=3, fix=[None, 0.07])
     assert all(p[1] == 0.07 for p in pts[1:])
+
+
+def test_comb_table_is_scipys():
+    """covest_amd.models builds comb(k, s) * 3 ** s (covest/models.py:25) without importing scipy.special (its import
+    is most of a first search's time); the numbers must be scipy's, bit for bit."""
+    from scipy.special import comb
+    from covest_amd.models import _comb_float, _comb_table
+    for n in list(range(0, 70)) + [100, 150, 199]:
+        for k in range(0, n + 1):
+            assert _comb_float(n, k) == float(comb(n, k)), (n, k)
+    assert _comb_table(21) == [comb(21, s) * (3 ** s) for s in range(22)]

@@ -20,8 +20,15 @@ done
 timeout -k 10 100 python3 bench.py --workload c1 > "$out/bench_c1.json" 2> "$out/bench_c1.err"
 timeout -k 10 200 python3 bench.py --workload og --steps 5 > "$out/bench_og.json" 2> "$out/bench_og.err"
 timeout -k 10 200 python3 bench.py --scaling strong --steps 5 --warmup 1 --cpu-budget 0 > "$out/bench_c3_strong_1gpu.json" 2> "$out/bench_strong.err"
-timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --backend gloo --share-gpu --scaling strong --steps 5 --warmup 1 --cpu-budget 0 2> "$out/bench_2rank.err" | tail -1 > "$out/bench_c3_strong_2rank_gloo_rehearsal.json"
-COVEST_FACTORED_DIAG=1 timeout -k 10 100 python3 tools/factored_diag.py > "$out/c3_factored_phase_stamps.txt" 2>&1
+# the driver's N > 1 command line, rehearsed with two ranks on the one card over gloo: the weak step AND variants.strong
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --backend gloo --share-gpu --steps 5 --warmup 1 --cpu-budget 0 2> "$out/bench_2rank.err" | tail -1 > "$out/bench_c3_2rank_gloo_rehearsal.json"
+# phase stamps and instruction counts by phase: the DIAGNOSTIC build only (the shipped library has no such switches)
+if [ -f tools/bin/libcovest_amd_diag.so ]; then
+  COVEST_AMD_LIB=$PWD/tools/bin/libcovest_amd_diag.so COVEST_FACTORED_DIAG=1 timeout -k 10 100 python3 tools/factored_diag.py > "$out/c3_factored_phase_stamps.txt" 2>&1
+  COVEST_AMD_LIB=$PWD/tools/bin/libcovest_amd_diag.so bash tools/phase_insts.sh "$out/phase_insts" > "$out/c3_factored_insts_by_phase.txt" 2>&1
+  rm -rf "$out/phase_insts"
+fi
+timeout -k 10 100 python3 tools/time_host.py > "$out/time_to_argmin_split.txt" 2>&1
 # the rows either side of the path, the shapes that used to fall back, the microbenchmarks behind DESIGN's rooflines
 timeout -k 10 300 python3 bench.py --workload c5 --kmer-gbp 1 --steps 5 --warmup 1 > "$out/bench_c5_1gbp.json" 2> "$out/bench_c5.err"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c5" -o c5 -- python3 bench.py --workload c5 --kmer-gbp 1 --steps 3 --warmup 1 --cpu-budget 0 > /dev/null 2> "$out/trace_c5.err"
