@@ -197,9 +197,6 @@ def cpu_baseline(kind, hist, axes, budget_s, seed=20240521):
     }
 
 
-SCATTERED_PAIRS_PER_S = 1.96e10  # tools/microbench_atomics.hip, row C, 16 GB table (profiles/r02_microbench_atomics.txt)
-
-
 def kmer_from_file(reads, n_reads, read_len, k, counts, cap_reads=10_000_000):
     """Config 5 'from a FASTA file': the first `cap_reads` reads of the same synthetic set written to a FASTA file on
     local disk (untimed), then timed end to end -- the C++ reader (parse + preprocess), covest_kmer_add (H2D copy +
@@ -261,16 +258,25 @@ def bench_kmer(args):
         reads[a * read_len:b * read_len] = r.reshape(-1)
     del genome
     n_kmers = n_reads * (read_len - k + 1)
-    # table sized for the distinct k-mers (genome + ~21 new k-mers per substitution), 3x headroom
+    # The step: count every k-mer of the resident reads and make the count-of-counts histogram -- main's loop,
+    # bin/kmer_hist.py:77-89.  Round 3: through the PARTITIONED path (covest_kmer_count_reads_device, kmer_bulk.hip:
+    # minimizer buckets of super-k-mer records in HBM, counted bucket by bucket in LDS); --kmer-path table: the
+    # open-addressing table in HBM of rounds 1-2 (clear + one scattered load/atomic pair per occurrence + a sweep).
     expected_distinct = genome_len + int(0.01 * n_reads * read_len * k)
-    counts = kh.KmerCounts(k, canonical=True, min_slots=3 * expected_distinct)
+    use_table = args.kmer_path == "table"
+    counts = kh.KmerCounts(k, canonical=True, min_slots=3 * expected_distinct if use_table else 1 << 20)
     stream = torch.cuda.current_stream().cuda_stream
+    paths = set()
 
     def step(timers=None):
-        counts.clear(stream)
         if timers:
             timers[0].record()
-        counts.add_device(reads.data_ptr(), n_reads, read_len, stream=stream, reserve=False)
+        if use_table:
+            counts.clear(stream)
+            counts.add_device(reads.data_ptr(), n_reads, read_len, stream=stream, reserve=False)
+            paths.add("table")
+        else:
+            paths.add(counts.count_reads_device(reads.data_ptr(), n_reads, read_len, stream=stream))
         if timers:
             timers[1].record()
         return counts.histogram()
@@ -289,29 +295,32 @@ def bench_kmer(args):
     counted = sum(i * v for i, v in enumerate(hist))  # every window lands in exactly one bin
     if counted != n_kmers or sum(hist) != distinct:
         raise SystemExit("k-mer histogram inconsistent: %d windows counted, %d expected" % (counted, n_kmers))
-    alg_bytes = 16.0 * n_kmers + 1.0 * n_reads * read_len  # one 16-byte {key, count} slot per k-mer, each base once
+    partitioned = paths == {"partitioned"}
+    # algorithmic HBM bytes: every base once; table path: one 16-byte {key, count} slot per occurrence; partitioned
+    # path: one 16-byte record per run of ~(w + 1) / 2 = 6 windows, written once and read once
+    alg_bytes = 1.0 * n_reads * read_len + (2.0 * 16.0 * n_kmers / 6.0 if partitioned else 16.0 * n_kmers)
     out = {
         "metric": "k-mers/s, canonical k=21 abundance histogram (bin/kmer_hist.py path)",
         "value": n_kmers * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "C5: canonical 21-mers of %d synthetic 100-bp reads (%.2f Gbp, 40x of a random "
-                               "genome, 1%% substitutions), table of %d slots" % (n_reads, n_reads * read_len / 1e9,
-                                                                                 counts.slots),
-                   "kernel": "kmer_count", "distinct_kmers": distinct, "windows_counted": counted,
+                               "genome, 1%% substitutions)" % (n_reads, n_reads * read_len / 1e9),
+                   "kernel": "kmer_scatter + kmer_bucket_count (partitioned)" if partitioned else "kmer_count (table of %d slots)" % counts.slots,
+                   "path": sorted(paths), "why_not_partitioned": getattr(counts, "why_not_partitioned", None),
+                   "distinct_kmers": distinct, "windows_counted": counted,
                    "hist_head": hist[:6], "hist_peak": int(np.argmax(hist[5:]) + 5) if len(hist) > 6 else None},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "kmer_count_kernel", "kernel_ms_avg": 1e3 * kernel_s,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "scattered 8-byte load/CAS + 8-byte atomic add (same line) per k-mer: the binding rate is the "
-                             "random-atomic rate of the memory side, far below the streaming HBM roof",
-                     # the roof that binds: scattered {8-byte load + 64-bit atomic add in the same 16-byte slot} pairs over
-                     # a 16 GB table, measured on this chip by tools/microbench_atomics.hip (profiles/
-                     # r02_microbench_atomics.txt, row C): the rate does not depend on the table's size, 2 MB included
-                     "scattered_ops": {"achieved": n_kmers / kernel_s, "peak": SCATTERED_PAIRS_PER_S,
-                                       "unit": "load+add pairs/s", "frac": n_kmers / kernel_s / SCATTERED_PAIRS_PER_S}},
+                     "kernel": "kmer_scatter_fixed_kernel + kmer_bucket_count_kernel" if partitioned else "kmer_count_fixed_kernel",
+                     "kernel_ms_avg": 1e3 * kernel_s, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": ("what binds the partitioned path is not bandwidth: pass 1 pays one returning atomic on a bucket "
+                              "cursor per record (k-mers / 6) and ~100 integer instructions per window for the minimizer, pass 2 "
+                              "one LDS compare-and-swap and one LDS add per k-mer") if partitioned else
+                             ("scattered 8-byte load/CAS + 8-byte atomic add (same line) per k-mer: the memory side retires "
+                              "about 2e10 such pairs a second whatever the table's size (tools/microbench_atomics.hip)")},
     }
+    counts.clear(stream)  # (from_file counts through the table: an ordinary counter again)
     out["config"]["from_file"] = kmer_from_file(reads, n_reads, read_len, k, counts)
     if args.cpu_budget > 0:
         from oracle import kmer_oracle as ko
@@ -627,6 +636,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5", "f2", "f3", "og"])
     ap.add_argument("--kmer-gbp", type=float, default=1.0, help="c5: gigabases of synthetic reads")
+    ap.add_argument("--kmer-path", default="partitioned", choices=["partitioned", "table"],
+                    help="c5: the partitioned path (round 3) or the table in HBM of rounds 1-2")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: one fixed 4.2 M-point c3 grid cut into N blocks balanced by sum(T - 1)")
@@ -788,12 +799,14 @@ def main():
         n_local = block[1] - block[0]
         # algorithmic HBM bytes of one launch: axes in, 8 B/point LL out, histogram once
         alg_bytes = 8.0 * sum(shape) + 8.0 * n_local + 24.0 * model.bins_evaluated
-        traffic = None
+        traffic, executed = None, None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get(args.workload, {}).get(kernel_name)
+                    rec = json.load(f).get(args.workload, {})
+                traffic = rec.get(kernel_name)
+                executed = rec.get(kernel_name + "_executed_flops")
             except (OSError, ValueError):
                 traffic = None
         out = {
@@ -831,6 +844,13 @@ def main():
                         "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
+        if executed:
+            # the fp64 flops the kernel EXECUTED (PMC: 64 x (2 FMA + MUL + ADD) + 2048 per MFMA, profiles/pmc_traffic.json,
+            # from a profiled run of this workload) over THIS run's kernel time -- beside `frac`, which is on algorithmic
+            # flops: K-basic's closed form leaves most of SURVEY's pmf terms unevaluated, so only this one says how busy
+            # the fp64 pipe is
+            out["roofline"]["executed"] = {"flops_per_launch": executed, "achieved": executed / avg_kernel_s / 1e12,
+                                           "unit": "TFLOP/s", "frac": executed / avg_kernel_s / 1e12 / FP64_PEAK_TFLOPS}
         if kernel_name == "ll_factored" and world == 1 and model.tail == 0:
             # The same kernel time on ROUND 1's flop count of K-factored (one multiply-add per (key, column, o < T)
             # in the contraction; since round 2 the steps below a q-tile's smallest cut-off are summed once per key --

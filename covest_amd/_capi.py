@@ -28,6 +28,7 @@ EXPORTS = (
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
     "covest_kmer_create", "covest_kmer_destroy", "covest_kmer_reserve", "covest_kmer_add",
     "covest_kmer_add_device", "covest_kmer_histogram", "covest_kmer_slots", "covest_kmer_clear",
+    "covest_kmer_count_reads_device",
     "covest_reads_open", "covest_reads_close", "covest_reads_next", "covest_reads_bytes",
     "covest_thin_histogram", "covest_thin_histogram_timed",
 )
@@ -133,6 +134,8 @@ def lib():
     L.covest_kmer_add.argtypes = [vp, u8p, i64p, i64]
     L.covest_kmer_add_device.restype = ctypes.c_int
     L.covest_kmer_add_device.argtypes = [vp, vp, vp, i64, i64, vp]
+    L.covest_kmer_count_reads_device.restype = ctypes.c_int
+    L.covest_kmer_count_reads_device.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     L.covest_kmer_histogram.restype = ctypes.c_int
     L.covest_kmer_histogram.argtypes = [vp, i64p, i64, i64p, i64p]
     L.covest_kmer_clear.restype = ctypes.c_int
@@ -159,6 +162,8 @@ def lib():
 
 
 COVEST_E_INVALID = -1
+COVEST_E_NOMEM = -4
+COVEST_E_UNSUPPORTED = -5
 
 
 def last_error():

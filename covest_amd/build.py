@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libcovest_amd.so")
 # when one of its kernels is first launched, so a process only pays for the variants it uses.
 SOURCES = [("capi.cpp", (), "capi"), ("reads_io.cpp", (), "reads_io"), ("ll_direct.hip", (), "ll_direct"),
            ("ll_basic.hip", (), "ll_basic"), ("ll_factored.hip", (), "ll_factored"), ("argmin.hip", (), "argmin"),
-           ("kmer_count.hip", (), "kmer_count"), ("kmer_wide.hip", (), "kmer_wide"), ("thin_hist.hip", (), "thin_hist")]
+           ("kmer_count.hip", (), "kmer_count"), ("kmer_wide.hip", (), "kmer_wide"), ("kmer_bulk.hip", (), "kmer_bulk"), ("thin_hist.hip", (), "thin_hist")]
 SOURCES += [("ll_factored.hip", ("-DCOVEST_FACTORED_VARIANT=%d" % v,), "ll_factored_v%d" % v) for v in range(8)]
 SOURCES += [("ll_basic.hip", ("-DCOVEST_BASIC_VARIANT=%d" % v,), "ll_basic_v%d" % v) for v in range(8)]
 MAX_PARALLEL = 8

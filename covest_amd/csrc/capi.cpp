@@ -2059,8 +2059,15 @@ struct covest_kmer {
     KmerWideTable wtable{};
     KmerTable table{};
     DevBuf slots, flag, stats, hist, ws_bases, ws_offsets;
+    // the partitioned path (kmer_bulk.hip): its buffers, kept from call to call, and what it found
+    bool bulk = false; // the counter holds the result of covest_kmer_count_reads_device (until covest_kmer_clear)
+    DevBuf bulk_cursor, bulk_recs, bulk_ovf, bulk_ctl, bulk_hist, bulk_big;
+    unsigned long long bulk_stats[4] = {0, 0, 0, 0};
     std::mutex lock;
 };
+
+constexpr unsigned long long kBulkHistLen = 1ull << 20; // dense count-of-counts bins of the partitioned path
+constexpr unsigned long long kBulkBigCap = 4096;        // counts beyond them, listed one by one
 
 namespace {
 
@@ -2160,6 +2167,12 @@ void covest_kmer_destroy(covest_kmer *c)
     c->hist.release();
     c->ws_bases.release();
     c->ws_offsets.release();
+    c->bulk_cursor.release();
+    c->bulk_recs.release();
+    c->bulk_ovf.release();
+    c->bulk_ctl.release();
+    c->bulk_hist.release();
+    c->bulk_big.release();
     delete c;
 }
 
@@ -2181,6 +2194,7 @@ int covest_kmer_clear(covest_kmer *c, void *stream)
     else
         HIP_TRY(launch_kmer_fill_empty(c->table, static_cast<hipStream_t>(stream)));
     HIP_TRY(hipMemsetAsync(c->flag.ptr, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+    c->bulk = false;
     return COVEST_OK;
 }
 
@@ -2234,6 +2248,9 @@ int covest_kmer_add_device(covest_kmer *c, const uint8_t *d_bases, const int64_t
     if (!c || n_reads < 0 || (n_reads > 0 && !d_bases) || (!d_offsets && read_len < 0))
         return fail(COVEST_E_INVALID, "covest_kmer_add_device: bad argument");
     std::lock_guard<std::mutex> guard(c->lock);
+    if (c->bulk)
+        return fail(COVEST_E_INVALID, "covest_kmer_add_device: the counter holds a covest_kmer_count_reads_device result "
+                                      "(its keys are not in the table); covest_kmer_clear first");
     DeviceGuard dev_guard(c->device);
     if (dev_guard.status() != COVEST_OK)
         return dev_guard.status();
@@ -2296,6 +2313,17 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
     else
         HIP_TRY(launch_kmer_stats(c->table, c->stats.as<unsigned long long>(), nullptr));
     HIP_TRY(hipMemcpy(stats, c->stats.ptr, sizeof(stats), hipMemcpyDeviceToHost));
+    // (after covest_kmer_count_reads_device the table holds only what the partitioned path handed back; the rest of
+    // the keys were counted in LDS, and what is left of them is their count-of-counts)
+    std::vector<unsigned long long> big;
+    if (c->bulk) {
+        stats[0] = std::max(stats[0], c->bulk_stats[0]);
+        stats[1] += c->bulk_stats[1];
+        if (c->bulk_stats[2] > 0) {
+            big.resize((size_t)c->bulk_stats[2]);
+            HIP_TRY(hipMemcpy(big.data(), c->bulk_big.ptr, big.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        }
+    }
     const int64_t need = (int64_t)stats[0] + 1; // index 0 .. max count (bin/kmer_hist.py:64)
     if (needed_len)
         *needed_len = need;
@@ -2312,6 +2340,146 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
     else
         HIP_TRY(launch_kmer_histogram(c->table, c->hist.as<unsigned long long>(), (unsigned long long)need, nullptr));
     HIP_TRY(hipMemcpy(out, c->hist.ptr, (size_t)need * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (c->bulk) {
+        const size_t n_dense = (size_t)std::min<unsigned long long>((unsigned long long)need, kBulkHistLen);
+        std::vector<unsigned long long> dense(n_dense);
+        HIP_TRY(hipMemcpy(dense.data(), c->bulk_hist.ptr, n_dense * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n_dense; ++i)
+            out[i] += (int64_t)dense[i];
+        for (unsigned long long v : big)
+            if ((int64_t)v < need)
+                out[v] += 1;
+    }
+    return COVEST_OK;
+}
+
+// The whole counting loop of bin/kmer_hist.py:77-89 for reads resident in HBM, by the partitioned path
+// (kmer_bulk.hip).  See include/covest_amd.h.
+int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_reads,
+                                   int64_t read_len, int64_t n_bases_total, void *stream)
+{
+    if (!c || n_reads < 0 || (n_reads > 0 && !d_bases) || (!d_offsets && read_len < 0))
+        return fail(COVEST_E_INVALID, "covest_kmer_count_reads_device: bad argument");
+    if (c->wide || c->k < 19 || c->k > 31)
+        return fail(COVEST_E_UNSUPPORTED, "covest_kmer_count_reads_device: the partitioned path takes k = 19 .. 31 "
+                                          "(use covest_kmer_add_device)");
+    if (!d_offsets && read_len < c->k)
+        return fail(COVEST_E_UNSUPPORTED, "covest_kmer_count_reads_device: reads shorter than k (use covest_kmer_add_device)");
+    std::lock_guard<std::mutex> guard(c->lock);
+    DeviceGuard dev_guard(c->device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int k = c->k;
+    // windows (an upper bound for reads of different lengths: every base starts at most one)
+    const double windows = d_offsets ? (double)std::max<int64_t>(n_bases_total, n_reads) : (double)n_reads * (double)(read_len - k + 1);
+    KmerBulk p{};
+    p.k = k;
+    p.m = std::min(k - 10, 13);
+    p.w = k - p.m + 1;
+    p.canonical = c->canonical;
+    p.max_run = 32 - k + 1;
+    // ~1024 k-mers per bucket (the LDS table of pass 2 holds 4096 keys), at least 256 buckets, at most 2^23 -- and no
+    // more buckets than half the minimizers there are
+    int lg = 8;
+    while (lg < 23 && (double)((int64_t)1 << lg) * 1024.0 < windows)
+        ++lg;
+    lg = std::min(lg, 2 * p.m - 1);
+    p.log2_buckets = lg;
+    const double n_buckets = (double)((int64_t)1 << lg);
+    // records: a run of one bucket is (w + 1) / 2 windows long on average and at most max_run; every read starts one
+    const double per_run = std::min((double)p.max_run, 0.5 * (double)(p.w + 1));
+    const double records = windows / per_run + (double)n_reads;
+    p.cap = (unsigned)std::max(32.0, std::ceil(3.0 * records / n_buckets));
+    p.overflow_cap = (unsigned long long)std::max(4096.0, records / 8.0);
+    const size_t recs_bytes = (size_t)n_buckets * p.cap * sizeof(ulonglong2);
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = c->bulk_recs.cap + c->bulk_ovf.cap;
+        if ((double)recs_bytes + (double)p.overflow_cap * 16.0 > 0.85 * (double)(free_b + have))
+            return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: the buckets do not fit the free device memory");
+    }
+    HIP_TRY(c->bulk_cursor.reserve((size_t)n_buckets * sizeof(unsigned)));
+    HIP_TRY(c->bulk_recs.reserve(recs_bytes));
+    HIP_TRY(c->bulk_ovf.reserve((size_t)p.overflow_cap * sizeof(ulonglong2)));
+    HIP_TRY(c->bulk_ctl.reserve(8 * sizeof(unsigned long long)));
+    HIP_TRY(c->bulk_hist.reserve((size_t)kBulkHistLen * sizeof(unsigned long long)));
+    HIP_TRY(c->bulk_big.reserve((size_t)kBulkBigCap * sizeof(unsigned long long)));
+    p.cursor = c->bulk_cursor.as<unsigned>();
+    p.recs = c->bulk_recs.as<ulonglong2>();
+    p.overflow = c->bulk_ovf.as<ulonglong2>();
+    unsigned long long *ctl = c->bulk_ctl.as<unsigned long long>(); // [0] list length, [1] table bound, [4..7] stats
+    p.ovf_count = ctl;
+    // an empty counter: the table (it takes what the LDS path hands back), the cursors, the bins
+    c->bulk = false;
+    HIP_TRY(launch_kmer_fill_empty(c->table, st));
+    HIP_TRY(hipMemsetAsync(c->flag.ptr, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(p.cursor, 0, (size_t)n_buckets * sizeof(unsigned), st));
+    HIP_TRY(hipMemsetAsync(ctl, 0, 8 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->bulk_hist.ptr, 0, (size_t)kBulkHistLen * sizeof(unsigned long long), st));
+    // pass 1
+    HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, p, c->table, c->flag.as<int>(), st));
+    HIP_TRY(launch_kmer_fallback_bound(p, ctl + 1, st));
+    unsigned long long head[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(head, ctl, sizeof(head), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (head[0] > p.overflow_cap)
+        return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: the overflow list is full (a few minimizers hold most of "
+                                    "the k-mers); use covest_kmer_add_device");
+    {
+        const int frc = kmer_check_overflow(c); // (reads shorter than k go straight to the table)
+        if (frc != COVEST_OK)
+            return frc;
+    }
+    // the table takes the buckets that overflowed and those whose keys will not fit the LDS table: room for the former
+    // (known) and a share of the windows for the latter
+    {
+        const double want = 2.0 * ((double)head[1] + windows / 64.0 + 4096.0);
+        int tlg = 10;
+        while (tlg < 40 && (double)((int64_t)1 << tlg) < want)
+            ++tlg;
+        if ((int64_t)(c->table.mask + 1) < ((int64_t)1 << tlg)) {
+            KmerTable bigger{};
+            DevBuf slots;
+            int rc = kmer_alloc_table(c, (int64_t)1 << tlg, bigger, slots);
+            hipError_t e = hipSuccess;
+            if (rc == COVEST_OK) {
+                e = launch_kmer_rehash(c->table, bigger, c->flag.as<int>(), nullptr);
+                if (e == hipSuccess)
+                    e = hipDeviceSynchronize();
+                if (e != hipSuccess)
+                    rc = fail_hip(e, "covest_kmer_count_reads_device: rehash");
+            }
+            if (rc != COVEST_OK) {
+                slots.release();
+                return rc;
+            }
+            c->slots.release();
+            c->slots = slots;
+            c->table = bigger;
+        }
+    }
+    // pass 2: two workgroups per CU (64 KB of LDS each)
+    int n_cu = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+            n_cu = prop.multiProcessorCount;
+    }
+    HIP_TRY(launch_kmer_overflow_to_table(p, head[0], c->table, c->flag.as<int>(), st));
+    HIP_TRY(launch_kmer_bucket_count(p, c->table, c->flag.as<int>(), c->bulk_hist.as<unsigned long long>(), kBulkHistLen, ctl + 4,
+                                     c->bulk_big.as<unsigned long long>(), kBulkBigCap, 2 * n_cu, st));
+    HIP_TRY(hipMemcpyAsync(c->bulk_stats, ctl + 4, sizeof(c->bulk_stats), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (c->bulk_stats[2] > kBulkBigCap)
+        return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: more than 4096 keys with counts beyond 2^20");
+    {
+        const int frc = kmer_check_overflow(c);
+        if (frc != COVEST_OK)
+            return frc;
+    }
+    c->bulk = true;
     return COVEST_OK;
 }
 

@@ -84,6 +84,29 @@ hipError_t launch_kmer_stats(const KmerTable &t, unsigned long long *stats, hipS
 hipError_t launch_kmer_histogram(const KmerTable &t, unsigned long long *hist, unsigned long long hist_len,
                                  hipStream_t stream);
 
+// ---- K-kmer, partitioned (kmer_bulk.hip): minimizer buckets of super-k-mer records in HBM, counted in LDS ----
+struct KmerBulk {
+    int k, m, w;          // k-mer length, minimizer length, m-mers per k-mer (k - m + 1)
+    int canonical;
+    int log2_buckets;
+    int max_run;          // windows per record: 32 - k + 1 (a record holds at most 32 bases)
+    unsigned cap;         // records a bucket has room for
+    unsigned *cursor;     // [buckets] records sent to the bucket (beyond cap: it overflowed, its surplus is in `overflow`)
+    ulonglong2 *recs;     // [buckets][cap] {bases as 2-bit codes, base i at bits 2i; number of bases}
+    ulonglong2 *overflow; // [overflow_cap]
+    unsigned long long *ovf_count; // [1] records sent to the list (beyond overflow_cap: lost -- the caller starts over)
+    unsigned long long overflow_cap;
+};
+hipError_t launch_kmer_scatter(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, int64_t fixed_len,
+                               const KmerBulk &p, const KmerTable &t, int *overflow, hipStream_t stream);
+hipError_t launch_kmer_fallback_bound(const KmerBulk &p, unsigned long long *out, hipStream_t stream);
+hipError_t launch_kmer_overflow_to_table(const KmerBulk &p, unsigned long long n, const KmerTable &t, int *overflow,
+                                         hipStream_t stream);
+// stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len), [3] buckets sent to the table
+hipError_t launch_kmer_bucket_count(const KmerBulk &p, const KmerTable &t, int *overflow, unsigned long long *hist,
+                                    unsigned long long hist_len, unsigned long long *stats, unsigned long long *big,
+                                    unsigned long long big_cap, int n_workgroups, hipStream_t stream);
+
 // ---- K-kmer for k > 31 (kmer_wide.hip): keys of w = 2, 4 or 8 words, slots of `stride` words {state/count, key[w]} ----
 struct KmerWideTable {
     unsigned long long *words;

@@ -196,8 +196,18 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
     __syncthreads();
     StreamSet<8> st;
-    st.init(m, lam, o_mine, finite && wave_builds && my_pass < n_pass && o_local < plan.max_o, log_tab, nullptr,
-            8 * my_pass, n_total);
+    if (wave_builds) { // (wave-uniform) the waves that build nothing skip the mixture weights' exps, divisions and logs
+        st.init(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab, nullptr, 8 * my_pass,
+                n_total);
+    } else {
+        st.gone = 0u;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            st.v[s] = 0.0;
+            st.x[s] = 0.0;
+            st.an.set(s, 0.0, -INFINITY);
+        }
+    }
     const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
     if (tid < 64)
         Gs[(size_t)plan.n_buf * kTileBins * LD + tid] = 0.0; // the slack behind the buffers (see launch)

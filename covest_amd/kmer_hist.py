@@ -151,6 +151,30 @@ class KmerCounts:
             int(n_reads), int(read_len), ctypes.c_void_p(stream or 0)), "covest_kmer_add_device")
         return self
 
+    def count_reads_device(self, d_bases_ptr, n_reads, read_len, d_offsets_ptr=None, n_bases=None, stream=None):
+        """ALL the k-mers of reads resident in HBM into this (emptied) counter -- the loop of main,
+        bin/kmer_hist.py:77-89 -- by the partitioned path where it applies (covest_kmer_count_reads_device: k = 19..31,
+        no read shorter than k, buckets that fit the device), else through the table (clear + add_device).  Afterwards
+        the counter answers histogram() / len() exactly; after the partitioned path it holds no dict to add to
+        (clear() first).  Returns the name of the path taken."""
+        n_bases = int(n_bases if n_bases is not None else int(n_reads) * max(int(read_len), 0))
+        rc = _capi.lib().covest_kmer_count_reads_device(
+            self._handle, ctypes.c_void_p(d_bases_ptr), ctypes.c_void_p(d_offsets_ptr or 0), int(n_reads), int(read_len),
+            n_bases, ctypes.c_void_p(stream or 0))
+        if rc == 0:
+            self._distinct = self._added = 0
+            return "partitioned"
+        if rc not in (_capi.COVEST_E_UNSUPPORTED, _capi.COVEST_E_NOMEM):
+            _capi.check(rc, "covest_kmer_count_reads_device")
+        self.why_not_partitioned = _capi.last_error()
+        self.clear(stream)
+        if d_offsets_ptr:
+            self._reserve_for(n_bases + int(n_reads))
+            self.add_device(d_bases_ptr, n_reads, 0, d_offsets_ptr=d_offsets_ptr, stream=stream, reserve=False)
+        else:
+            self.add_device(d_bases_ptr, n_reads, read_len, stream=stream)
+        return "table"
+
     def clear(self, stream=None):
         """Drop every count but keep the table (a fresh `defaultdict(int)` of the same size)."""
         self._distinct = self._added = 0

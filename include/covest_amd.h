@@ -43,6 +43,7 @@ extern "C" {
 #define COVEST_E_NO_DEVICE (-2) /* no HIP device / HIP runtime error at init */
 #define COVEST_E_HIP (-3)       /* HIP runtime error during a call */
 #define COVEST_E_NOMEM (-4)
+#define COVEST_E_UNSUPPORTED (-5) /* the request is valid but this entry point does not serve it (another one does) */
 
 /* Kernel selection for covest_grid_eval / covest_eval_points (mostly for tests
  * and benchmarks; AUTO picks the fastest kernel valid for the request). */
@@ -209,6 +210,16 @@ int covest_kmer_add_device(covest_kmer *c, const uint8_t *d_bases, const int64_t
  * number of distinct k-mers; fails with COVEST_E_NOMEM-like status if the table overflowed. */
 int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t *needed_len,
                           int64_t *distinct);
+/* The WHOLE counting loop of main (bin/kmer_hist.py:77-89: compute_counts over every read) for reads resident in
+ * HBM, into an EMPTY counter, by the partitioned path (kmer_bulk.hip): the k-mers are grouped by minimizer into
+ * buckets of super-k-mer records and counted bucket by bucket in LDS -- an occurrence costs no scattered memory
+ * operation.  The counts are not kept as a dict: afterwards the counter answers covest_kmer_histogram (count-of-counts,
+ * distinct keys -- exact) and nothing else, until covest_kmer_clear.  d_offsets NULL: every read is read_len bases;
+ * else offsets[n_reads + 1] and n_bases_total = offsets[n_reads] - offsets[0].  Blocks until done.
+ * COVEST_E_UNSUPPORTED: k outside 19..31 or reads shorter than k; COVEST_E_NOMEM: the buckets do not fit the device,
+ * or a few minimizers hold most of the k-mers (low-complexity input) -- count with covest_kmer_add_device then. */
+int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_reads,
+                                   int64_t read_len, int64_t n_bases_total, void *stream);
 int64_t covest_kmer_slots(const covest_kmer *c);
 /* Forget every count (counts = defaultdict(int) again), keeping the table's size; asynchronous on `stream`. */
 int covest_kmer_clear(covest_kmer *c, void *stream);

@@ -226,3 +226,91 @@ def test_reads_of_one_length_resident_in_hbm(hip_lib):
     env = dict(os.environ, COVEST_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     proc = subprocess.run([sys.executable, "-c", _FIXED_LEN_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0 and "fixed-length ok" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
+
+
+_PARTITIONED_SCRIPT = r"""
+import os, sys
+import torch                      # first: ONE HIP runtime per process (INTEGRATION.md 8)
+sys.path.insert(0, os.environ["COVEST_REPO"])
+import numpy as np
+from covest_amd import kmer_hist as kh
+from oracle import kmer_oracle as ko
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(5)
+LUT = np.frombuffer(b"ACGT", dtype=np.uint8)
+taken = []
+def run(name, reads, k, canonical, fixed_len=None, expect=None):
+    blob = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    d_bases = torch.from_numpy(blob.copy()).to(dev) if blob.size else torch.zeros(1, dtype=torch.uint8, device=dev)
+    lens = np.array([len(r) for r in reads], dtype=np.int64)
+    offs = np.zeros(len(reads) + 1, dtype=np.int64); np.cumsum(lens, out=offs[1:])
+    d_offs = torch.from_numpy(offs).to(dev)
+    want = ko.histogram(reads, k, canonical=canonical)
+    want_distinct = len(ko.count_kmers(reads, k, canonical=canonical)[0])
+    for layout in (("fixed",) if fixed_len else ()) + ("offsets",):
+        c = kh.KmerCounts(k, canonical=canonical, min_slots=1 << 12)
+        if layout == "fixed":
+            path = c.count_reads_device(d_bases.data_ptr(), len(reads), fixed_len)
+        else:
+            path = c.count_reads_device(d_bases.data_ptr(), len(reads), 0, d_offsets_ptr=d_offs.data_ptr(), n_bases=int(offs[-1]))
+        got = c.histogram()
+        assert got == want, (name, layout, path, k, canonical, got[:8], want[:8])
+        assert len(c) == want_distinct, (name, layout, path)
+        if expect:
+            assert path == expect, (name, layout, path, getattr(c, "why_not_partitioned", ""))
+        taken.append((name, layout, path))
+        # the counter is reusable: a second count of the same reads gives the same histogram, not twice the counts
+        if layout == "offsets":
+            c.count_reads_device(d_bases.data_ptr(), len(reads), 0, d_offsets_ptr=d_offs.data_ptr(), n_bases=int(offs[-1]))
+            assert c.histogram() == want, (name, "second count")
+        if path == "partitioned":
+            try:
+                c.add_device(d_bases.data_ptr(), 1, 0, d_offsets_ptr=d_offs.data_ptr())
+                raise SystemExit("add after a partitioned count must be refused")
+            except kh._capi.CovestHipError:
+                pass
+            c.clear()
+            c.add_reads(reads[:50])      # ... and after clear() the counter is an ordinary one again
+            assert c.histogram() == ko.histogram(reads[:50], k, canonical=canonical), (name, "after clear")
+        c.close()
+
+def genome_reads(n, L, g_len, err=0.01):
+    genome = rng.integers(0, 4, size=g_len, dtype=np.uint8)
+    starts = rng.integers(0, g_len - L, size=n)
+    codes = genome[starts[:, None] + np.arange(L)[None, :]]
+    flips = rng.random(codes.shape) < err
+    codes = np.where(flips, rng.integers(0, 4, size=codes.shape, dtype=np.uint8), codes)
+    return ["".join(map(chr, row)) for row in LUT[codes]]
+
+for k, canonical in ((21, True), (21, False), (19, True), (25, False), (31, True)):
+    L = 100
+    reads = genome_reads(20000, L, 40000)                       # 40x-50x coverage with 1 % substitutions
+    run("genome k=%d" % k, reads, k, canonical, fixed_len=L, expect="partitioned")
+# reads of different lengths, some shorter than k (they count the hash of what there is), an empty one
+ragged = [r[:int(n)] for r, n in zip(genome_reads(4000, 150, 30000), rng.integers(0, 151, size=4000))] + ["", "ACGT"]
+run("ragged", ragged, 21, True)
+run("ragged forward", ragged, 23, False)
+# low complexity: a handful of minimizers hold everything -- buckets overflow, the table takes them, still exact
+low = ["A" * 100, "AC" * 50, "ACG" * 33 + "A", "T" * 100] * 3000 + genome_reads(2000, 100, 5000)
+run("low complexity", low, 21, True, fixed_len=100)
+# highly repetitive: 40 000 copies of 25 reads -- counts far beyond the LDS bins
+rep = genome_reads(25, 100, 2000, err=0.0) * 40000
+run("repeats", rep, 21, True, fixed_len=100)
+# k the partitioned path does not take
+run("k=12", genome_reads(3000, 60, 5000), 12, True, fixed_len=60, expect="table")
+assert any(p == "partitioned" for _, _, p in taken)
+print("partitioned ok", taken)
+"""
+
+
+def test_partitioned_count_of_resident_reads(hip_lib):
+    """covest_kmer_count_reads_device (kmer_bulk.hip: minimizer buckets of super-k-mer records, counted in LDS) against
+    the numpy oracle, exact: genome-like reads (both layouts, several k, both strand modes), reads of different
+    lengths with some shorter than k, low-complexity reads whose buckets overflow into the table, repeats whose counts
+    leave the LDS bins, a k the path declines (the wrapper then counts through the table)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, COVEST_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    proc = subprocess.run([sys.executable, "-c", _PARTITIONED_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0 and "partitioned ok" in proc.stdout, proc.stdout[-3000:] + proc.stderr[-4000:]
