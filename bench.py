@@ -296,6 +296,7 @@ def bench_kmer(args):
     if counted != n_kmers or sum(hist) != distinct:
         raise SystemExit("k-mer histogram inconsistent: %d windows counted, %d expected" % (counted, n_kmers))
     partitioned = paths == {"partitioned"}
+    partition = counts.partition_info() if partitioned else None
     # algorithmic HBM bytes: every base once; table path: one 16-byte {key, count} slot per occurrence; partitioned
     # path: one 16-byte record per run of ~(w + 1) / 2 = 6 windows, written once and read once
     alg_bytes = 1.0 * n_reads * read_len + (2.0 * 16.0 * n_kmers / 6.0 if partitioned else 16.0 * n_kmers)
@@ -308,6 +309,7 @@ def bench_kmer(args):
                                "genome, 1%% substitutions)" % (n_reads, n_reads * read_len / 1e9),
                    "kernel": "kmer_scatter + kmer_bucket_count (partitioned)" if partitioned else "kmer_count (table of %d slots)" % counts.slots,
                    "path": sorted(paths), "why_not_partitioned": getattr(counts, "why_not_partitioned", None),
+                   "partition": partition,
                    "distinct_kmers": distinct, "windows_counted": counted,
                    "hist_head": hist[:6], "hist_peak": int(np.argmax(hist[5:]) + 5) if len(hist) > 6 else None},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

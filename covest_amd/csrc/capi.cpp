@@ -2061,8 +2061,12 @@ struct covest_kmer {
     DevBuf slots, flag, stats, hist, ws_bases, ws_offsets;
     // the partitioned path (kmer_bulk.hip): its buffers, kept from call to call, and what it found
     bool bulk = false; // the counter holds the result of covest_kmer_count_reads_device (until covest_kmer_clear)
-    DevBuf bulk_cursor, bulk_recs, bulk_ovf, bulk_ctl, bulk_hist, bulk_big;
+    DevBuf bulk_sampled, bulk_cursor, bulk_fill, bulk_later, bulk_partial, bulk_recs, bulk_ovf, bulk_ctl, bulk_hist, bulk_big;
     unsigned long long bulk_stats[4] = {0, 0, 0, 0};
+    int64_t bulk_info[5] = {0, 0, 0, 0, 0}; // buckets, m, sample, records there was room for, records that found none
+    unsigned bulk_later_n = 0;              // buckets a workgroup (not a wave) counted
+    unsigned long long bulk_to_table_n = 0; // buckets counted through the table in HBM
+    bool bulk_table_used = false;           // ... and whether the table holds anything of the result
     std::mutex lock;
 };
 
@@ -2167,6 +2171,10 @@ void covest_kmer_destroy(covest_kmer *c)
     c->hist.release();
     c->ws_bases.release();
     c->ws_offsets.release();
+    c->bulk_sampled.release();
+    c->bulk_fill.release();
+    c->bulk_later.release();
+    c->bulk_partial.release();
     c->bulk_cursor.release();
     c->bulk_recs.release();
     c->bulk_ovf.release();
@@ -2307,12 +2315,15 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
     if (rc != COVEST_OK)
         return rc;
     unsigned long long stats[2] = {0, 0};
-    HIP_TRY(hipMemset(c->stats.ptr, 0, sizeof(stats)));
-    if (c->wide)
-        HIP_TRY(launch_kmer_wide_stats(c->wtable, c->stats.as<unsigned long long>(), nullptr));
-    else
-        HIP_TRY(launch_kmer_stats(c->table, c->stats.as<unsigned long long>(), nullptr));
-    HIP_TRY(hipMemcpy(stats, c->stats.ptr, sizeof(stats), hipMemcpyDeviceToHost));
+    const bool table_in_use = !c->bulk || c->bulk_table_used; // (a partitioned count may leave nothing in the table)
+    if (table_in_use) {
+        HIP_TRY(hipMemset(c->stats.ptr, 0, sizeof(stats)));
+        if (c->wide)
+            HIP_TRY(launch_kmer_wide_stats(c->wtable, c->stats.as<unsigned long long>(), nullptr));
+        else
+            HIP_TRY(launch_kmer_stats(c->table, c->stats.as<unsigned long long>(), nullptr));
+        HIP_TRY(hipMemcpy(stats, c->stats.ptr, sizeof(stats), hipMemcpyDeviceToHost));
+    }
     // (after covest_kmer_count_reads_device the table holds only what the partitioned path handed back; the rest of
     // the keys were counted in LDS, and what is left of them is their count-of-counts)
     std::vector<unsigned long long> big;
@@ -2335,7 +2346,9 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
         return fail(COVEST_E_INVALID, "covest_kmer_histogram: output shorter than max count + 1");
     HIP_TRY(c->hist.reserve((size_t)need * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->hist.ptr, 0, (size_t)need * sizeof(unsigned long long)));
-    if (c->wide)
+    if (!table_in_use)
+        ;
+    else if (c->wide)
         HIP_TRY(launch_kmer_wide_histogram(c->wtable, c->hist.as<unsigned long long>(), (unsigned long long)need, nullptr));
     else
         HIP_TRY(launch_kmer_histogram(c->table, c->hist.as<unsigned long long>(), (unsigned long long)need, nullptr));
@@ -2363,8 +2376,9 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     if (c->wide || c->k < 19 || c->k > 31)
         return fail(COVEST_E_UNSUPPORTED, "covest_kmer_count_reads_device: the partitioned path takes k = 19 .. 31 "
                                           "(use covest_kmer_add_device)");
-    if (!d_offsets && read_len < c->k)
-        return fail(COVEST_E_UNSUPPORTED, "covest_kmer_count_reads_device: reads shorter than k (use covest_kmer_add_device)");
+    if (!d_offsets && (read_len < c->k || read_len >= ((int64_t)1 << 30)))
+        return fail(COVEST_E_UNSUPPORTED, "covest_kmer_count_reads_device: reads shorter than k, or of 2^30 bases and more "
+                                          "(use covest_kmer_add_device)");
     std::lock_guard<std::mutex> guard(c->lock);
     DeviceGuard dev_guard(c->device);
     if (dev_guard.status() != COVEST_OK)
@@ -2375,82 +2389,110 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     const double windows = d_offsets ? (double)std::max<int64_t>(n_bases_total, n_reads) : (double)n_reads * (double)(read_len - k + 1);
     KmerBulk p{};
     p.k = k;
-    p.m = std::min(k - 10, 13);
-    p.w = k - p.m + 1;
+    p.m = std::min(k - 8, 13);
     p.canonical = c->canonical;
     p.max_run = 32 - k + 1;
-    // ~1024 k-mers per bucket (the LDS table of pass 2 holds 4096 keys), at least 256 buckets, at most 2^23 -- and no
-    // more buckets than half the minimizers there are
-    int lg = 8;
-    while (lg < 23 && (double)((int64_t)1 << lg) * 1024.0 < windows)
+    // ~256 windows per bucket (a wave's LDS table of pass 2 holds 1024 keys), at least 2^10 buckets, at most an eighth
+    // of the minimizers there are
+    int lg = 10;
+    while (lg < 2 * p.m - 3 && (double)((int64_t)1 << lg) * 256.0 < windows)
         ++lg;
-    lg = std::min(lg, 2 * p.m - 1);
+#ifdef COVEST_DIAG // diagnostic builds only: the shipped library has no knobs
+    if (const char *e = std::getenv("COVEST_KMER_M"))
+        p.m = std::max(8, std::min(std::atoi(e), std::min(k - 1, 15)));
+    if (const char *e = std::getenv("COVEST_KMER_LG"))
+        lg = std::max(10, std::min(std::atoi(e), 26));
+#endif
+    p.w = k - p.m + 1;
     p.log2_buckets = lg;
-    const double n_buckets = (double)((int64_t)1 << lg);
-    // records: a run of one bucket is (w + 1) / 2 windows long on average and at most max_run; every read starts one
-    const double per_run = std::min((double)p.max_run, 0.5 * (double)(p.w + 1));
-    const double records = windows / per_run + (double)n_reads;
-    p.cap = (unsigned)std::max(32.0, std::ceil(3.0 * records / n_buckets));
-    p.overflow_cap = (unsigned long long)std::max(4096.0, records / 8.0);
-    const size_t recs_bytes = (size_t)n_buckets * p.cap * sizeof(ulonglong2);
+    const size_t n_buckets = (size_t)1 << lg;
+    // pass 0 looks at everything when that is little, else at one block of tiles (one read) in 16
+    if (d_offsets) {
+        p.sample = n_reads >= ((int64_t)1 << 16) ? 16 : 1;
+    } else {
+        const double blocks = (double)n_reads * (double)read_len / (double)kmer_bulk_block_bytes(p);
+        p.sample = blocks >= 4096.0 ? 16 : 1;
+    }
+#ifdef COVEST_DIAG
+    if (const char *e = std::getenv("COVEST_KMER_SAMPLE"))
+        p.sample = std::max(1, std::atoi(e));
+#endif
+    HIP_TRY(c->bulk_sampled.reserve(n_buckets * sizeof(unsigned)));
+    HIP_TRY(c->bulk_cursor.reserve(n_buckets * sizeof(ulonglong2)));
+    HIP_TRY(c->bulk_fill.reserve(n_buckets * sizeof(unsigned long long)));
+    HIP_TRY(c->bulk_later.reserve((2 * n_buckets + 8) * sizeof(unsigned)));
+    HIP_TRY(c->bulk_partial.reserve((n_buckets / 1024 + 1) * sizeof(unsigned long long)));
+    HIP_TRY(c->bulk_ctl.reserve(16 * sizeof(unsigned long long)));
+    HIP_TRY(c->bulk_hist.reserve((size_t)kBulkHistLen * sizeof(unsigned long long)));
+    HIP_TRY(c->bulk_big.reserve((size_t)kBulkBigCap * sizeof(unsigned long long)));
+    p.sampled = c->bulk_sampled.as<unsigned>();
+    p.ctl = c->bulk_cursor.as<ulonglong2>();
+    p.fill = c->bulk_fill.as<KmerBulk::fill_t>();
+    // [0] overflow list length, [1] table bound, [2] room for records in all, [4..7] stats
+    unsigned long long *ctl = c->bulk_ctl.as<unsigned long long>();
+    p.ovf_count = ctl;
+    c->bulk = false;
+    // pass 0: room per bucket from the sample, the buckets' places
+    HIP_TRY(hipMemsetAsync(p.sampled, 0, n_buckets * sizeof(unsigned), st));
+    HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(unsigned long long), st));
+    HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, p, true, st));
+    HIP_TRY(launch_kmer_place_buckets(p, c->bulk_partial.as<unsigned long long>(), ctl + 2, st));
+    unsigned long long room = 0;
+    HIP_TRY(hipMemcpyAsync(&room, ctl + 2, sizeof(room), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    p.overflow_cap = std::max<unsigned long long>(4096ull, room / 8ull);
     {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const size_t have = c->bulk_recs.cap + c->bulk_ovf.cap;
-        if ((double)recs_bytes + (double)p.overflow_cap * 16.0 > 0.85 * (double)(free_b + have))
+        if (((double)room + (double)p.overflow_cap) * 16.0 > 0.85 * (double)(free_b + have))
             return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: the buckets do not fit the free device memory");
     }
-    HIP_TRY(c->bulk_cursor.reserve((size_t)n_buckets * sizeof(unsigned)));
-    HIP_TRY(c->bulk_recs.reserve(recs_bytes));
+    HIP_TRY(c->bulk_recs.reserve(std::max<size_t>((size_t)room, 1) * sizeof(ulonglong2)));
     HIP_TRY(c->bulk_ovf.reserve((size_t)p.overflow_cap * sizeof(ulonglong2)));
-    HIP_TRY(c->bulk_ctl.reserve(8 * sizeof(unsigned long long)));
-    HIP_TRY(c->bulk_hist.reserve((size_t)kBulkHistLen * sizeof(unsigned long long)));
-    HIP_TRY(c->bulk_big.reserve((size_t)kBulkBigCap * sizeof(unsigned long long)));
-    p.cursor = c->bulk_cursor.as<unsigned>();
     p.recs = c->bulk_recs.as<ulonglong2>();
     p.overflow = c->bulk_ovf.as<ulonglong2>();
-    unsigned long long *ctl = c->bulk_ctl.as<unsigned long long>(); // [0] list length, [1] table bound, [4..7] stats
-    p.ovf_count = ctl;
-    // an empty counter: the table (it takes what the LDS path hands back), the cursors, the bins
-    c->bulk = false;
-    HIP_TRY(launch_kmer_fill_empty(c->table, st));
-    HIP_TRY(hipMemsetAsync(c->flag.ptr, 0, sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(p.cursor, 0, (size_t)n_buckets * sizeof(unsigned), st));
-    HIP_TRY(hipMemsetAsync(ctl, 0, 8 * sizeof(unsigned long long), st));
+    // [0] buckets left to a workgroup, [2..3] buckets left to the table and (64-bit) their k-mers; the lists behind
+    unsigned *later = c->bulk_later.as<unsigned>();
+    unsigned long long *to_table = reinterpret_cast<unsigned long long *>(later + 2);
+    unsigned *later_list = later + 8, *to_table_list = later + 8 + n_buckets;
+    HIP_TRY(hipMemsetAsync(later, 0, 8 * sizeof(unsigned), st));
+    HIP_TRY(hipMemsetAsync(p.fill, 0, n_buckets * sizeof(KmerBulk::fill_t), st));
     HIP_TRY(hipMemsetAsync(c->bulk_hist.ptr, 0, (size_t)kBulkHistLen * sizeof(unsigned long long), st));
-    // pass 1
-    HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, p, c->table, c->flag.as<int>(), st));
-    HIP_TRY(launch_kmer_fallback_bound(p, ctl + 1, st));
-    unsigned long long head[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(head, ctl, sizeof(head), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (head[0] > p.overflow_cap)
-        return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: the overflow list is full (a few minimizers hold most of "
-                                    "the k-mers); use covest_kmer_add_device");
+    // pass 1, pass 2
+    int n_cu = 256;
     {
-        const int frc = kmer_check_overflow(c); // (reads shorter than k go straight to the table)
-        if (frc != COVEST_OK)
-            return frc;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+            n_cu = prop.multiProcessorCount;
     }
-    // the table takes the buckets that overflowed and those whose keys will not fit the LDS table: room for the former
-    // (known) and a share of the windows for the latter
-    {
-        const double want = 2.0 * ((double)head[1] + windows / 64.0 + 4096.0);
+    HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, p, false, st));
+    HIP_TRY(launch_kmer_bucket_count(p, c->bulk_hist.as<unsigned long long>(), kBulkHistLen, ctl + 4,
+                                     c->bulk_big.as<unsigned long long>(), kBulkBigCap, later, later_list, to_table, to_table_list,
+                                     n_cu, st));
+    unsigned long long n_overflowed = 0, listed[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&n_overflowed, ctl, sizeof(n_overflowed), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(c->bulk_stats, ctl + 4, sizeof(c->bulk_stats), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&c->bulk_later_n, later, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(listed, to_table, sizeof(listed), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_overflowed > p.overflow_cap)
+        return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: the overflow list is full (the sample of the reads "
+                                    "misjudged the buckets); use covest_kmer_add_device");
+    if (c->bulk_stats[2] > kBulkBigCap)
+        return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: more than 4096 keys with counts beyond 2^20");
+    // what no LDS table could hold -- the buckets that overflowed their room (all their records: a key is counted in one
+    // place), those with too many distinct keys -- goes to the table in HBM, sized now that the need is known
+    c->bulk_table_used = n_overflowed > 0 || listed[0] > 0;
+    if (c->bulk_table_used) {
+        const double want = 2.0 * ((double)listed[1] + (double)n_overflowed * (double)p.max_run) + 1024.0;
         int tlg = 10;
         while (tlg < 40 && (double)((int64_t)1 << tlg) < want)
             ++tlg;
-        if ((int64_t)(c->table.mask + 1) < ((int64_t)1 << tlg)) {
+        if ((int64_t)(c->table.mask + 1) < ((int64_t)1 << tlg)) { // (nothing to keep: the counter was to be emptied)
             KmerTable bigger{};
             DevBuf slots;
-            int rc = kmer_alloc_table(c, (int64_t)1 << tlg, bigger, slots);
-            hipError_t e = hipSuccess;
-            if (rc == COVEST_OK) {
-                e = launch_kmer_rehash(c->table, bigger, c->flag.as<int>(), nullptr);
-                if (e == hipSuccess)
-                    e = hipDeviceSynchronize();
-                if (e != hipSuccess)
-                    rc = fail_hip(e, "covest_kmer_count_reads_device: rehash");
-            }
+            const int rc = kmer_alloc_table(c, (int64_t)1 << tlg, bigger, slots);
             if (rc != COVEST_OK) {
                 slots.release();
                 return rc;
@@ -2459,27 +2501,35 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
             c->slots = slots;
             c->table = bigger;
         }
-    }
-    // pass 2: two workgroups per CU (64 KB of LDS each)
-    int n_cu = 256;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
-            n_cu = prop.multiProcessorCount;
-    }
-    HIP_TRY(launch_kmer_overflow_to_table(p, head[0], c->table, c->flag.as<int>(), st));
-    HIP_TRY(launch_kmer_bucket_count(p, c->table, c->flag.as<int>(), c->bulk_hist.as<unsigned long long>(), kBulkHistLen, ctl + 4,
-                                     c->bulk_big.as<unsigned long long>(), kBulkBigCap, 2 * n_cu, st));
-    HIP_TRY(hipMemcpyAsync(c->bulk_stats, ctl + 4, sizeof(c->bulk_stats), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (c->bulk_stats[2] > kBulkBigCap)
-        return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: more than 4096 keys with counts beyond 2^20");
-    {
+        HIP_TRY(launch_kmer_fill_empty(c->table, st));
+        HIP_TRY(hipMemsetAsync(c->flag.ptr, 0, sizeof(int), st));
+        HIP_TRY(launch_kmer_to_table(p, n_overflowed, c->table, c->flag.as<int>(), to_table, to_table_list, st));
+        HIP_TRY(hipStreamSynchronize(st));
         const int frc = kmer_check_overflow(c);
         if (frc != COVEST_OK)
             return frc;
     }
+    c->bulk_info[0] = (int64_t)n_buckets;
+    c->bulk_info[1] = p.m;
+    c->bulk_info[2] = p.sample;
+    c->bulk_info[3] = (int64_t)room;
+    c->bulk_info[4] = (int64_t)n_overflowed;
+    c->bulk_to_table_n = listed[0];
     c->bulk = true;
+    return COVEST_OK;
+}
+
+int covest_kmer_partition_info(const covest_kmer *c, int64_t out[8])
+{
+    if (!c || !out)
+        return fail(COVEST_E_INVALID, "covest_kmer_partition_info: bad argument");
+    if (!c->bulk)
+        return fail(COVEST_E_INVALID, "covest_kmer_partition_info: the counter holds no covest_kmer_count_reads_device result");
+    for (int i = 0; i < 5; ++i)
+        out[i] = c->bulk_info[i];
+    out[5] = (int64_t)c->bulk_later_n;
+    out[6] = (int64_t)c->bulk_to_table_n;
+    out[7] = 0;
     return COVEST_OK;
 }
 

@@ -90,22 +90,31 @@ struct KmerBulk {
     int canonical;
     int log2_buckets;
     int max_run;          // windows per record: 32 - k + 1 (a record holds at most 32 bases)
-    unsigned cap;         // records a bucket has room for
-    unsigned *cursor;     // [buckets] records sent to the bucket (beyond cap: it overflowed, its surplus is in `overflow`)
-    ulonglong2 *recs;     // [buckets][cap] {bases as 2-bit codes, base i at bits 2i; number of bases}
+    int sample;           // pass 0 looks at 1 block of tiles (1 read) in `sample`
+    unsigned *sampled;    // [buckets] records pass 0 counted
+    typedef unsigned long long fill_t; // (32-bit cursors are no faster -- measured)
+    ulonglong2 *ctl;      // [buckets] {first, end}: the bucket's places in recs
+    fill_t *fill;         // [buckets] records sent to the bucket (beyond its room: it overflowed, the surplus is in `overflow`)
+    ulonglong2 *recs;     // {bases as 2-bit codes, base i at bits 2i; number of bases}
     ulonglong2 *overflow; // [overflow_cap]
     unsigned long long *ovf_count; // [1] records sent to the list (beyond overflow_cap: lost -- the caller starts over)
     unsigned long long overflow_cap;
 };
+int kmer_bulk_block_bytes(const KmerBulk &p); // bytes of reads of one length a workgroup of pass 0/1 answers for
 hipError_t launch_kmer_scatter(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, int64_t fixed_len,
-                               const KmerBulk &p, const KmerTable &t, int *overflow, hipStream_t stream);
-hipError_t launch_kmer_fallback_bound(const KmerBulk &p, unsigned long long *out, hipStream_t stream);
-hipError_t launch_kmer_overflow_to_table(const KmerBulk &p, unsigned long long n, const KmerTable &t, int *overflow,
-                                         hipStream_t stream);
-// stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len), [3] buckets sent to the table
-hipError_t launch_kmer_bucket_count(const KmerBulk &p, const KmerTable &t, int *overflow, unsigned long long *hist,
-                                    unsigned long long hist_len, unsigned long long *stats, unsigned long long *big,
-                                    unsigned long long big_cap, int n_workgroups, hipStream_t stream);
+                               const KmerBulk &p, bool count_only, hipStream_t stream);
+hipError_t launch_kmer_place_buckets(const KmerBulk &p, unsigned long long *partial, unsigned long long *total,
+                                     hipStream_t stream);
+// stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len)
+// later: [0] buckets the wave-per-bucket kernel left to the workgroup-per-bucket one, later_list: [buckets]
+// to_table: [0] buckets no LDS table could hold, [1] their k-mer occurrences, to_table_list: [buckets]
+hipError_t launch_kmer_bucket_count(const KmerBulk &p, unsigned long long *hist, unsigned long long hist_len,
+                                    unsigned long long *stats, unsigned long long *big, unsigned long long big_cap,
+                                    unsigned *later, unsigned *later_list, unsigned long long *to_table, unsigned *to_table_list,
+                                    int n_cu, hipStream_t stream);
+// the overflow list's records and the listed buckets' into the table in HBM
+hipError_t launch_kmer_to_table(const KmerBulk &p, unsigned long long n_overflowed, const KmerTable &t, int *overflow,
+                                const unsigned long long *to_table, const unsigned *to_table_list, hipStream_t stream);
 
 // ---- K-kmer for k > 31 (kmer_wide.hip): keys of w = 2, 4 or 8 words, slots of `stride` words {state/count, key[w]} ----
 struct KmerWideTable {

@@ -4,21 +4,28 @@
 // K-kmer's table (kmer_count.hip) pays one scattered memory-side operation pair per k-mer OCCURRENCE: 2e10 a
 // second, whatever the table's size (tools/microbench_atomics.hip).  Here an occurrence costs LDS work only:
 //
-//   pass 1  (kmer_scatter_*)   every window's MINIMIZER -- the m-mer of smallest hash among the k - m + 1 it holds,
-//           canonical when the keys are -- names a BUCKET, a function of the k-mer alone: every occurrence of a key
-//           lands in the same bucket.  Consecutive windows of a read mostly share their minimizer, so a wave cuts its 64
-//           windows into runs of equal bucket ("super-k-mers") and writes ONE 16-byte record per run -- the run's
-//           bases as 2-bit codes and their number -- behind the bucket's cursor: one returning atomic and one store
-//           per ~6 windows, 2.6 bytes of HBM traffic per k-mer instead of 16 scattered ones.
-//   pass 2  (kmer_bucket_count_kernel)   a persistent workgroup takes bucket after bucket: the records' k-mers go into
-//           a hash table in LDS (64-bit compare-and-swap on the key, 32-bit add on the count), the table is swept
-//           into the workgroup's count-of-counts bins (LDS too, flushed once at the end).
+//   pass 0  (kmer_tile_kernel<COUNT>, kmer_caps_*)   the records pass 1 will write, counted per bucket on a SAMPLE of
+//           the reads (1 block of tiles in `sample`; everything when the input is small), turned into room per bucket
+//           (the estimate plus three standard deviations) and, by a prefix sum, into the buckets' places in ONE array:
+//           minimizers are far from equally frequent, a fixed room per bucket would be wasted on most and short for some.
+//   pass 1  (kmer_tile_kernel<SCATTER>)   every window's MINIMIZER -- the m-mer of smallest hash among the k - m + 1
+//           it holds, canonical when the keys are -- names a BUCKET, a function of the k-mer alone: every occurrence
+//           of a key lands in the same bucket.  Consecutive windows of a read mostly share their minimizer: the runs
+//           of equal bucket ("super-k-mers") become ONE 16-byte record each -- the run's bases as 2-bit codes and their
+//           number -- behind the bucket's cursor: one returning atomic and one store per ~5 windows, 6 bytes of HBM
+//           traffic per k-mer instead of 16 scattered ones.  A workgroup works through tiles of 256 consecutive BYTES
+//           of the read array: every thread packs the 16 bases from its byte on (one unaligned 16-byte load), hashes the
+//           m-mer that starts there ONCE (LDS), and the window's minimizer is the smallest of w neighbouring entries.
+//   pass 2  (kmer_wave_count_kernel)   one WAVE per bucket, no barrier anywhere: the records' k-mers go into the wave's
+//           own hash table in LDS (1024 slots; 64-bit compare-and-swap on the key, 32-bit add on the count), the table
+//           is swept into the workgroup's count-of-counts bins (LDS too, flushed once at the end).  Twelve waves a CU
+//           hide each other's latency.  (kmer_bucket_count_kernel)  the few buckets with too many records or too many
+//           distinct keys for that: a workgroup each, 4096 slots.
 //
-// Exact by construction -- and by a fall-back for everything that does not fit: a bucket that overflows its space in
-// HBM (minimizers are not equally frequent; low-complexity reads put everything into a few buckets), a bucket whose
-// distinct keys do not fit the LDS table, a read shorter than k: all of THAT bucket's k-mers (records in place and
-// records in the overflow list alike -- a key must be counted in one place only) go to the open-addressing table of
-// kmer_count.hip, whose histogram is added at the end.
+// Exact by construction -- and by a fall-back for everything that does not fit: a bucket that overflows its room in
+// HBM (the sample misjudged it), a bucket whose distinct keys do not fit the LDS tables: all of THAT bucket's k-mers
+// (records in place and records in the overflow list alike -- a key must be counted in one place only) go to the
+// open-addressing table of kmer_count.hip, whose histogram is added at the end.
 //
 // Reference restated: bin/kmer_hist.py:18-41 (codes, counts), :57-64 (count-of-counts); `canonical` as in kmer_count.hip.
 #include <hip/hip_runtime.h>
@@ -36,25 +43,55 @@ namespace {
 using namespace kmer;
 typedef unsigned long long u64;
 
-// The bucket of a k-mer: a hash of its minimizer.  `h`: the k-mer's code (first base in the highest bits), `rc`: its
-// reverse complement's.  canonical: the m-mers count as the smaller of themselves and their reverse complements, which
-// makes the function symmetric in (h, rc); otherwise the forward m-mers only.  Either way a function of the KEY.
-__device__ __forceinline__ unsigned bucket_of(u64 h, u64 rc, const KmerBulk &p)
+constexpr int kTile = 256;            // bytes (threads) of a tile of pass 0/1
+constexpr int kTilesPerBlock = 8;     // consecutive tiles a workgroup works through (the unit of the sample)
+constexpr unsigned kNoBucket = ~0u;
+
+// ---- the bucket of a k-mer ---------------------------------------------------------------------------------------
+// m-mers as little-endian codes (base j at bits 2j).  The reverse complement of one: complement, reverse the pairs.
+__device__ __forceinline__ unsigned mmer_canonical(unsigned x, int m, int canonical)
 {
-    const u64 mm = (1ull << (2 * p.m)) - 1ull;
-    u64 best = ~0ull;
-    for (int i = 0; i < p.w; ++i) {
-        const u64 a = (h >> (2 * i)) & mm;                     // m-mer i of the key (counted from its end) ...
-        u64 c = a;
-        if (p.canonical) {
-            const u64 b = (rc >> (2 * (p.w - 1 - i))) & mm;    // ... and its reverse complement
-            c = a < b ? a : b;
-        }
-        const u64 x = (c + 1ull) * 0x9E3779B97F4A7C15ull;
-        best = x < best ? x : best;
+    if (!canonical)
+        return x;
+    unsigned r = __brev(~x);
+    r = ((r & 0xAAAAAAAAu) >> 1) | ((r & 0x55555555u) << 1);
+    r >>= 32 - 2 * m;
+    return r < x ? r : x;
+}
+
+__device__ __forceinline__ unsigned mmer_hash(unsigned c)
+{
+    const unsigned h = (c + 1u) * 0x9E3779B1u; // (a bijection: different m-mers never tie)
+    return h ^ (h >> 15);
+}
+
+__device__ __forceinline__ unsigned bucket_of_min(unsigned mn, int log2_buckets)
+{
+    unsigned h = mn * 0x85EBCA77u; // (the minimum of w hashes is small: spread it again)
+    h ^= h >> 13;
+    h *= 0xC2B2AE3Du;
+    return h >> (32 - log2_buckets);
+}
+
+// The bucket of ONE window from its little-endian code (the slow way: pass 1's tiles share the m-mer hashes between
+// windows).  The rc of the k-mer holds the rc's of its m-mers: with canonical m-mers the function is one of the KEY.
+__device__ __forceinline__ unsigned bucket_of_le(u64 le, const KmerBulk &p)
+{
+    const unsigned mm = (1u << (2 * p.m)) - 1u;
+    unsigned best = ~0u;
+    for (int j = 0; j < p.w; ++j) {
+        const unsigned hv = mmer_hash(mmer_canonical((unsigned)(le >> (2 * j)) & mm, p.m, p.canonical));
+        best = hv < best ? hv : best;
     }
-    const u64 h2 = best * 0xD6E8FEB86659FD93ull; // (the minimum of w hashes is small: spread it again)
-    return (unsigned)(h2 >> (64 - p.log2_buckets));
+    return bucket_of_min(best, p.log2_buckets);
+}
+
+// four ASCII bases -> one byte of 2-bit codes (base j at bits 2j)
+__device__ __forceinline__ unsigned pack4(unsigned w)
+{
+    unsigned x = (w >> 1) & 0x03030303u;
+    x ^= (x >> 1) & 0x01010101u;
+    return (x * 0x01041040u) >> 24;
 }
 
 // Up to 32 bases of a read from seq[s] on as 2-bit codes, little-endian: base i at bits 2i.
@@ -65,9 +102,7 @@ __device__ __forceinline__ u64 pack_bases(const unsigned char *__restrict__ seq,
         for (int j = 0; j < 8; ++j) { // (whole words: the bases beyond n are masked off below)
             unsigned w;
             __builtin_memcpy(&w, seq + s + 4 * j, 4);
-            unsigned x = (w >> 1) & 0x03030303u;
-            x ^= (x >> 1) & 0x01010101u;
-            le |= (u64)((x * 0x01041040u) >> 24) << (8 * j);
+            le |= (u64)pack4(w) << (8 * j);
         }
     } else {
         for (int i = 0; i < n; ++i)
@@ -76,11 +111,20 @@ __device__ __forceinline__ u64 pack_bases(const unsigned char *__restrict__ seq,
     return n < 32 ? le & ((1ull << (2 * n)) - 1ull) : le;
 }
 
+// One record behind its bucket's cursor (COUNT: only counted).  ctl[b] = {first, end}: places in recs; fill[b]: the cursor.
+template <bool COUNT>
 __device__ __forceinline__ void append_record(unsigned b, u64 code, int n_bases, const KmerBulk &p)
 {
-    const unsigned pos = atomicAdd(&p.cursor[b], 1u);
-    if (pos < p.cap) {
-        p.recs[(u64)b * p.cap + pos] = make_ulonglong2(code, (u64)n_bases);
+    if (COUNT) {
+        atomicAdd(&p.sampled[b], 1u);
+        return;
+    }
+    // (the cursors are an array of their own, touched by atomics only: atomics on lines that plain loads of the same
+    // kernel keep in the caches run at a tenth of the rate -- measured)
+    const ulonglong2 place = p.ctl[b];
+    const u64 pos = place.x + (u64)atomicAdd(&p.fill[b], (KmerBulk::fill_t)1);
+    if (pos < place.y) {
+        p.recs[pos] = make_ulonglong2(code, (u64)n_bases);
     } else { // the bucket is full: the record goes to the list, and the WHOLE bucket to the table later (pass 2)
         const u64 at = atomicAdd(p.ovf_count, 1ull);
         if (at < p.overflow_cap)
@@ -88,60 +132,122 @@ __device__ __forceinline__ void append_record(unsigned b, u64 code, int n_bases,
     }
 }
 
-// One wave, one window per lane (`valid`: the lane has one): runs of consecutive windows of one read with one bucket,
-// cut into pieces of at most p.max_run windows, each piece a record behind its bucket's cursor.
-__device__ __forceinline__ void scatter_wave(const unsigned char *__restrict__ seq, int64_t s, int64_t len, int64_t read_id,
-                                             bool valid, const KmerBulk &p)
+// ---- pass 0 / 1, reads of one length ----------------------------------------------------------------------------
+// The read array as one run of bytes (`len` bytes a read, nothing between them): tile t covers bytes
+// [t * n_win, t * n_win + 256), its first n_win = 256 - max(16, w - 1) bytes are the window starts it answers for.
+// `positions`: bytes of this launch (whole reads, < 2^32); `avail`: bytes that may be read from `bases` on.
+template <bool COUNT>
+__global__ __launch_bounds__(kTile) void kmer_tile_kernel(const unsigned char *__restrict__ bases, unsigned positions,
+                                                          u64 avail, unsigned len, unsigned n_tiles, const KmerBulk p)
 {
-    const int lane = threadIdx.x & (kWave - 1);
-    unsigned b = 0;
-    if (valid) {
-        u64 h, rc;
-        window_codes(seq, s, len, p.k, h, rc);
-        b = bucket_of(h, rc, p);
+    __shared__ unsigned hs[kTile]; // hash of the m-mer that starts at the byte
+    __shared__ unsigned cs[kTile]; // the 16 bases from the byte on
+    __shared__ unsigned bk[kTile]; // bucket of the window that starts at the byte
+    __shared__ u64 hmask[kTile / kWave], vmask[kTile / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int n_win = kTile - max(16, p.w - 1);
+    const unsigned mm = (1u << (2 * p.m)) - 1u;
+    const unsigned block = COUNT ? blockIdx.x * (unsigned)p.sample : blockIdx.x;
+    for (int tt = 0; tt < kTilesPerBlock; ++tt) {
+        const unsigned tile = block * kTilesPerBlock + tt;
+        if (tile >= n_tiles)
+            break; // (workgroup-uniform)
+        const unsigned at = tile * (unsigned)n_win + (unsigned)tid;
+        unsigned c16 = 0;
+        if ((u64)at + 16ull <= avail) {
+            uint4 v;
+            __builtin_memcpy(&v, bases + at, 16);
+            c16 = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
+        } else {
+            for (int j = 0; j < 16; ++j)
+                if ((u64)at + (u64)j < avail)
+                    c16 |= base_code(bases[at + j]) << (2 * j);
+        }
+        const unsigned i = at % len; // place in its read
+        hs[tid] = (at < positions && i + (unsigned)p.m <= len) ? mmer_hash(mmer_canonical(c16 & mm, p.m, p.canonical)) : ~0u;
+        cs[tid] = c16;
+        __syncthreads();
+        const bool valid = tid < n_win && at < positions && i + (unsigned)p.k <= len;
+        unsigned b = kNoBucket;
+        if (valid) {
+            unsigned mn = hs[tid];
+            for (int j = 1; j < p.w; ++j) {
+                const unsigned o = hs[tid + j];
+                mn = o < mn ? o : mn;
+            }
+            b = bucket_of_min(mn, p.log2_buckets);
+        }
+        bk[tid] = b;
+        __syncthreads();
+        // a run starts where the window before is none (a read begins, the tile does) or belongs elsewhere
+        const bool head = valid && (tid == 0 || bk[tid - 1] != b);
+        const u64 hm = __ballot(head), vm = __ballot(valid);
+        if (lane == 0) {
+            hmask[wave] = hm;
+            vmask[wave] = vm;
+        }
+        __syncthreads();
+        if (head) {
+            // ... and ends before the next head or the first byte that starts no window (the tile's halo counts as such)
+            int run;
+            const u64 stop = (hm | ~vm) & (lane == kWave - 1 ? 0ull : (~0ull << (lane + 1)));
+            if (stop) {
+                run = __ffsll((long long)stop) - 1 - lane;
+            } else {
+                run = kWave - lane;
+                for (int wv = wave + 1; wv < kTile / kWave; ++wv) {
+                    const u64 s2 = hmask[wv] | ~vmask[wv];
+                    if (s2) {
+                        run += __ffsll((long long)s2) - 1;
+                        break;
+                    }
+                    run += kWave;
+                }
+            }
+            for (int off = 0; off < run; off += p.max_run) { // pieces of at most max_run windows: 32 bases a record
+                const int a = tid + off;
+                const int n_bases = min(p.max_run, run - off) + p.k - 1;
+                u64 le = (u64)cs[a] | ((u64)cs[a + 16] << 32);
+                if (n_bases < 32)
+                    le &= (1ull << (2 * n_bases)) - 1ull;
+                append_record<COUNT>(b, le, n_bases, p);
+            }
+        }
+        __syncthreads(); // (the arrays are the next tile's)
     }
-    const unsigned prev_b = __shfl_up(b, 1, kWave);
-    const int64_t prev_r = __shfl_up(read_id, 1, kWave);
-    const bool prev_valid = __shfl_up((int)valid, 1, kWave) != 0;
-    const bool head = valid && (lane == 0 || !prev_valid || prev_r != read_id || prev_b != b);
-    const u64 headmask = __ballot(head);
-    const u64 validmask = __ballot(valid);
-    if (!valid)
-        return;
-    // this lane's run starts at the highest head at or below it; pieces of max_run windows
-    const u64 upto = headmask & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-    const int hp = 63 - __clzll((long long)upto);
-    const bool piece_head = ((lane - hp) % p.max_run) == 0;
-    if (!piece_head)
-        return;
-    // the piece ends before the next head, the next invalid lane, its max_run-th window, or the wave's end
-    const u64 above = lane == 63 ? 0ull : (~0ull << (lane + 1));
-    const u64 stop = (headmask | ~validmask) & above;
-    int run = (stop ? __ffsll((long long)stop) - 1 : 64) - lane;
-    run = min(run, p.max_run);
-    const int n_bases = run + p.k - 1;
-    append_record(b, pack_bases(seq, s, len, n_bases), n_bases, p);
 }
 
-// Reads of one length: the windows of all reads numbered through, 64 consecutive ones per wave (as kmer_count.hip).
-__global__ __launch_bounds__(256) void kmer_scatter_fixed_kernel(const unsigned char *__restrict__ bases, int64_t n_reads,
-                                                                 int64_t len, const KmerBulk p)
-{
-    const int64_t n_windows = len - p.k + 1;
-    const int64_t total = n_reads * n_windows;
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = w < total;
-    const int64_t r = valid ? w / n_windows : 0;
-    scatter_wave(bases + r * len, valid ? w - r * n_windows : 0, len, r, valid, p);
-}
-
-// One wave per read (reads of any length).
-__global__ __launch_bounds__(256) void kmer_scatter_kernel(const unsigned char *__restrict__ bases,
-                                                           const int64_t *__restrict__ offsets, int64_t n_reads,
-                                                           const KmerBulk p, const KmerTable t, int *overflow)
+// ---- pass 0 / 1, reads of any length: one wave per read, a window per lane, the bucket the slow way ------------------
+template <bool COUNT>
+__device__ __forceinline__ void scatter_wave(const unsigned char *__restrict__ seq, int64_t s, int64_t len, bool valid,
+                                             const KmerBulk &p)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t r = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    unsigned b = kNoBucket;
+    if (valid)
+        b = bucket_of_le(pack_bases(seq, s, len, p.k), p);
+    const unsigned prev_b = __shfl_up(b, 1, kWave);
+    const bool head = valid && (lane == 0 || prev_b != b);
+    const u64 hm = __ballot(head), vm = __ballot(valid);
+    if (!head)
+        return;
+    const u64 stop = (hm | ~vm) & (lane == kWave - 1 ? 0ull : (~0ull << (lane + 1)));
+    const int run = (stop ? __ffsll((long long)stop) - 1 : kWave) - lane;
+    for (int off = 0; off < run; off += p.max_run) {
+        const int n_bases = min(p.max_run, run - off) + p.k - 1;
+        append_record<COUNT>(b, pack_bases(seq, s + off, len, n_bases), n_bases, p);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void kmer_scatter_reads_kernel(const unsigned char *__restrict__ bases,
+                                                                 const int64_t *__restrict__ offsets, int64_t n_reads,
+                                                                 const KmerBulk p)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    int64_t r = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (COUNT)
+        r *= p.sample;
     if (r >= n_reads)
         return;
     const int64_t p0 = offsets[r];
@@ -155,19 +261,107 @@ __global__ __launch_bounds__(256) void kmer_scatter_kernel(const unsigned char *
             u64 le = 0;
             for (int i = 0; i < (int)len; ++i)
                 le |= (u64)base_code(seq[i]) << (2 * (p.k - (int)len + i));
-            u64 h, rc;
-            codes_from_le(le, p.k, h, rc);
-            append_record(bucket_of(h, rc, p), le, p.k, p);
+            append_record<COUNT>(bucket_of_le(le, p), le, p.k, p);
         }
         return;
     }
     const int64_t n_windows = len - p.k + 1;
     for (int64_t s0 = 0; s0 < n_windows; s0 += kWave) { // wave-uniform trip count
         const int64_t s = s0 + lane;
-        scatter_wave(seq, s < n_windows ? s : 0, len, r, s < n_windows, p);
+        scatter_wave<COUNT>(seq, s < n_windows ? s : 0, len, s < n_windows, p);
     }
 }
 
+// ---- pass 0: room per bucket and the buckets' places (a prefix sum over the buckets) -------------------------------
+constexpr int kScanItems = 4;
+constexpr int kScanBlock = 256 * kScanItems;
+
+// sampled records of a bucket -> records it gets room for: all of them when everything was counted, else the estimate
+// plus three standard deviations of it (the count in a 1-in-s sample of n records scatters by sqrt(n / s))
+__device__ __forceinline__ u64 room_for(unsigned sampled, int sample)
+{
+    if (sample <= 1)
+        return sampled;
+    const float c = (float)sampled;
+    return (u64)((float)sample * (c + 3.0f * sqrtf(c) + 2.0f));
+}
+
+// exclusive prefix of `v` over the 256 threads of the workgroup (lds: 4 words); `total` = the sum over all of them
+__device__ __forceinline__ u64 block_exclusive_scan(u64 v, u64 *lds, u64 &total)
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    u64 inc = v;
+    for (int off = 1; off < kWave; off <<= 1) {
+        const u64 o = __shfl_up(inc, off, kWave);
+        if (lane >= off)
+            inc += o;
+    }
+    __syncthreads(); // (lds may still be read from the call before)
+    if (lane == kWave - 1)
+        lds[wave] = inc;
+    __syncthreads();
+    u64 before = 0;
+    total = 0;
+    for (int wv = 0; wv < 4; ++wv) {
+        const u64 s = lds[wv];
+        if (wv < wave)
+            before += s;
+        total += s;
+    }
+    return before + inc - v;
+}
+
+__global__ __launch_bounds__(256) void kmer_caps_partial_kernel(const KmerBulk p, u64 *__restrict__ partial)
+{
+    __shared__ u64 lds[4];
+    const unsigned first = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+    u64 mine = 0;
+    for (int j = 0; j < kScanItems; ++j)
+        mine += room_for(p.sampled[first + j], p.sample);
+    u64 total;
+    block_exclusive_scan(mine, lds, total);
+    if (threadIdx.x == 0)
+        partial[blockIdx.x] = total;
+}
+
+// one workgroup: partial[] -> its exclusive prefix, in place; out[0] = the total
+__global__ __launch_bounds__(256) void kmer_caps_scan_kernel(u64 *__restrict__ partial, unsigned n, u64 *__restrict__ out)
+{
+    __shared__ u64 lds[4];
+    const unsigned per = (n + 255u) / 256u;
+    const unsigned first = threadIdx.x * per;
+    u64 mine = 0;
+    for (unsigned j = first; j < first + per && j < n; ++j)
+        mine += partial[j];
+    u64 total;
+    u64 run = block_exclusive_scan(mine, lds, total);
+    for (unsigned j = first; j < first + per && j < n; ++j) {
+        const u64 v = partial[j];
+        partial[j] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0)
+        out[0] = total;
+}
+
+__global__ __launch_bounds__(256) void kmer_caps_place_kernel(const KmerBulk p, const u64 *__restrict__ partial)
+{
+    __shared__ u64 lds[4];
+    const unsigned first = blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+    u64 room[kScanItems], mine = 0;
+    for (int j = 0; j < kScanItems; ++j) {
+        room[j] = room_for(p.sampled[first + j], p.sample);
+        mine += room[j];
+    }
+    u64 total;
+    u64 at = partial[blockIdx.x] + block_exclusive_scan(mine, lds, total);
+    for (int j = 0; j < kScanItems; ++j) {
+        p.ctl[first + j] = make_ulonglong2(at, at + room[j]);
+        at += room[j];
+    }
+}
+
+// ---- pass 2 --------------------------------------------------------------------------------------------------------
 // Every k-mer of a record into the table in HBM.
 __device__ __forceinline__ void record_to_table(ulonglong2 rec, const KmerBulk &p, const KmerTable &t, int *overflow)
 {
@@ -185,126 +379,247 @@ __device__ __forceinline__ void record_to_table(ulonglong2 rec, const KmerBulk &
     }
 }
 
-constexpr int kLdsSlots = 4096;      // LDS hash table of a bucket: 32 KB of keys + 16 KB of counts
-constexpr int kLdsHistBins = 4096;   // count-of-counts bins kept in LDS per workgroup
+constexpr int kWaveSlots = 1024;     // LDS hash table of a wave: 8 KB of keys + 4 KB of counts
+constexpr int kWaveRecs = 768;       // a bucket with more records than this goes to a workgroup instead
+constexpr int kLdsSlots = 4096;      // LDS hash table of a workgroup: 32 KB of keys + 16 KB of counts
+constexpr int kLdsHistBins = 1024;   // count-of-counts bins kept in LDS per workgroup
 constexpr u64 kLdsEmpty = ~0ull;
 
-// Pass 2.  stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len), [3] buckets sent to the
-// table.  hist: dense count-of-counts for counts < hist_len.
-__global__ __launch_bounds__(256) void kmer_bucket_count_kernel(const KmerBulk p, const KmerTable t, int *overflow,
-                                                                u64 *__restrict__ hist, u64 hist_len,
-                                                                u64 *__restrict__ stats, u64 *__restrict__ big, u64 big_cap)
+// the key a k-mer is counted under in the LDS tables (any one-to-one function of the reference's key does)
+__device__ __forceinline__ u64 lds_key(u64 le, const KmerBulk &p)
+{
+    if (!p.canonical)
+        return le;
+    u64 h, rc;
+    codes_from_le(le, p.k, h, rc);
+    return rc < h ? rc : h;
+}
+
+__device__ __forceinline__ unsigned lds_slot(u64 key, unsigned smask)
+{
+    const unsigned x = ((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA77u);
+    return (x >> 12) & smask;
+}
+
+// true: counted
+__device__ __forceinline__ bool lds_insert(u64 *keys, unsigned *cnts, unsigned slots, u64 key)
+{
+    const unsigned smask = slots - 1u;
+    unsigned at = lds_slot(key, smask);
+    for (unsigned probe = 0; probe < slots; ++probe) {
+        u64 cur = keys[at];
+        if (cur == kLdsEmpty)
+            cur = atomicCAS(&keys[at], kLdsEmpty, key);
+        if (cur == kLdsEmpty || cur == key) {
+            atomicAdd(&cnts[at], 1u);
+            return true;
+        }
+        at = (at + 1u) & smask;
+    }
+    return false;
+}
+
+struct SweepAcc {
+    u64 distinct = 0, mx = 0;
+};
+
+// one slot's count into the bins
+__device__ __forceinline__ void count_into_bins(u64 c, SweepAcc &acc, unsigned *bins, u64 *__restrict__ hist, u64 hist_len,
+                                                u64 *__restrict__ stats, u64 *__restrict__ big, u64 big_cap)
+{
+    ++acc.distinct;
+    acc.mx = c > acc.mx ? c : acc.mx;
+    if (c < (u64)kLdsHistBins) {
+        atomicAdd(&bins[c], 1u);
+    } else if (c < hist_len) {
+        atomicAdd(&hist[c], 1ull);
+    } else {
+        const u64 at = atomicAdd(&stats[2], 1ull);
+        if (at < big_cap)
+            big[at] = c;
+    }
+}
+
+__device__ __forceinline__ void flush_stats(SweepAcc acc, const unsigned *bins, u64 *__restrict__ hist, u64 hist_len,
+                                            u64 *__restrict__ stats)
+{
+    for (int i = threadIdx.x; i < kLdsHistBins; i += blockDim.x)
+        if (bins[i] != 0u && (u64)i < hist_len)
+            atomicAdd(&hist[i], (u64)bins[i]);
+    for (int off = 32; off >= 1; off >>= 1) {
+        acc.distinct += __shfl_xor(acc.distinct, off, kWave);
+        const u64 o = __shfl_xor(acc.mx, off, kWave);
+        acc.mx = o > acc.mx ? o : acc.mx;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicMax(&stats[0], acc.mx);
+        atomicAdd(&stats[1], acc.distinct);
+    }
+}
+
+// Pass 2, a wave per bucket.  stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len).
+// hist: dense count-of-counts for counts < hist_len.  later[0]: buckets left to
+// kmer_bucket_count_kernel, listed in later_list.
+__global__ __launch_bounds__(256) void kmer_wave_count_kernel(const KmerBulk p, u64 *__restrict__ hist, u64 hist_len,
+                                                              u64 *__restrict__ stats, u64 *__restrict__ big, u64 big_cap,
+                                                              unsigned *__restrict__ later, unsigned *__restrict__ later_list)
+{
+    __shared__ u64 all_keys[256 / kWave][kWaveSlots];
+    __shared__ unsigned all_cnts[256 / kWave][kWaveSlots];
+    __shared__ unsigned bins[kLdsHistBins];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    u64 *keys = all_keys[wave];
+    unsigned *cnts = all_cnts[wave];
+    for (int i = tid; i < kLdsHistBins; i += blockDim.x)
+        bins[i] = 0u;
+    for (int i = lane; i < kWaveSlots; i += kWave) {
+        keys[i] = kLdsEmpty;
+        cnts[i] = 0u;
+    }
+    __syncthreads();
+    SweepAcc acc;
+    const unsigned n_groups = (1u << p.log2_buckets) / kWave; // (at least 2^10 buckets)
+    const unsigned n_waves = gridDim.x * (blockDim.x / kWave);
+    const u64 kmask = p.k < 32 ? (1ull << (2 * p.k)) - 1ull : ~0ull;
+    for (unsigned g = blockIdx.x * (blockDim.x / kWave) + wave; g < n_groups; g += n_waves) {
+        // 64 buckets' cursors at once, a lane each
+        const unsigned b_lane = g * kWave + lane;
+        const ulonglong2 c = p.ctl[b_lane];
+        const u64 first = c.x, filled = p.fill[b_lane], room = c.y - c.x;
+        const bool skip = filled > room || filled > (u64)kWaveRecs;
+        const u64 skipmask = __ballot(skip);
+        if (skipmask) {
+            unsigned at = 0;
+            if (lane == 0)
+                at = atomicAdd(later, (unsigned)__popcll(skipmask));
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (skip)
+                later_list[at + __popcll(skipmask & ((1ull << lane) - 1ull))] = b_lane;
+        }
+        u64 todo = __ballot(!skip && filled > 0);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const u64 s_b = __shfl(first, l, kWave);
+            const unsigned n_b = (unsigned)__shfl((unsigned)filled, l, kWave);
+            unsigned slots = 64;
+            while (slots < 8u * n_b && slots < (unsigned)kWaveSlots)
+                slots <<= 1;
+            bool ok = true;
+            for (unsigned i0 = 0; i0 < n_b; i0 += kWave) {
+                ulonglong2 rec = make_ulonglong2(0ull, 0ull);
+                if (i0 + lane < n_b)
+                    rec = p.recs[s_b + i0 + lane];
+                const int n_k = rec.y ? (int)rec.y - p.k + 1 : 0;
+                for (int j = 0; j < p.max_run; ++j) {
+                    if (!__ballot(j < n_k))
+                        break;
+                    if (j < n_k)
+                        ok = lds_insert(keys, cnts, slots, lds_key((rec.x >> (2 * j)) & kmask, p)) && ok;
+                }
+            }
+            const bool failed = __ballot(!ok) != 0ull; // more distinct keys than slots: a workgroup takes the bucket
+            for (unsigned i = lane; i < slots; i += kWave) {
+                if (keys[i] != kLdsEmpty) {
+                    const u64 cnt = cnts[i];
+                    keys[i] = kLdsEmpty; // (the table is the next bucket's)
+                    cnts[i] = 0u;
+                    if (!failed)
+                        count_into_bins(cnt, acc, bins, hist, hist_len, stats, big, big_cap);
+                }
+            }
+            if (failed && lane == 0)
+                later_list[atomicAdd(later, 1u)] = g * kWave + (unsigned)l;
+        }
+    }
+    __syncthreads();
+    flush_stats(acc, bins, hist, hist_len, stats);
+}
+
+// Pass 2, a workgroup per bucket: those of later_list.  What does not fit here either is listed for the table in HBM
+// (to_table[0] buckets, to_table[1] their k-mer occurrences -- the table is sized AFTER this is known --, to_table_list).
+__global__ __launch_bounds__(256) void kmer_bucket_count_kernel(const KmerBulk p, u64 *__restrict__ hist, u64 hist_len,
+                                                                u64 *__restrict__ stats, u64 *__restrict__ big, u64 big_cap,
+                                                                const unsigned *__restrict__ later,
+                                                                const unsigned *__restrict__ later_list,
+                                                                u64 *__restrict__ to_table, unsigned *__restrict__ to_table_list)
 {
     __shared__ u64 keys[kLdsSlots];
     __shared__ unsigned cnts[kLdsSlots];
     __shared__ unsigned bins[kLdsHistBins];
-    __shared__ unsigned n_kmers_s, failed_s;
     const int tid = threadIdx.x;
     for (int i = tid; i < kLdsHistBins; i += blockDim.x)
         bins[i] = 0u;
-    u64 distinct = 0, mx = 0, to_table = 0;
-    const unsigned n_buckets = 1u << p.log2_buckets;
+    for (int i = tid; i < kLdsSlots; i += blockDim.x) {
+        keys[i] = kLdsEmpty;
+        cnts[i] = 0u;
+    }
+    __syncthreads();
+    SweepAcc acc;
+    const unsigned n_later = later[0];
     const u64 kmask = p.k < 32 ? (1ull << (2 * p.k)) - 1ull : ~0ull;
-    for (unsigned b = blockIdx.x; b < n_buckets; b += gridDim.x) {
-        const unsigned filled = p.cursor[b];
-        if (filled == 0)
-            continue; // (workgroup-uniform)
-        const unsigned n = min(filled, p.cap);
-        const ulonglong2 *recs = p.recs + (u64)b * p.cap;
-        bool fall_back = filled > p.cap; // records of this bucket sit in the overflow list too: everything to the table
-        unsigned slots = 0;
+    for (unsigned at = blockIdx.x; at < n_later; at += gridDim.x) {
+        const unsigned b = later_list[at];
+        const ulonglong2 c = p.ctl[b];
+        const u64 first = c.x, filled = p.fill[b], room = c.y - c.x;
+        const u64 n = filled < room ? filled : room;
+        const ulonglong2 *recs = p.recs + first;
+        // records of this bucket in the overflow list too, or more distinct keys than the table holds: to the table
+        bool fall_back = filled > room;
+        u64 n_kmers = 0;
         if (!fall_back) {
-            // the bucket's k-mers, to size the table: a power of two >= twice their number (distinct keys are fewer)
-            if (tid == 0) {
-                n_kmers_s = 0u;
-                failed_s = 0u;
-            }
-            __syncthreads();
-            unsigned mine = 0;
-            for (unsigned i = tid; i < n; i += blockDim.x)
-                mine += (unsigned)recs[i].y - (unsigned)p.k + 1u;
-            for (int off = 32; off >= 1; off >>= 1)
-                mine += __shfl_xor(mine, off, kWave);
-            if ((tid & (kWave - 1)) == 0)
-                atomicAdd(&n_kmers_s, mine);
-            __syncthreads();
-            const unsigned n_kmers = n_kmers_s;
-            slots = 256;
-            while (slots < 2u * n_kmers && slots < (unsigned)kLdsSlots)
+            unsigned slots = 1024;
+            while ((u64)slots < 8ull * n && slots < (unsigned)kLdsSlots)
                 slots <<= 1;
-            for (unsigned i = tid; i < slots; i += blockDim.x) {
-                keys[i] = kLdsEmpty;
-                cnts[i] = 0u;
-            }
-            __syncthreads();
-            const unsigned smask = slots - 1u;
-            for (unsigned i = tid; i < n; i += blockDim.x) {
+            bool ok = true;
+            for (u64 i = tid; i < n; i += blockDim.x) {
                 const ulonglong2 rec = recs[i];
                 const int n_k = (int)rec.y - p.k + 1;
-                for (int j = 0; j < n_k; ++j) {
-                    u64 h, rc;
-                    codes_from_le((rec.x >> (2 * j)) & kmask, p.k, h, rc);
-                    const u64 key = (p.canonical && rc < h) ? rc : h;
-                    unsigned at = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & smask;
-                    bool done = false;
-                    for (unsigned probe = 0; probe < slots; ++probe) {
-                        u64 cur = keys[at];
-                        if (cur == kLdsEmpty)
-                            cur = atomicCAS(&keys[at], kLdsEmpty, key);
-                        if (cur == kLdsEmpty || cur == key) {
-                            atomicAdd(&cnts[at], 1u);
-                            done = true;
-                            break;
-                        }
-                        at = (at + 1u) & smask;
-                    }
-                    if (!done)
-                        failed_s = 1u; // more distinct keys than slots: the bucket goes to the table instead
+                n_kmers += (u64)n_k;
+                for (int j = 0; j < n_k && ok; ++j)
+                    ok = lds_insert(keys, cnts, slots, lds_key((rec.x >> (2 * j)) & kmask, p));
+            }
+            fall_back = __syncthreads_or(!ok) != 0;
+            for (unsigned i = tid; i < slots; i += blockDim.x)
+                if (keys[i] != kLdsEmpty) {
+                    const u64 cnt = cnts[i];
+                    keys[i] = kLdsEmpty;
+                    cnts[i] = 0u;
+                    if (!fall_back)
+                        count_into_bins(cnt, acc, bins, hist, hist_len, stats, big, big_cap);
                 }
-            }
             __syncthreads();
-            fall_back = failed_s != 0u;
-            if (!fall_back) {
-                for (unsigned i = tid; i < slots; i += blockDim.x)
-                    if (keys[i] != kLdsEmpty) {
-                        const u64 c = cnts[i];
-                        ++distinct;
-                        mx = c > mx ? c : mx;
-                        if (c < (u64)kLdsHistBins) {
-                            atomicAdd(&bins[c], 1u);
-                        } else if (c < hist_len) {
-                            atomicAdd(&hist[c], 1ull);
-                        } else {
-                            const u64 at = atomicAdd(&stats[2], 1ull);
-                            if (at < big_cap)
-                                big[at] = c;
-                        }
-                    }
-            }
-            __syncthreads(); // (the table is cleared again for the next bucket)
         }
         if (fall_back) {
-            for (unsigned i = tid; i < n; i += blockDim.x)
-                record_to_table(recs[i], p, t, overflow);
+            if (filled > room) // (not read yet)
+                for (u64 i = tid; i < n; i += blockDim.x)
+                    n_kmers += (u64)((int)recs[i].y - p.k + 1);
+            for (int off = 32; off >= 1; off >>= 1)
+                n_kmers += __shfl_xor(n_kmers, off, kWave);
+            if ((tid & (kWave - 1)) == 0)
+                atomicAdd(&to_table[1], n_kmers);
             if (tid == 0)
-                ++to_table;
+                to_table_list[atomicAdd(&to_table[0], 1ull)] = b;
         }
     }
     __syncthreads();
-    for (int i = tid; i < kLdsHistBins; i += blockDim.x)
-        if (bins[i] != 0u && (u64)i < hist_len)
-            atomicAdd(&hist[i], (u64)bins[i]);
-    for (int off = 32; off >= 1; off >>= 1) {
-        distinct += __shfl_xor(distinct, off, kWave);
-        const u64 o = __shfl_xor(mx, off, kWave);
-        mx = o > mx ? o : mx;
+    flush_stats(acc, bins, hist, hist_len, stats);
+}
+
+// The buckets no LDS table could hold: their records' k-mers into the table in HBM.
+__global__ __launch_bounds__(256) void kmer_buckets_to_table_kernel(const KmerBulk p, const KmerTable t, int *overflow,
+                                                                    const u64 *__restrict__ to_table,
+                                                                    const unsigned *__restrict__ to_table_list)
+{
+    const unsigned n_listed = (unsigned)to_table[0];
+    for (unsigned at = blockIdx.x; at < n_listed; at += gridDim.x) {
+        const unsigned b = to_table_list[at];
+        const ulonglong2 c = p.ctl[b];
+        const u64 filled = p.fill[b], room = c.y - c.x;
+        const u64 n = filled < room ? filled : room;
+        for (u64 i = threadIdx.x; i < n; i += blockDim.x)
+            record_to_table(p.recs[c.x + i], p, t, overflow);
     }
-    if ((tid & (kWave - 1)) == 0) {
-        atomicMax(&stats[0], mx);
-        atomicAdd(&stats[1], distinct);
-    }
-    if (tid == 0 && to_table)
-        atomicAdd(&stats[3], to_table);
 }
 
 // The records that found their bucket full: their k-mers into the table (their buckets' other records follow in pass 2).
@@ -314,74 +629,96 @@ __global__ __launch_bounds__(256) void kmer_overflow_to_table_kernel(const KmerB
         record_to_table(p.overflow[i], p, t, overflow);
 }
 
-// k-mer occurrences the table will have to take (an upper bound: max_run per record): the records of the buckets that
-// overflowed, in place and in the list.  out[0]
-__global__ __launch_bounds__(256) void kmer_fallback_bound_kernel(const KmerBulk p, u64 *out)
+template <bool COUNT>
+hipError_t launch_tiles(const unsigned char *bases, int64_t n_reads, int64_t len, const KmerBulk &p, hipStream_t stream)
 {
-    const unsigned n_buckets = 1u << p.log2_buckets;
-    u64 mine = 0;
-    for (unsigned b = blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += gridDim.x * blockDim.x) {
-        const unsigned filled = p.cursor[b];
-        if (filled > p.cap)
-            mine += (u64)filled * (u64)p.max_run;
+    const int n_win = kTile - std::max(16, p.w - 1);
+    // whole reads per launch, their bytes (and the tiles' halo) below 2^32
+    const int64_t reads_per_launch = std::max<int64_t>(1, (((int64_t)1 << 31)) / len);
+    for (int64_t first = 0; first < n_reads; first += reads_per_launch) {
+        const int64_t n = std::min(n_reads - first, reads_per_launch);
+        const uint64_t positions = (uint64_t)(n * len);
+        const uint64_t avail = (uint64_t)((n_reads - first) * len);
+        const uint64_t n_tiles = (positions + n_win - 1) / n_win;
+        uint64_t blocks = (n_tiles + kTilesPerBlock - 1) / kTilesPerBlock;
+        if (COUNT)
+            blocks = (blocks + p.sample - 1) / p.sample;
+        hipLaunchKernelGGL(kmer_tile_kernel<COUNT>, dim3((unsigned)blocks), dim3(kTile), 0, stream, bases + first * len,
+                           (unsigned)positions, (u64)avail, (unsigned)len, (unsigned)n_tiles, p);
     }
-    for (int off = 32; off >= 1; off >>= 1)
-        mine += __shfl_xor(mine, off, kWave);
-    if ((threadIdx.x & (kWave - 1)) == 0 && mine)
-        atomicAdd(out, mine);
+    return hipGetLastError();
+}
+
+template <bool COUNT>
+hipError_t launch_reads(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, const KmerBulk &p,
+                        hipStream_t stream)
+{
+    const int reads_per_block = 4;
+    const int64_t step = COUNT ? p.sample : 1;
+    const int64_t reads_per_launch = ((int64_t)reads_per_block << 23) * step; // (a multiple of the sample's stride)
+    for (int64_t first = 0; first < n_reads; first += reads_per_launch) {
+        const int64_t n = std::min(n_reads - first, reads_per_launch);
+        const int64_t waves = (n + step - 1) / step;
+        const dim3 grid((unsigned)((waves + reads_per_block - 1) / reads_per_block));
+        hipLaunchKernelGGL(kmer_scatter_reads_kernel<COUNT>, grid, dim3(reads_per_block * kWave), 0, stream, bases, offsets + first,
+                           n, p);
+    }
+    return hipGetLastError();
 }
 
 } // namespace
 
+int kmer_bulk_block_bytes(const KmerBulk &p)
+{
+    return kTilesPerBlock * (kTile - std::max(16, p.w - 1));
+}
+
 hipError_t launch_kmer_scatter(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, int64_t fixed_len,
-                               const KmerBulk &p, const KmerTable &t, int *overflow, hipStream_t stream)
+                               const KmerBulk &p, bool count_only, hipStream_t stream)
 {
     if (n_reads <= 0)
         return hipSuccess;
-    if (!offsets) { // (the host sends reads shorter than k to the table path)
-        const int64_t n_windows = fixed_len - p.k + 1;
-        const int64_t reads_per_launch = std::max<int64_t>(1, (((int64_t)1 << 31) - 256) / n_windows);
-        for (int64_t first = 0; first < n_reads; first += reads_per_launch) {
-            const int64_t n = std::min(n_reads - first, reads_per_launch);
-            const int64_t total = n * n_windows;
-            hipLaunchKernelGGL(kmer_scatter_fixed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                               bases + first * fixed_len, n, fixed_len, p);
-        }
-        return hipGetLastError();
-    }
-    const int reads_per_block = 4;
-    const int64_t reads_per_launch = (int64_t)reads_per_block << 23;
-    for (int64_t first = 0; first < n_reads; first += reads_per_launch) {
-        const int64_t n = n_reads - first < reads_per_launch ? n_reads - first : reads_per_launch;
-        const dim3 grid((unsigned)((n + reads_per_block - 1) / reads_per_block));
-        hipLaunchKernelGGL(kmer_scatter_kernel, grid, dim3(reads_per_block * kWave), 0, stream, bases, offsets + first, n, p, t,
+    if (!offsets) // (the host sends reads shorter than k to the table path)
+        return count_only ? launch_tiles<true>(bases, n_reads, fixed_len, p, stream)
+                          : launch_tiles<false>(bases, n_reads, fixed_len, p, stream);
+    return count_only ? launch_reads<true>(bases, offsets, n_reads, p, stream)
+                      : launch_reads<false>(bases, offsets, n_reads, p, stream);
+}
+
+// sampled[] -> ctl[] = {first place, end} of every bucket; total[0] = the records there is room for.  partial: a word
+// per 1024 buckets.
+hipError_t launch_kmer_place_buckets(const KmerBulk &p, unsigned long long *partial, unsigned long long *total,
+                                     hipStream_t stream)
+{
+    const unsigned n_blocks = (1u << p.log2_buckets) / kScanBlock; // (at least 2^10 buckets)
+    hipLaunchKernelGGL(kmer_caps_partial_kernel, dim3(n_blocks), dim3(256), 0, stream, p, partial);
+    hipLaunchKernelGGL(kmer_caps_scan_kernel, dim3(1), dim3(256), 0, stream, partial, n_blocks, total);
+    hipLaunchKernelGGL(kmer_caps_place_kernel, dim3(n_blocks), dim3(256), 0, stream, p, partial);
+    return hipGetLastError();
+}
+
+hipError_t launch_kmer_bucket_count(const KmerBulk &p, unsigned long long *hist, unsigned long long hist_len,
+                                    unsigned long long *stats, unsigned long long *big, unsigned long long big_cap,
+                                    unsigned *later, unsigned *later_list, unsigned long long *to_table, unsigned *to_table_list,
+                                    int n_cu, hipStream_t stream)
+{
+    // a wave per bucket, three workgroups of four per CU (52 KB of LDS each); then a workgroup per bucket left over
+    hipLaunchKernelGGL(kmer_wave_count_kernel, dim3((unsigned)(3 * n_cu)), dim3(256), 0, stream, p, hist, hist_len, stats, big,
+                       big_cap, later, later_list);
+    hipLaunchKernelGGL(kmer_bucket_count_kernel, dim3((unsigned)(3 * n_cu)), dim3(256), 0, stream, p, hist, hist_len, stats, big,
+                       big_cap, later, later_list, to_table, to_table_list);
+    return hipGetLastError();
+}
+
+hipError_t launch_kmer_to_table(const KmerBulk &p, unsigned long long n_overflowed, const KmerTable &t, int *overflow,
+                                const unsigned long long *to_table, const unsigned *to_table_list, hipStream_t stream)
+{
+    if (n_overflowed > 0) {
+        const unsigned long long blocks = std::min<unsigned long long>((n_overflowed + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(kmer_overflow_to_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n_overflowed, t,
                            overflow);
     }
-    return hipGetLastError();
-}
-
-hipError_t launch_kmer_fallback_bound(const KmerBulk &p, unsigned long long *out, hipStream_t stream)
-{
-    hipLaunchKernelGGL(kmer_fallback_bound_kernel, dim3(1024), dim3(256), 0, stream, p, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_kmer_overflow_to_table(const KmerBulk &p, unsigned long long n, const KmerTable &t, int *overflow,
-                                         hipStream_t stream)
-{
-    if (n == 0)
-        return hipSuccess;
-    const unsigned long long blocks = std::min<unsigned long long>((n + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(kmer_overflow_to_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n, t, overflow);
-    return hipGetLastError();
-}
-
-hipError_t launch_kmer_bucket_count(const KmerBulk &p, const KmerTable &t, int *overflow, unsigned long long *hist,
-                                    unsigned long long hist_len, unsigned long long *stats, unsigned long long *big,
-                                    unsigned long long big_cap, int n_workgroups, hipStream_t stream)
-{
-    hipLaunchKernelGGL(kmer_bucket_count_kernel, dim3((unsigned)n_workgroups), dim3(256), 0, stream, p, t, overflow, hist, hist_len,
-                       stats, big, big_cap);
+    hipLaunchKernelGGL(kmer_buckets_to_table_kernel, dim3(2048), dim3(256), 0, stream, p, t, overflow, to_table, to_table_list);
     return hipGetLastError();
 }
 

@@ -175,6 +175,14 @@ class KmerCounts:
             self.add_device(d_bases_ptr, n_reads, read_len, stream=stream)
         return "table"
 
+    def partition_info(self):
+        """How the last partitioned count went (covest_kmer_partition_info), as a dict."""
+        out = (ctypes.c_int64 * 8)()
+        _capi.check(_capi.lib().covest_kmer_partition_info(self._handle, out), "covest_kmer_partition_info")
+        names = ("buckets", "minimizer", "sampled_1_in", "room_records", "overflowed_records", "buckets_by_workgroup",
+                 "buckets_through_table")
+        return dict(zip(names, list(out)))
+
     def clear(self, stream=None):
         """Drop every count but keep the table (a fresh `defaultdict(int)` of the same size)."""
         self._distinct = self._added = 0

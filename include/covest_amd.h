@@ -220,6 +220,11 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
  * or a few minimizers hold most of the k-mers (low-complexity input) -- count with covest_kmer_add_device then. */
 int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_reads,
                                    int64_t read_len, int64_t n_bases_total, void *stream);
+/* How the last covest_kmer_count_reads_device went (the counter still holds its result): out[0] buckets, [1] minimizer
+ * length, [2] pass 0 sampled one block of reads in this many, [3] records the buckets had room for, [4] records that
+ * found their bucket full, [5] buckets counted by a workgroup instead of a wave, [6] buckets counted through the table
+ * in HBM, [7] 0.  Diagnostics for the caller's log; no reference counterpart. */
+int covest_kmer_partition_info(const covest_kmer *c, int64_t out[8]);
 int64_t covest_kmer_slots(const covest_kmer *c);
 /* Forget every count (counts = defaultdict(int) again), keeping the table's size; asynchronous on `stream`. */
 int covest_kmer_clear(covest_kmer *c, void *stream);

@@ -259,6 +259,7 @@ def run(name, reads, k, canonical, fixed_len=None, expect=None):
         if expect:
             assert path == expect, (name, layout, path, getattr(c, "why_not_partitioned", ""))
         taken.append((name, layout, path))
+        info = c.partition_info() if path == "partitioned" else None
         # the counter is reusable: a second count of the same reads gives the same histogram, not twice the counts
         if layout == "offsets":
             c.count_reads_device(d_bases.data_ptr(), len(reads), 0, d_offsets_ptr=d_offs.data_ptr(), n_bases=int(offs[-1]))
@@ -273,6 +274,7 @@ def run(name, reads, k, canonical, fixed_len=None, expect=None):
             c.add_reads(reads[:50])      # ... and after clear() the counter is an ordinary one again
             assert c.histogram() == ko.histogram(reads[:50], k, canonical=canonical), (name, "after clear")
         c.close()
+    return info
 
 def genome_reads(n, L, g_len, err=0.01):
     genome = rng.integers(0, 4, size=g_len, dtype=np.uint8)
@@ -290,12 +292,42 @@ for k, canonical in ((21, True), (21, False), (19, True), (25, False), (31, True
 ragged = [r[:int(n)] for r, n in zip(genome_reads(4000, 150, 30000), rng.integers(0, 151, size=4000))] + ["", "ACGT"]
 run("ragged", ragged, 21, True)
 run("ragged forward", ragged, 23, False)
-# low complexity: a handful of minimizers hold everything -- buckets overflow, the table takes them, still exact
-low = ["A" * 100, "AC" * 50, "ACG" * 33 + "A", "T" * 100] * 3000 + genome_reads(2000, 100, 5000)
-run("low complexity", low, 21, True, fixed_len=100)
-# highly repetitive: 40 000 copies of 25 reads -- counts far beyond the LDS bins
-rep = genome_reads(25, 100, 2000, err=0.0) * 40000
+# low complexity: a handful of minimizers hold everything -- their buckets go to a workgroup each; one key (poly-A)
+# is seen more than 2^20 times: beyond the dense bins
+low = ["A" * 100] * 14000 + ["AC" * 50, "ACG" * 33 + "A", "T" * 100] * 3000 + genome_reads(2000, 100, 5000)
+info = run("low complexity", low, 21, True, fixed_len=100)
+assert info["buckets_by_workgroup"] > 0, info
+# highly repetitive: 12 000 copies of 25 reads -- counts beyond the LDS bins
+rep = genome_reads(25, 100, 2000, err=0.0) * 12000
 run("repeats", rep, 21, True, fixed_len=100)
+# enough reads for pass 0 to SAMPLE them (one block of 1920 bytes / one read in 16)
+many = genome_reads(100000, 100, 200000)
+info = run("sampled", many, 21, True, fixed_len=100, expect="partitioned")
+assert info["sampled_1_in"] == 16, info
+# ... and a sample that misleads: outside the sampled blocks, one read in 20 is a copy of the same one -- its buckets
+# get far more records than they were given room for, overflow, and are counted through the table in HBM
+misled = list(many)
+block = 8 * (256 - 16)
+for r in range(len(misled)):
+    if (r * 100 // block) % 16 != 0 and ((r + 1) * 100 // block) % 16 != 0 and r % 16 != 0 and r % 20 == 1:
+        misled[r] = many[7]
+info = run("misled sample", misled, 21, True, fixed_len=100, expect="partitioned")
+assert info["overflowed_records"] > 0 and info["buckets_through_table"] > 0, info
+# one minimizer, thousands of distinct k-mers around it: more than a workgroup's LDS table holds -- to the table.
+# (white box: the m-mer hash of kmer_bulk.hip restated to find a 13-mer that wins wherever it occurs)
+def mmer_hash(code, m=13):
+    rc = 0
+    for j in range(m):
+        rc |= (3 - ((code >> (2 * j)) & 3)) << (2 * (m - 1 - j))
+    h = ((min(code, rc) + 1) * 0x9E3779B1) & 0xFFFFFFFF
+    return h ^ (h >> 15)
+cands = rng.integers(0, 4 ** 13, size=200000)
+core = int(min(cands, key=lambda c: mmer_hash(int(c))))
+core_s = "".join("ACGT"[(core >> (2 * j)) & 3] for j in range(13))
+flank = LUT[rng.integers(0, 4, size=(3000, 16), dtype=np.uint8)]
+around = ["".join(map(chr, f[:8])) + core_s + "".join(map(chr, f[8:])) for f in flank]
+info = run("one minimizer", around + genome_reads(3000, 29, 20000), 21, True, fixed_len=29, expect="partitioned")
+assert info["buckets_through_table"] > 0, info
 # k the partitioned path does not take
 run("k=12", genome_reads(3000, 60, 5000), 12, True, fixed_len=60, expect="table")
 assert any(p == "partitioned" for _, _, p in taken)
