@@ -297,9 +297,33 @@ def bench_kmer(args):
         raise SystemExit("k-mer histogram inconsistent: %d windows counted, %d expected" % (counted, n_kmers))
     partitioned = paths == {"partitioned"}
     partition = counts.partition_info() if partitioned else None
-    # algorithmic HBM bytes: every base once; table path: one 16-byte {key, count} slot per occurrence; partitioned
-    # path: one 16-byte record per run of ~(w + 1) / 2 = 6 windows, written once and read once
-    alg_bytes = 1.0 * n_reads * read_len + (2.0 * 16.0 * n_kmers / 6.0 if partitioned else 16.0 * n_kmers)
+    # What bounds either path is the rate at which the memory side retires scattered atomics -- MEASURED here, on this
+    # device, over an array the size of the one the run's atomics fall into (no constant from an earlier round): the
+    # partitioned path pays one returning add per RECORD (a cursor per bucket), the table one load + add per OCCURRENCE.
+    atomic_slots = partition["buckets"] if partitioned else counts.slots * 2
+    atomics_per_s = kh.scatter_rate(atomic_slots, ops=1 << 28)
+    if partitioned:
+        records = partition["records"]
+        scatter_s = 1e-3 * partition["ms"]["scatter"]
+        # pass 1, the dominant kernel: every base once, and per record a 16-byte {first, end}, an 8-byte cursor add and
+        # the 16-byte record
+        alg_bytes = 1.0 * n_reads * read_len + 40.0 * records
+        dominant = {"kernel": "kmer_tile_kernel<false> (pass 1: records to their buckets)", "kernel_ms_avg": 1e3 * scatter_s,
+                    "algorithmic_bytes_per_launch": alg_bytes, "achieved": alg_bytes / scatter_s / 1e9,
+                    "atomics": {"per_launch": records, "achieved_per_s": records / scatter_s,
+                                "roof_per_s_measured": atomics_per_s, "frac": records / scatter_s / atomics_per_s,
+                                "roof_slots": atomic_slots},
+                    "passes_ms": partition["ms"],
+                    "note": "bound by the memory side's scattered-atomic rate (one returning add per record, 64-byte "
+                            "requests), not by bytes: `atomics.frac` is the fraction of the rate measured in this run"}
+    else:
+        alg_bytes = 1.0 * n_reads * read_len + 16.0 * n_kmers
+        dominant = {"kernel": "kmer_count_fixed_kernel", "kernel_ms_avg": 1e3 * kernel_s,
+                    "algorithmic_bytes_per_launch": alg_bytes, "achieved": alg_bytes / kernel_s / 1e9,
+                    "atomics": {"per_launch": n_kmers, "achieved_per_s": n_kmers / kernel_s,
+                                "roof_per_s_measured": atomics_per_s, "frac": n_kmers / kernel_s / atomics_per_s,
+                                "roof_slots": atomic_slots},
+                    "note": "scattered 8-byte load/CAS + 8-byte atomic add (same line) per k-mer occurrence"}
     out = {
         "metric": "k-mers/s, canonical k=21 abundance histogram (bin/kmer_hist.py path)",
         "value": n_kmers * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": 1, "steps": args.steps,
@@ -307,20 +331,14 @@ def bench_kmer(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "C5: canonical 21-mers of %d synthetic 100-bp reads (%.2f Gbp, 40x of a random "
                                "genome, 1%% substitutions)" % (n_reads, n_reads * read_len / 1e9),
-                   "kernel": "kmer_scatter + kmer_bucket_count (partitioned)" if partitioned else "kmer_count (table of %d slots)" % counts.slots,
+                   "kernel": "partitioned: kmer_tile (pass 0/1) + kmer_wave_count / kmer_bucket_count (pass 2)" if partitioned
+                             else "kmer_count (table of %d slots)" % counts.slots,
                    "path": sorted(paths), "why_not_partitioned": getattr(counts, "why_not_partitioned", None),
-                   "partition": partition,
+                   "partition": partition, "device_ms_per_step": 1e3 * kernel_s,
                    "distinct_kmers": distinct, "windows_counted": counted,
                    "hist_head": hist[:6], "hist_peak": int(np.argmax(hist[5:]) + 5) if len(hist) > 6 else None},
-        "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": alg_bytes / kernel_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "kmer_scatter_fixed_kernel + kmer_bucket_count_kernel" if partitioned else "kmer_count_fixed_kernel",
-                     "kernel_ms_avg": 1e3 * kernel_s, "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": ("what binds the partitioned path is not bandwidth: pass 1 pays one returning atomic on a bucket "
-                              "cursor per record (k-mers / 6) and ~100 integer instructions per window for the minimizer, pass 2 "
-                              "one LDS compare-and-swap and one LDS add per k-mer") if partitioned else
-                             ("scattered 8-byte load/CAS + 8-byte atomic add (same line) per k-mer: the memory side retires "
-                              "about 2e10 such pairs a second whatever the table's size (tools/microbench_atomics.hip)")},
+        "roofline": dict({"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                          "frac": dominant["achieved"] / HBM_PEAK_GBPS, "traffic": None}, **dominant),
     }
     counts.clear(stream)  # (from_file counts through the table: an ordinary counter again)
     out["config"]["from_file"] = kmer_from_file(reads, n_reads, read_len, k, counts)

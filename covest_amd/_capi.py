@@ -28,7 +28,8 @@ EXPORTS = (
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
     "covest_kmer_create", "covest_kmer_destroy", "covest_kmer_reserve", "covest_kmer_add",
     "covest_kmer_add_device", "covest_kmer_histogram", "covest_kmer_slots", "covest_kmer_clear",
-    "covest_kmer_count_reads_device", "covest_kmer_partition_info",
+    "covest_kmer_count_reads_device", "covest_kmer_partition_info", "covest_kmer_partition_ms",
+    "covest_kmer_scatter_rate",
     "covest_reads_open", "covest_reads_close", "covest_reads_next", "covest_reads_bytes",
     "covest_thin_histogram", "covest_thin_histogram_timed",
 )
@@ -138,6 +139,10 @@ def lib():
     L.covest_kmer_count_reads_device.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     L.covest_kmer_partition_info.restype = ctypes.c_int
     L.covest_kmer_partition_info.argtypes = [vp, i64p]
+    L.covest_kmer_partition_ms.restype = ctypes.c_int
+    L.covest_kmer_partition_ms.argtypes = [vp, dp]
+    L.covest_kmer_scatter_rate.restype = ctypes.c_int
+    L.covest_kmer_scatter_rate.argtypes = [i32, i64, i64, dp]
     L.covest_kmer_histogram.restype = ctypes.c_int
     L.covest_kmer_histogram.argtypes = [vp, i64p, i64, i64p, i64p]
     L.covest_kmer_clear.restype = ctypes.c_int

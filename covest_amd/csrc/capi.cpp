@@ -2067,6 +2067,8 @@ struct covest_kmer {
     unsigned bulk_later_n = 0;              // buckets a workgroup (not a wave) counted
     unsigned long long bulk_to_table_n = 0; // buckets counted through the table in HBM
     bool bulk_table_used = false;           // ... and whether the table holds anything of the result
+    hipEvent_t bulk_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // start, placed, scattered, counted, done
+    float bulk_ms[4] = {0, 0, 0, 0};
     std::mutex lock;
 };
 
@@ -2171,6 +2173,11 @@ void covest_kmer_destroy(covest_kmer *c)
     c->hist.release();
     c->ws_bases.release();
     c->ws_offsets.release();
+    for (hipEvent_t &e : c->bulk_ev)
+        if (e) {
+            (void)hipEventDestroy(e);
+            e = nullptr;
+        }
     c->bulk_sampled.release();
     c->bulk_fill.release();
     c->bulk_later.release();
@@ -2432,11 +2439,16 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     unsigned long long *ctl = c->bulk_ctl.as<unsigned long long>();
     p.ovf_count = ctl;
     c->bulk = false;
+    for (hipEvent_t &e : c->bulk_ev)
+        if (!e)
+            HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(c->bulk_ev[0], st));
     // pass 0: room per bucket from the sample, the buckets' places
     HIP_TRY(hipMemsetAsync(p.sampled, 0, n_buckets * sizeof(unsigned), st));
     HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(unsigned long long), st));
     HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, p, true, st));
     HIP_TRY(launch_kmer_place_buckets(p, c->bulk_partial.as<unsigned long long>(), ctl + 2, st));
+    HIP_TRY(hipEventRecord(c->bulk_ev[1], st));
     unsigned long long room = 0;
     HIP_TRY(hipMemcpyAsync(&room, ctl + 2, sizeof(room), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2467,9 +2479,11 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
             n_cu = prop.multiProcessorCount;
     }
     HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, p, false, st));
+    HIP_TRY(hipEventRecord(c->bulk_ev[2], st));
     HIP_TRY(launch_kmer_bucket_count(p, c->bulk_hist.as<unsigned long long>(), kBulkHistLen, ctl + 4,
                                      c->bulk_big.as<unsigned long long>(), kBulkBigCap, later, later_list, to_table, to_table_list,
                                      n_cu, st));
+    HIP_TRY(hipEventRecord(c->bulk_ev[3], st));
     unsigned long long n_overflowed = 0, listed[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&n_overflowed, ctl, sizeof(n_overflowed), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(c->bulk_stats, ctl + 4, sizeof(c->bulk_stats), hipMemcpyDeviceToHost, st));
@@ -2509,6 +2523,10 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
         if (frc != COVEST_OK)
             return frc;
     }
+    HIP_TRY(hipEventRecord(c->bulk_ev[4], st));
+    HIP_TRY(hipEventSynchronize(c->bulk_ev[4]));
+    for (int i = 0; i < 4; ++i)
+        HIP_TRY(hipEventElapsedTime(&c->bulk_ms[i], c->bulk_ev[i], c->bulk_ev[i + 1]));
     c->bulk_info[0] = (int64_t)n_buckets;
     c->bulk_info[1] = p.m;
     c->bulk_info[2] = p.sample;
@@ -2529,7 +2547,64 @@ int covest_kmer_partition_info(const covest_kmer *c, int64_t out[8])
         out[i] = c->bulk_info[i];
     out[5] = (int64_t)c->bulk_later_n;
     out[6] = (int64_t)c->bulk_to_table_n;
-    out[7] = 0;
+    out[7] = (int64_t)c->bulk_stats[3];
+    return COVEST_OK;
+}
+
+int covest_kmer_partition_ms(const covest_kmer *c, double out[4])
+{
+    if (!c || !out)
+        return fail(COVEST_E_INVALID, "covest_kmer_partition_ms: bad argument");
+    if (!c->bulk)
+        return fail(COVEST_E_INVALID, "covest_kmer_partition_ms: the counter holds no covest_kmer_count_reads_device result");
+    for (int i = 0; i < 4; ++i)
+        out[i] = (double)c->bulk_ms[i];
+    return COVEST_OK;
+}
+
+int covest_kmer_scatter_rate(int32_t device, int64_t slots, int64_t ops, double *ops_per_s)
+{
+    if (slots < 1 || ops < 1 || !ops_per_s)
+        return fail(COVEST_E_INVALID, "covest_kmer_scatter_rate: bad argument");
+    {
+        const int drc = resolve_device(device, "covest_kmer_scatter_rate", &device);
+        if (drc != COVEST_OK)
+            return drc;
+    }
+    DeviceGuard dev_guard(device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
+    DevBuf words;
+    HIP_TRY(words.reserve(((size_t)slots + 1) * sizeof(unsigned long long)));
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipMemset(words.ptr, 0, ((size_t)slots + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipEventCreate(&a);
+    if (e == hipSuccess)
+        e = hipEventCreate(&b);
+    unsigned long long *w = words.as<unsigned long long>();
+    if (e == hipSuccess) // (once untimed: the pages are touched, the clocks are up)
+        e = launch_kmer_scatter_rate(w, (unsigned long long)slots, std::min<int64_t>(ops, 1 << 24), w + slots, nullptr);
+    if (e == hipSuccess)
+        e = hipEventRecord(a, nullptr);
+    if (e == hipSuccess)
+        e = launch_kmer_scatter_rate(w, (unsigned long long)slots, ops, w + slots, nullptr);
+    if (e == hipSuccess)
+        e = hipEventRecord(b, nullptr);
+    if (e == hipSuccess)
+        e = hipEventSynchronize(b);
+    float ms = 0.0f;
+    if (e == hipSuccess)
+        e = hipEventElapsedTime(&ms, a, b);
+    if (a)
+        (void)hipEventDestroy(a);
+    if (b)
+        (void)hipEventDestroy(b);
+    words.release();
+    if (e != hipSuccess)
+        return fail_hip(e, "covest_kmer_scatter_rate");
+    const double done = (double)(((ops + 63) / 64) * 64);
+    *ops_per_s = done / ((double)ms * 1e-3);
     return COVEST_OK;
 }
 

@@ -105,13 +105,16 @@ hipError_t launch_kmer_scatter(const unsigned char *bases, const int64_t *offset
                                const KmerBulk &p, bool count_only, hipStream_t stream);
 hipError_t launch_kmer_place_buckets(const KmerBulk &p, unsigned long long *partial, unsigned long long *total,
                                      hipStream_t stream);
-// stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len)
+// stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len), [3] records pass 1 sent
 // later: [0] buckets the wave-per-bucket kernel left to the workgroup-per-bucket one, later_list: [buckets]
 // to_table: [0] buckets no LDS table could hold, [1] their k-mer occurrences, to_table_list: [buckets]
 hipError_t launch_kmer_bucket_count(const KmerBulk &p, unsigned long long *hist, unsigned long long hist_len,
                                     unsigned long long *stats, unsigned long long *big, unsigned long long big_cap,
                                     unsigned *later, unsigned *later_list, unsigned long long *to_table, unsigned *to_table_list,
                                     int n_cu, hipStream_t stream);
+// `ops` (rounded up to 64 per thread) returning atomic adds at pseudo-random places of words[slots]
+hipError_t launch_kmer_scatter_rate(unsigned long long *words, unsigned long long slots, long long ops, unsigned long long *sink,
+                                    hipStream_t stream);
 // the overflow list's records and the listed buckets' into the table in HBM
 hipError_t launch_kmer_to_table(const KmerBulk &p, unsigned long long n_overflowed, const KmerTable &t, int *overflow,
                                 const unsigned long long *to_table, const unsigned *to_table_list, hipStream_t stream);

@@ -46,6 +46,12 @@ typedef unsigned long long u64;
 constexpr int kTile = 256;            // bytes (threads) of a tile of pass 0/1
 constexpr int kTilesPerBlock = 8;     // consecutive tiles a workgroup works through (the unit of the sample)
 constexpr unsigned kNoBucket = ~0u;
+#ifndef KMER_TILES_AT_ONCE
+#define KMER_TILES_AT_ONCE 1
+#endif
+// ... side by side (divides kTilesPerBlock).  Measured at 10 Gbp: 1 and 2 the same (18.5-18.9 ms a launch), 4 slower
+// (20.6-21.4: 80 VGPRs) -- more atomics in flight per wave buy nothing, the memory side's rate is the bound.
+constexpr int kTilesAtOnce = KMER_TILES_AT_ONCE;
 
 // ---- the bucket of a k-mer ---------------------------------------------------------------------------------------
 // m-mers as little-endian codes (base j at bits 2j).  The reverse complement of one: complement, reverse the pairs.
@@ -136,84 +142,133 @@ __device__ __forceinline__ void append_record(unsigned b, u64 code, int n_bases,
 // The read array as one run of bytes (`len` bytes a read, nothing between them): tile t covers bytes
 // [t * n_win, t * n_win + 256), its first n_win = 256 - max(16, w - 1) bytes are the window starts it answers for.
 // `positions`: bytes of this launch (whole reads, < 2^32); `avail`: bytes that may be read from `bases` on.
-template <bool COUNT>
+template <bool COUNT, int U>
 __global__ __launch_bounds__(kTile) void kmer_tile_kernel(const unsigned char *__restrict__ bases, unsigned positions,
                                                           u64 avail, unsigned len, unsigned n_tiles, const KmerBulk p)
 {
-    __shared__ unsigned hs[kTile]; // hash of the m-mer that starts at the byte
-    __shared__ unsigned cs[kTile]; // the 16 bases from the byte on
-    __shared__ unsigned bk[kTile]; // bucket of the window that starts at the byte
-    __shared__ u64 hmask[kTile / kWave], vmask[kTile / kWave];
+    // U tiles side by side (a wave that waits for the places of one tile's records would keep U times as many atomics
+    // in flight: see kTilesAtOnce for what that bought)
+    __shared__ unsigned hs[U][kTile]; // hash of the m-mer that starts at the byte
+    __shared__ unsigned cs[U][kTile]; // the 16 bases from the byte on
+    __shared__ unsigned bk[U][kTile]; // bucket of the window that starts at the byte
+    __shared__ u64 hmask[U][kTile / kWave], vmask[U][kTile / kWave];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int n_win = kTile - max(16, p.w - 1);
     const unsigned mm = (1u << (2 * p.m)) - 1u;
     const unsigned block = COUNT ? blockIdx.x * (unsigned)p.sample : blockIdx.x;
-    for (int tt = 0; tt < kTilesPerBlock; ++tt) {
-        const unsigned tile = block * kTilesPerBlock + tt;
-        if (tile >= n_tiles)
+    for (int tt = 0; tt < kTilesPerBlock; tt += U) {
+        const unsigned tile0 = block * kTilesPerBlock + tt;
+        if (tile0 >= n_tiles)
             break; // (workgroup-uniform)
-        const unsigned at = tile * (unsigned)n_win + (unsigned)tid;
-        unsigned c16 = 0;
-        if ((u64)at + 16ull <= avail) {
-            uint4 v;
-            __builtin_memcpy(&v, bases + at, 16);
-            c16 = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
-        } else {
-            for (int j = 0; j < 16; ++j)
-                if ((u64)at + (u64)j < avail)
-                    c16 |= base_code(bases[at + j]) << (2 * j);
-        }
-        const unsigned i = at % len; // place in its read
-        hs[tid] = (at < positions && i + (unsigned)p.m <= len) ? mmer_hash(mmer_canonical(c16 & mm, p.m, p.canonical)) : ~0u;
-        cs[tid] = c16;
-        __syncthreads();
-        const bool valid = tid < n_win && at < positions && i + (unsigned)p.k <= len;
-        unsigned b = kNoBucket;
-        if (valid) {
-            unsigned mn = hs[tid];
-            for (int j = 1; j < p.w; ++j) {
-                const unsigned o = hs[tid + j];
-                mn = o < mn ? o : mn;
+        bool valid[U];
+        unsigned b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned at = (tile0 + u) * (unsigned)n_win + (unsigned)tid;
+            unsigned c16 = 0;
+            if ((u64)at + 16ull <= avail) {
+                uint4 v;
+                __builtin_memcpy(&v, bases + at, 16);
+                c16 = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
+            } else {
+                for (int j = 0; j < 16; ++j)
+                    if ((u64)at + (u64)j < avail)
+                        c16 |= base_code(bases[at + j]) << (2 * j);
             }
-            b = bucket_of_min(mn, p.log2_buckets);
+            const unsigned i = at % len; // place in its read
+            const bool live = tile0 + u < n_tiles && at < positions;
+            hs[u][tid] = (live && i + (unsigned)p.m <= len) ? mmer_hash(mmer_canonical(c16 & mm, p.m, p.canonical)) : ~0u;
+            cs[u][tid] = c16;
+            valid[u] = live && tid < n_win && i + (unsigned)p.k <= len;
         }
-        bk[tid] = b;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            b[u] = kNoBucket;
+            if (valid[u]) {
+                unsigned mn = hs[u][tid];
+                for (int j = 1; j < p.w; ++j) {
+                    const unsigned o = hs[u][tid + j];
+                    mn = o < mn ? o : mn;
+                }
+                b[u] = bucket_of_min(mn, p.log2_buckets);
+            }
+            bk[u][tid] = b[u];
+        }
         __syncthreads();
         // a run starts where the window before is none (a read begins, the tile does) or belongs elsewhere
-        const bool head = valid && (tid == 0 || bk[tid - 1] != b);
-        const u64 hm = __ballot(head), vm = __ballot(valid);
-        if (lane == 0) {
-            hmask[wave] = hm;
-            vmask[wave] = vm;
+        bool head[U];
+        u64 hm[U], vm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            head[u] = valid[u] && (tid == 0 || bk[u][tid - 1] != b[u]);
+            hm[u] = __ballot(head[u]);
+            vm[u] = __ballot(valid[u]);
+            if (lane == 0) {
+                hmask[u][wave] = hm[u];
+                vmask[u][wave] = vm[u];
+            }
         }
         __syncthreads();
-        if (head) {
-            // ... and ends before the next head or the first byte that starts no window (the tile's halo counts as such)
-            int run;
-            const u64 stop = (hm | ~vm) & (lane == kWave - 1 ? 0ull : (~0ull << (lane + 1)));
-            if (stop) {
-                run = __ffsll((long long)stop) - 1 - lane;
-            } else {
-                run = kWave - lane;
-                for (int wv = wave + 1; wv < kTile / kWave; ++wv) {
-                    const u64 s2 = hmask[wv] | ~vmask[wv];
-                    if (s2) {
-                        run += __ffsll((long long)s2) - 1;
-                        break;
+        // ... and ends before the next head or the first byte that starts no window (the tile's halo counts as such).
+        // Pieces of at most max_run windows: 32 bases a record.  The FIRST piece of every run first, all tiles': their
+        // cursors' atomics are in flight together.
+        int run[U];
+        u64 le[U], pos[U], end[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            run[u] = 0;
+            if (head[u]) {
+                const u64 stop = (hm[u] | ~vm[u]) & (lane == kWave - 1 ? 0ull : (~0ull << (lane + 1)));
+                if (stop) {
+                    run[u] = __ffsll((long long)stop) - 1 - lane;
+                } else {
+                    run[u] = kWave - lane;
+                    for (int wv = wave + 1; wv < kTile / kWave; ++wv) {
+                        const u64 s2 = hmask[u][wv] | ~vmask[u][wv];
+                        if (s2) {
+                            run[u] += __ffsll((long long)s2) - 1;
+                            break;
+                        }
+                        run[u] += kWave;
                     }
-                    run += kWave;
+                }
+                if (COUNT) {
+                    atomicAdd(&p.sampled[b[u]], (unsigned)((run[u] + p.max_run - 1) / p.max_run));
+                } else {
+                    const int n_bases = min(p.max_run, run[u]) + p.k - 1;
+                    le[u] = (u64)cs[u][tid] | ((u64)cs[u][tid + 16] << 32);
+                    if (n_bases < 32)
+                        le[u] &= (1ull << (2 * n_bases)) - 1ull;
+                    const ulonglong2 place = p.ctl[b[u]];
+                    end[u] = place.y;
+                    pos[u] = place.x + (u64)atomicAdd(&p.fill[b[u]], (KmerBulk::fill_t)1);
                 }
             }
-            for (int off = 0; off < run; off += p.max_run) { // pieces of at most max_run windows: 32 bases a record
-                const int a = tid + off;
-                const int n_bases = min(p.max_run, run - off) + p.k - 1;
-                u64 le = (u64)cs[a] | ((u64)cs[a + 16] << 32);
-                if (n_bases < 32)
-                    le &= (1ull << (2 * n_bases)) - 1ull;
-                append_record<COUNT>(b, le, n_bases, p);
-            }
         }
-        __syncthreads(); // (the arrays are the next tile's)
+        if (!COUNT) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (head[u]) {
+                    const ulonglong2 rec = make_ulonglong2(le[u], (u64)(min(p.max_run, run[u]) + p.k - 1));
+                    if (pos[u] < end[u]) {
+                        p.recs[pos[u]] = rec;
+                    } else { // the bucket is full: the record goes to the list, and the WHOLE bucket to the table later
+                        const u64 o = atomicAdd(p.ovf_count, 1ull);
+                        if (o < p.overflow_cap)
+                            p.overflow[o] = rec;
+                    }
+                    for (int off = p.max_run; off < run[u]; off += p.max_run) { // (a run of more than max_run windows)
+                        const int a = tid + off;
+                        const int n_bases = min(p.max_run, run[u] - off) + p.k - 1;
+                        u64 more = (u64)cs[u][a] | ((u64)cs[u][a + 16] << 32);
+                        if (n_bases < 32)
+                            more &= (1ull << (2 * n_bases)) - 1ull;
+                        append_record<false>(b[u], more, n_bases, p);
+                    }
+                }
+        }
+        __syncthreads(); // (the arrays are the next tiles')
     }
 }
 
@@ -385,38 +440,65 @@ constexpr int kLdsSlots = 4096;      // LDS hash table of a workgroup: 32 KB of 
 constexpr int kLdsHistBins = 1024;   // count-of-counts bins kept in LDS per workgroup
 constexpr u64 kLdsEmpty = ~0ull;
 
-// the key a k-mer is counted under in the LDS tables (any one-to-one function of the reference's key does)
-__device__ __forceinline__ u64 lds_key(u64 le, const KmerBulk &p)
+// The key a k-mer is counted under in the LDS tables: any one-to-one function of the reference's key does -- the
+// smaller of the window's little-endian code and its reverse complement's.  The reverse complement of the RECORD once
+// (complement, reverse the pairs), its windows are then shifts of it.
+__device__ __forceinline__ u64 record_revcomp(ulonglong2 rec)
 {
-    if (!p.canonical)
-        return le;
-    u64 h, rc;
-    codes_from_le(le, p.k, h, rc);
-    return rc < h ? rc : h;
+    if (rec.y == 0)
+        return 0ull;
+    u64 r = __brevll(~rec.x);
+    r = ((r & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((r & 0x5555555555555555ull) << 1);
+    return r >> (64 - 2 * (int)rec.y);
 }
 
 __device__ __forceinline__ unsigned lds_slot(u64 key, unsigned smask)
 {
-    const unsigned x = ((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA77u);
+    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+    const unsigned x = (lo ^ (hi << 15) ^ (hi >> 5) ^ (hi << 27)) * 0x9E3779B1u;
     return (x >> 12) & smask;
 }
 
-// true: counted
-__device__ __forceinline__ bool lds_insert(u64 *keys, unsigned *cnts, unsigned slots, u64 key)
+// Every k-mer of the lane's record (none: rec.y == 0) into the table, false: the table is full.  The lanes of a wave
+// go through their records side by side but each at its own pace -- ONE flat loop, a probe per turn: a lane whose probe
+// hit counts and moves on to its next k-mer while its neighbours still probe (nested loops -- k-mers outside, probes
+// inside -- cost three scalar instructions of mask bookkeeping per vector instruction).
+__device__ __forceinline__ bool insert_record(ulonglong2 rec, u64 *keys, unsigned *cnts, unsigned slots, u64 kmask,
+                                              const KmerBulk &p)
 {
     const unsigned smask = slots - 1u;
-    unsigned at = lds_slot(key, smask);
-    for (unsigned probe = 0; probe < slots; ++probe) {
-        u64 cur = keys[at];
-        if (cur == kLdsEmpty)
-            cur = atomicCAS(&keys[at], kLdsEmpty, key);
-        if (cur == kLdsEmpty || cur == key) {
-            atomicAdd(&cnts[at], 1u);
-            return true;
-        }
-        at = (at + 1u) & smask;
+    int left = rec.y ? (int)rec.y - p.k + 1 : 0;                 // k-mers to go (< 0: gave up); window j of the record is
+    const u64 rc = p.canonical ? record_revcomp(rec) : 0ull;     // window n_k - 1 - j of its reverse complement
+    u64 f = rec.x;
+    u64 key = f & kmask;
+    if (p.canonical) {
+        const u64 r = (rc >> (2 * max(left - 1, 0))) & kmask;
+        key = r < key ? r : key;
     }
-    return false;
+    unsigned at = lds_slot(key, smask), probes = 0;
+    while (__ballot(left > 0) != 0ull) {
+        if (left > 0) {
+            // (no look before the compare-and-swap: one LDS round trip a probe instead of two -- measured, 10 % of pass 2)
+            const u64 cur = atomicCAS(&keys[at], kLdsEmpty, key);
+            if (cur == kLdsEmpty || cur == key) {
+                atomicAdd(&cnts[at], 1u);
+                f >>= 2;
+                --left;
+                key = f & kmask;
+                if (p.canonical) {
+                    const u64 r = (rc >> (2 * max(left - 1, 0))) & kmask;
+                    key = r < key ? r : key;
+                }
+                at = lds_slot(key, smask);
+                probes = 0;
+            } else {
+                at = (at + 1u) & smask;
+                if (++probes >= slots) // every slot holds another key
+                    left = -1;
+            }
+        }
+    }
+    return left == 0;
 }
 
 struct SweepAcc {
@@ -457,7 +539,8 @@ __device__ __forceinline__ void flush_stats(SweepAcc acc, const unsigned *bins, 
     }
 }
 
-// Pass 2, a wave per bucket.  stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len).
+// Pass 2, a wave per bucket.  stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len), [3]
+// records pass 1 sent (to the buckets and to the overflow list).
 // hist: dense count-of-counts for counts < hist_len.  later[0]: buckets left to
 // kmer_bucket_count_kernel, listed in later_list.
 __global__ __launch_bounds__(256) void kmer_wave_count_kernel(const KmerBulk p, u64 *__restrict__ hist, u64 hist_len,
@@ -478,6 +561,7 @@ __global__ __launch_bounds__(256) void kmer_wave_count_kernel(const KmerBulk p, 
     }
     __syncthreads();
     SweepAcc acc;
+    u64 n_records = 0;
     const unsigned n_groups = (1u << p.log2_buckets) / kWave; // (at least 2^10 buckets)
     const unsigned n_waves = gridDim.x * (blockDim.x / kWave);
     const u64 kmask = p.k < 32 ? (1ull << (2 * p.k)) - 1ull : ~0ull;
@@ -486,6 +570,7 @@ __global__ __launch_bounds__(256) void kmer_wave_count_kernel(const KmerBulk p, 
         const unsigned b_lane = g * kWave + lane;
         const ulonglong2 c = p.ctl[b_lane];
         const u64 first = c.x, filled = p.fill[b_lane], room = c.y - c.x;
+        n_records += filled;
         const bool skip = filled > room || filled > (u64)kWaveRecs;
         const u64 skipmask = __ballot(skip);
         if (skipmask) {
@@ -497,26 +582,43 @@ __global__ __launch_bounds__(256) void kmer_wave_count_kernel(const KmerBulk p, 
                 later_list[at + __popcll(skipmask & ((1ull << lane) - 1ull))] = b_lane;
         }
         u64 todo = __ballot(!skip && filled > 0);
+        u64 s_next = 0;
+        unsigned n_next = 0;
+        int l_next = 0;
+        ulonglong2 rec = make_ulonglong2(0ull, 0ull);
+        if (todo) {
+            l_next = __ffsll((long long)todo) - 1;
+            s_next = __shfl(first, l_next, kWave);
+            n_next = (unsigned)__shfl((unsigned)filled, l_next, kWave);
+            if ((unsigned)lane < n_next)
+                rec = p.recs[s_next + lane];
+        }
         while (todo) {
-            const int l = __ffsll((long long)todo) - 1;
+            const int l = l_next;
+            const u64 s_b = s_next;
+            const unsigned n_b = n_next;
             todo &= todo - 1ull;
-            const u64 s_b = __shfl(first, l, kWave);
-            const unsigned n_b = (unsigned)__shfl((unsigned)filled, l, kWave);
+            n_next = 0;
+            if (todo) {
+                l_next = __ffsll((long long)todo) - 1;
+                s_next = __shfl(first, l_next, kWave);
+                n_next = (unsigned)__shfl((unsigned)filled, l_next, kWave);
+            }
             unsigned slots = 64;
             while (slots < 8u * n_b && slots < (unsigned)kWaveSlots)
                 slots <<= 1;
             bool ok = true;
             for (unsigned i0 = 0; i0 < n_b; i0 += kWave) {
-                ulonglong2 rec = make_ulonglong2(0ull, 0ull);
-                if (i0 + lane < n_b)
-                    rec = p.recs[s_b + i0 + lane];
-                const int n_k = rec.y ? (int)rec.y - p.k + 1 : 0;
-                for (int j = 0; j < p.max_run; ++j) {
-                    if (!__ballot(j < n_k))
-                        break;
-                    if (j < n_k)
-                        ok = lds_insert(keys, cnts, slots, lds_key((rec.x >> (2 * j)) & kmask, p)) && ok;
-                }
+                // the records after these -- the bucket's next 64, or the first of the next bucket -- are on their way
+                // while these are counted
+                const bool last = i0 + kWave >= n_b;
+                const u64 from = last ? s_next : s_b + i0 + kWave;
+                const unsigned have = last ? n_next : n_b - (i0 + kWave);
+                ulonglong2 rec_next = make_ulonglong2(0ull, 0ull);
+                if ((unsigned)lane < have)
+                    rec_next = p.recs[from + lane];
+                ok = insert_record(rec, keys, cnts, slots, kmask, p) && ok;
+                rec = rec_next;
             }
             const bool failed = __ballot(!ok) != 0ull; // more distinct keys than slots: a workgroup takes the bucket
             for (unsigned i = lane; i < slots; i += kWave) {
@@ -534,6 +636,10 @@ __global__ __launch_bounds__(256) void kmer_wave_count_kernel(const KmerBulk p, 
     }
     __syncthreads();
     flush_stats(acc, bins, hist, hist_len, stats);
+    for (int off = 32; off >= 1; off >>= 1)
+        n_records += __shfl_xor(n_records, off, kWave);
+    if (lane == 0 && n_records)
+        atomicAdd(&stats[3], n_records);
 }
 
 // Pass 2, a workgroup per bucket: those of later_list.  What does not fit here either is listed for the table in HBM
@@ -576,8 +682,7 @@ __global__ __launch_bounds__(256) void kmer_bucket_count_kernel(const KmerBulk p
                 const ulonglong2 rec = recs[i];
                 const int n_k = (int)rec.y - p.k + 1;
                 n_kmers += (u64)n_k;
-                for (int j = 0; j < n_k && ok; ++j)
-                    ok = lds_insert(keys, cnts, slots, lds_key((rec.x >> (2 * j)) & kmask, p));
+                ok = insert_record(rec, keys, cnts, slots, kmask, p) && ok;
             }
             fall_back = __syncthreads_or(!ok) != 0;
             for (unsigned i = tid; i < slots; i += blockDim.x)
@@ -629,6 +734,23 @@ __global__ __launch_bounds__(256) void kmer_overflow_to_table_kernel(const KmerB
         record_to_table(p.overflow[i], p, t, overflow);
 }
 
+// What bounds pass 1, measured: returning 64-bit atomic adds at pseudo-random places of `slots` words -- a wave
+// instruction's 64 lanes all on different lines, as the records of a tile are.
+__global__ __launch_bounds__(256) void kmer_scatter_rate_kernel(u64 *__restrict__ words, u64 slots, int per_thread,
+                                                                u64 *__restrict__ sink)
+{
+    u64 x = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    u64 acc = 0;
+    for (int i = 0; i < per_thread; ++i) {
+        x ^= x >> 29;
+        x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 32;
+        acc += atomicAdd(&words[x % slots], 1ull);
+    }
+    if (acc == ~0ull)
+        sink[0] = acc; // (never: keeps the returned values alive)
+}
+
 template <bool COUNT>
 hipError_t launch_tiles(const unsigned char *bases, int64_t n_reads, int64_t len, const KmerBulk &p, hipStream_t stream)
 {
@@ -643,7 +765,7 @@ hipError_t launch_tiles(const unsigned char *bases, int64_t n_reads, int64_t len
         uint64_t blocks = (n_tiles + kTilesPerBlock - 1) / kTilesPerBlock;
         if (COUNT)
             blocks = (blocks + p.sample - 1) / p.sample;
-        hipLaunchKernelGGL(kmer_tile_kernel<COUNT>, dim3((unsigned)blocks), dim3(kTile), 0, stream, bases + first * len,
+        hipLaunchKernelGGL((kmer_tile_kernel<COUNT, kTilesAtOnce>), dim3((unsigned)blocks), dim3(kTile), 0, stream, bases + first * len,
                            (unsigned)positions, (u64)avail, (unsigned)len, (unsigned)n_tiles, p);
     }
     return hipGetLastError();
@@ -694,6 +816,16 @@ hipError_t launch_kmer_place_buckets(const KmerBulk &p, unsigned long long *part
     hipLaunchKernelGGL(kmer_caps_partial_kernel, dim3(n_blocks), dim3(256), 0, stream, p, partial);
     hipLaunchKernelGGL(kmer_caps_scan_kernel, dim3(1), dim3(256), 0, stream, partial, n_blocks, total);
     hipLaunchKernelGGL(kmer_caps_place_kernel, dim3(n_blocks), dim3(256), 0, stream, p, partial);
+    return hipGetLastError();
+}
+
+hipError_t launch_kmer_scatter_rate(unsigned long long *words, unsigned long long slots, long long ops, unsigned long long *sink,
+                                    hipStream_t stream)
+{
+    const int per_thread = 64;
+    const long long threads = (ops + per_thread - 1) / per_thread;
+    hipLaunchKernelGGL(kmer_scatter_rate_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, words, slots,
+                       per_thread, sink);
     return hipGetLastError();
 }
 

@@ -68,6 +68,15 @@ def preprocess(seq, nstrategy=NS_IGNORE):
     return seq
 
 
+def scatter_rate(slots, ops=1 << 28, device=0):
+    """Returning 64-bit atomic adds per second at pseudo-random places of a `slots`-word array on this device
+    (covest_kmer_scatter_rate): the measured roof of pass 1 of the partitioned path."""
+    out = ctypes.c_double()
+    _capi.check(_capi.lib().covest_kmer_scatter_rate(int(device), int(slots), int(ops), ctypes.byref(out)),
+                "covest_kmer_scatter_rate")
+    return out.value
+
+
 class KmerCounts:
     """The `counts` of compute_counts: an open-addressing table in HBM (covest_kmer*)."""
 
@@ -180,8 +189,12 @@ class KmerCounts:
         out = (ctypes.c_int64 * 8)()
         _capi.check(_capi.lib().covest_kmer_partition_info(self._handle, out), "covest_kmer_partition_info")
         names = ("buckets", "minimizer", "sampled_1_in", "room_records", "overflowed_records", "buckets_by_workgroup",
-                 "buckets_through_table")
-        return dict(zip(names, list(out)))
+                 "buckets_through_table", "records")
+        info = dict(zip(names, list(out)))
+        ms = (ctypes.c_double * 4)()
+        _capi.check(_capi.lib().covest_kmer_partition_ms(self._handle, ms), "covest_kmer_partition_ms")
+        info["ms"] = dict(zip(("place", "scatter", "count", "table"), [round(v, 4) for v in ms]))
+        return info
 
     def clear(self, stream=None):
         """Drop every count but keep the table (a fresh `defaultdict(int)` of the same size)."""

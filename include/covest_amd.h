@@ -223,8 +223,16 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
 /* How the last covest_kmer_count_reads_device went (the counter still holds its result): out[0] buckets, [1] minimizer
  * length, [2] pass 0 sampled one block of reads in this many, [3] records the buckets had room for, [4] records that
  * found their bucket full, [5] buckets counted by a workgroup instead of a wave, [6] buckets counted through the table
- * in HBM, [7] 0.  Diagnostics for the caller's log; no reference counterpart. */
+ * in HBM, [7] records pass 1 wrote.  Diagnostics for the caller's log; no reference counterpart. */
 int covest_kmer_partition_info(const covest_kmer *c, int64_t out[8]);
+/* ... and how long its steps took on the device, milliseconds (HIP events on the caller's stream): out[0] pass 0
+ * (sample of the reads, room per bucket, their places), [1] pass 1 (records to their buckets), [2] pass 2 (the buckets
+ * counted in LDS), [3] what was left for the table in HBM. */
+int covest_kmer_partition_ms(const covest_kmer *c, double out[4]);
+/* Measurement only: the rate at which THIS device retires returning 64-bit atomic adds at pseudo-random places of a
+ * `slots`-word array (the 64 lanes of a wave instruction on 64 different lines) -- what bounds pass 1 of the
+ * partitioned path (one such add per record) and, per occurrence, the table path.  `ops` adds are timed. */
+int covest_kmer_scatter_rate(int32_t device, int64_t slots, int64_t ops, double *ops_per_s);
 int64_t covest_kmer_slots(const covest_kmer *c);
 /* Forget every count (counts = defaultdict(int) again), keeping the table's size; asynchronous on `stream`. */
 int covest_kmer_clear(covest_kmer *c, void *stream);

@@ -19,7 +19,7 @@ for path in sorted(glob.glob(os.path.join(d, "*counter_collection.csv"))):
                 continue
             import re
             # kernel name with its template arguments (the tail / no-tail variants are different kernels)
-            mm = re.search(r"(ll_[a-z_]+(?:<[^>]*>)?|argmin_stage\d)", name)
+            mm = re.search(r"(ll_[a-z_]+(?:<[^>]*>)?|argmin_stage\d|kmer_[a-z_]+(?:<[^>]*>)?)", name)
             short = mm.group(1).replace(" ", "") if mm else name[:40]
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
