@@ -346,3 +346,74 @@ def test_partitioned_count_of_resident_reads(hip_lib):
     env = dict(os.environ, COVEST_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     proc = subprocess.run([sys.executable, "-c", _PARTITIONED_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0 and "partitioned ok" in proc.stdout, proc.stdout[-3000:] + proc.stderr[-4000:]
+
+
+_SCALE_SCRIPT = r"""
+import os, sys
+import torch                      # first: ONE HIP runtime per process (INTEGRATION.md 8)
+sys.path.insert(0, os.environ["COVEST_REPO"])
+from covest_amd import kmer_hist as kh
+dev = torch.device("cuda", 0)
+free, total = torch.cuda.mem_get_info()
+k, L = 21, 100
+lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+
+def synthetic_reads(n_reads, seed):
+    # 40x of a random genome, 1 % substitutions: bench.py's C5 input
+    gen = torch.Generator(device=dev); gen.manual_seed(seed)
+    g_len = max(1_000_000, n_reads * L // 40)
+    genome = lut[torch.randint(0, 4, (g_len,), device=dev, generator=gen)]
+    reads = torch.empty(n_reads * L, dtype=torch.uint8, device=dev)
+    ar = torch.arange(L, device=dev)
+    for a in range(0, n_reads, 2_000_000):
+        b = min(n_reads, a + 2_000_000)
+        starts = torch.randint(0, g_len - L, (b - a,), device=dev, generator=gen)
+        r = genome[starts[:, None] + ar[None, :]]
+        err = torch.rand(r.shape, device=dev, generator=gen) < 0.01
+        r = torch.where(err, lut[torch.randint(0, 4, r.shape, device=dev, generator=gen)], r)
+        reads[a * L:b * L] = r.reshape(-1)
+    return reads
+
+# 1 Gbp: the partitioned path and the table in HBM give the SAME histogram, bin for bin
+n = 10_000_000
+reads = synthetic_reads(n, 11)
+part = kh.KmerCounts(k, canonical=True, min_slots=1 << 20)
+assert part.count_reads_device(reads.data_ptr(), n, L) == "partitioned", getattr(part, "why_not_partitioned", "")
+h_part, d_part = part.histogram(), len(part)
+info = part.partition_info()
+assert info["sampled_1_in"] == 16 and info["records"] > n, info
+table = kh.KmerCounts(k, canonical=True, min_slots=1 << 29)
+table.add_device(reads.data_ptr(), n, L, reserve=False)
+assert table.histogram() == h_part and len(table) == d_part, "1 Gbp: partitioned != table"
+assert sum(i * v for i, v in enumerate(h_part)) == n * (L - k + 1) and sum(h_part) == d_part
+table.close(); del reads
+# 10 Gbp (BASELINE.json config 5's size): every window lands in exactly one bin, the bins add up to the distinct keys,
+# and counting twice gives the same histogram (the counter is emptied, the buckets' room is found again)
+if free < 200e9:
+    print("scale ok (10 Gbp skipped: %.0f GB of HBM free)" % (free / 1e9)); sys.exit(0)
+n = 100_000_000
+reads = synthetic_reads(n, 12)
+assert part.count_reads_device(reads.data_ptr(), n, L) == "partitioned", getattr(part, "why_not_partitioned", "")
+h10, d10 = part.histogram(), len(part)
+assert sum(i * v for i, v in enumerate(h10)) == n * (L - k + 1), "10 Gbp: windows lost or counted twice"
+assert sum(h10) == d10 and d10 > 10 * d_part // 2
+assert part.count_reads_device(reads.data_ptr(), n, L) == "partitioned"
+assert part.histogram() == h10
+peak = max(range(5, len(h10)), key=lambda i: h10[i])
+assert 20 <= peak <= 36, peak        # 40x coverage, 80 of 100 windows a read, 19 % of them hit by an error: ~26
+print("scale ok", info, part.partition_info())
+"""
+
+
+def test_partitioned_at_scale(hip_lib):
+    """covest_kmer_count_reads_device at sizes no oracle reaches.  1 Gbp (8e8 windows): the histogram equals, bin for
+    bin, the one of the open-addressing table in HBM (rounds 1-2, itself checked against the oracle at small sizes).
+    10 Gbp (8e9 windows, BASELINE.json config 5; skipped below 200 GB of free HBM): conservation -- sum_i i*h_i = the
+    windows, sum_i h_i = the distinct keys --, a second count reproduces the histogram, the coverage peak sits where
+    the input puts it."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, COVEST_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    proc = subprocess.run([sys.executable, "-c", _SCALE_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0 and "scale ok" in proc.stdout, proc.stdout[-3000:] + proc.stderr[-4000:]
