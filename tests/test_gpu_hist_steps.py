@@ -114,16 +114,25 @@ def test_result_record(hip_lib, kind):
 
 
 @pytest.mark.parametrize("model", ["basic", "repeats"])
-def test_whole_default_flow(hip_lib, model):
-    """covest_amd.pipeline.estimate == covest.covest.main on the reference's own test histogram (file in,
-    record out): the guess and its likelihood to 1e-9, the optimum's likelihood to 1e-9; where L-BFGS-B stops on
-    the flat optimum depends on rounding noise in the finite differences (coverage to 2e-3, genome size to 0.1 %,
-    and for the repeats model only the likelihood pins the weakly determined q's)."""
+def test_whole_default_flow(hip_lib, oracle, model):
+    """covest_amd.pipeline.estimate against covest.covest.main on the reference's own test histogram (file in, record
+    out).  Deterministic parts to the letter: the guess (host arithmetic, bit-identical), its likelihood (1e-9), and
+    the likelihood AT THE REFERENCE'S OPTIMUM, evaluated here (1e-9).  The optimum itself is where L-BFGS-B stops on a
+    flat ridge, finite differences with step 1e-8 of values near 3.7e6: the last bits of the likelihood decide the
+    path, the reference's run and this library's need not take the same one.  What must hold whatever the path: this
+    run's optimum is NO WORSE than the reference's by the reference's own likelihood (the oracle's value of it, which
+    the GPU value equals to 1e-9), and the well-determined parameters agree (coverage to 0.5 %, error rate to 1 %,
+    genome size to 0.5 %; for the repeats model the q's are weakly determined and only the likelihood pins them).
+    On this histogram the repeats run of round 3 ends 5.05 ABOVE the reference's (-3678677.53 against -3678682.58, at
+    coverage 10.0002 against 10.0184: the data were simulated at 10); the basic run ends on the reference's value."""
     import os
     from conftest import GOLDEN
+    from covest_amd import constants, hist_steps as hs
+    from covest_amd.models import select_model
     from covest_amd.pipeline import estimate
     want = G["end_to_end"][model]
-    rec = estimate(os.path.join(GOLDEN, "sim_c10_e0.05.hist"), model=model)
+    path = os.path.join(GOLDEN, "sim_c10_e0.05.hist")
+    rec = estimate(path, model=model)
     rec.pop("version")
     assert set(rec) == set(want)
     for key in ("model", "hist_size", "sample_factor", "orig_sample_factor", "starting_points", "use_grid_search", "success"):
@@ -131,7 +140,22 @@ def test_whole_default_flow(hip_lib, model):
     for key in ("guessed_coverage", "guessed_error_rate"):
         assert rec[key] == want[key], key  # host arithmetic: bit-identical
     assert rel_err(rec["guessed_loglikelihood"], want["guessed_loglikelihood"]) <= TOL
-    assert rel_err(rec["loglikelihood"], want["loglikelihood"]) <= TOL
-    assert abs(rec["coverage"] - want["coverage"]) <= 2e-3 and abs(rec["error_rate"] - want["error_rate"]) <= 1e-5
+    # the same model the flow built, evaluated at both optima on the GPU and by the oracle
+    hist_orig, _ = hs.load_histogram(path)
+    hist, tail, _, _, _ = hs.process_histogram(hist_orig, constants.DEFAULT_K, constants.DEFAULT_READ_LENGTH)
+    m = select_model(model)(constants.DEFAULT_K, constants.DEFAULT_READ_LENGTH, hist, tail, max_error=constants.MAX_ERRORS,
+                            min_single_copy_ratio=constants.DEFAULT_MIN_SINGLECOPY_RATIO)
+    om = oracle.OracleModel(model, constants.DEFAULT_K, constants.DEFAULT_READ_LENGTH, hist, tail,
+                            max_error=constants.MAX_ERRORS)
+    names = ("coverage", "error_rate", "q1", "q2", "q")[:m.param_count]
+    theirs = [want[n] for n in names]
+    ours = [rec[n] for n in names]
+    assert rel_err(m.compute_loglikelihood(*theirs), want["loglikelihood"]) <= TOL      # value parity at THEIR optimum
+    assert rel_err(m.compute_loglikelihood(*ours), rec["loglikelihood"]) <= 1e-12        # the record reports its own point
+    ref_at_theirs, ref_at_ours = om.compute_loglikelihood_many(np.array([theirs, ours]), n_threads=2)
+    assert rel_err(ref_at_theirs, want["loglikelihood"]) <= TOL
+    assert rel_err(ref_at_ours, rec["loglikelihood"]) <= TOL                             # value parity at OUR optimum
+    assert ref_at_ours >= ref_at_theirs - TOL * abs(ref_at_theirs), (ref_at_ours, ref_at_theirs)   # no worse an optimum
+    assert abs(rec["coverage"] / want["coverage"] - 1.0) <= 5e-3 and abs(rec["error_rate"] / want["error_rate"] - 1.0) <= 1e-2
     assert rec["orig_coverage"] == rec["coverage"]
-    assert abs(rec["genome_size"] / want["genome_size"] - 1.0) <= 1e-3
+    assert abs(rec["genome_size"] / want["genome_size"] - 1.0) <= 5e-3

@@ -30,10 +30,17 @@ if [ -f tools/bin/libcovest_amd_diag.so ]; then
 fi
 timeout -k 10 100 python3 tools/time_host.py > "$out/time_to_argmin_split.txt" 2>&1
 # the rows either side of the path, the shapes that used to fall back, the microbenchmarks behind DESIGN's rooflines
-timeout -k 10 300 python3 bench.py --workload c5 --kmer-gbp 1 --steps 5 --warmup 1 > "$out/bench_c5_1gbp.json" 2> "$out/bench_c5.err"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c5" -o c5 -- python3 bench.py --workload c5 --kmer-gbp 1 --steps 3 --warmup 1 --cpu-budget 0 > /dev/null 2> "$out/trace_c5.err"
-find "$out/trace_c5" -name "*kernel_stats.csv" -exec cp {} "$out/c5_kernel_stats.csv" \;
-rm -rf "$out/trace_c5"
+for g in 1 10; do
+  timeout -k 10 400 python3 bench.py --workload c5 --kmer-gbp $g --steps 3 --warmup 1 > "$out/bench_c5_${g}gbp.json" 2> "$out/bench_c5_$g.err"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c5_$g" -o c5 -- python3 bench.py --workload c5 --kmer-gbp $g --steps 3 --warmup 1 --cpu-budget 0 > /dev/null 2> "$out/trace_c5_$g.err"
+  find "$out/trace_c5_$g" -name "*kernel_stats.csv" -exec cp {} "$out/c5_${g}gbp_kernel_stats.csv" \;
+  rm -rf "$out/trace_c5_$g"
+done
+# the table path of rounds 1-2 on the same input, for the comparison in DESIGN 6b
+timeout -k 10 400 python3 bench.py --workload c5 --kmer-gbp 10 --kmer-path table --steps 2 --warmup 1 --cpu-budget 0 > "$out/bench_c5_10gbp_table_path.json" 2> "$out/bench_c5_table.err"
+bash tools/pmc_profile.sh "$out/pmc_c5" --workload c5 --kmer-gbp 1 --steps 2 --warmup 1 > "$out/pmc_c5.log" 2>&1
+python3 tools/pmc_summary.py "$out/pmc_c5" kmer_ > "$out/c5_1gbp_pmc_summary.json"
+find "$out/pmc_c5" -name "*.csv" -size +2000k -delete
 timeout -k 10 200 python3 bench.py --workload f2 > "$out/bench_f2.json" 2> "$out/bench_f2.err"
 timeout -k 10 100 python3 bench.py --workload f3 > "$out/bench_f3.json" 2> "$out/bench_f3.err"
 timeout -k 10 200 python3 tools/time_cliffs.py > "$out/cliffs.txt" 2>&1
