@@ -634,6 +634,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     // (the assignment fixes the order of a point's sums: the shipped library takes the constants of tiles.h, only a
     // diagnostic build -- tiles.h -- lets the environment override them for tuning sweeps)
     int unit_overhead = kUnitOverhead, build_cost = kBuildCost, shared_div = kSharedStepsPerMfma;
+    int last_builder_extra = kLastBuilderExtra;
     // (with a tail an item may stand for up to 32 count-less tiles, tiles.h: the builders walk every one of them
     // while the contraction sees one item -- charge them for the tiles an item holds on average)
     if (m->has_tiles && m->tv.n_items > 0)
@@ -645,6 +646,8 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         build_cost = std::atoi(v);
     if (const char *v = std::getenv("COVEST_FACTORED_SHARED_DIV"))
         shared_div = std::max(1, std::atoi(v));
+    if (const char *v = std::getenv("COVEST_FACTORED_LAST_BUILDER_EXTRA"))
+        last_builder_extra = std::atoi(v);
 #endif
     const size_t n_unit = (size_t)n_qblocks * nw * mu;
     std::vector<int32_t> unit_tile(n_unit, -1), unit_half(n_unit, 0), unit_s0(n_unit, 0), unit_o0(n_unit, 1),
@@ -667,8 +670,11 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         std::vector<long> bin_load((size_t)n_bins, 0), wave_load((size_t)nw, 0);
         if (n_buf == 2) // builders contract less: they fill the next key tile in the same interval
             for (int w = 0; w < nw && w * 64 < n_columns; ++w) {
-                bin_load[(size_t)(w % n_bins)] += build_cost;
-                wave_load[(size_t)w] += build_cost;
+                // (the builder of the TOP copy numbers is the wave every interval waits for -- the stamps of round 3:
+                // its streams stay live over the widest range of keys, and it shares its SIMD with another builder)
+                const int cost = build_cost + (((w + 1) * 64 >= n_columns && w >= n_bins) ? last_builder_extra : 0);
+                bin_load[(size_t)(w % n_bins)] += cost;
+                wave_load[(size_t)w] += cost;
             }
         std::vector<std::vector<Unit>> held((size_t)nw);
         for (const Unit &u : units) {

@@ -446,6 +446,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // With two buffers the builders fill item t+1 while every wave contracts item t: one barrier per item, and the
     // host's unit assignment charges the builders for phase A.  ONE loop for both set-ups (and ONE copy of phase A in
     // the code: three used to be inlined): interval t builds item `tb` and contracts item t.
+    // (Measured and not kept, round 3: no barrier between the items but two counters per buffer in LDS -- builder waves
+    // that have filled it, waves that are done with it -- so that a wave may run an item ahead: 0.846-0.849 against
+    // 0.831-0.832 ms; the polling costs more than the hardware barrier's lock step, whose waits are 10 % of the kernel.)
     const bool dbuf = plan.n_buf == 2;
     // the rows' constants of the item an interval builds are fetched one interval ahead (32 lanes of wave 0; the two
     // or three loads are independent and have a whole interval to arrive)

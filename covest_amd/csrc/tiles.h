@@ -114,6 +114,7 @@ constexpr int kListSegments = 8;   // key segments of a point-list evaluation (l
 constexpr int kMinPieceSteps = 6;  // pieces are not made shorter than this
 constexpr int kSharedStepsPerMfma = 5; // cost of the shared steps in the assignment: this many weigh one MFMA step
 constexpr int kMinSharedSteps = 3; // fewer shared steps than this are left to the MFMA steps
+constexpr int kLastBuilderExtra = 4; // extra charge of the builder of the top copy numbers when it shares a SIMD with another builder
 constexpr int kUnitOverhead = 2;   // per-unit cost besides its MFMA steps (logs, setup), same unit
 
 struct FactoredPlan {
