@@ -225,9 +225,28 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
     }
 }
 
+// The winner where it is wanted: in HBM (the ranks' exchange reads it there) and, when the caller gave one, in a
+// page-locked HOST mirror -- the kernel's own store, visible once the stream is synchronised: no copy launch and no
+// staging for 16 bytes.
+__device__ __forceinline__ void publish(Cand c, int64_t flat_begin, ArgminResult *__restrict__ result,
+                                        ArgminResult *__restrict__ host_mirror)
+{
+    ArgminResult r;
+    r.min_negll = c.v;
+    r.index = (c.i == INT64_MAX) ? -1 : c.i;
+    // the same as a pair of doubles with the GLOBAL flat index, for the cross-GPU exchange (flat indices
+    // stay below 2^53)
+    r.pair[0] = c.v;
+    r.pair[1] = (c.i == INT64_MAX) ? -1.0 : (double)(flat_begin + c.i);
+    *result = r;
+    if (host_mirror)
+        *host_mirror = r;
+}
+
 __global__ __launch_bounds__(256) void argmin_stage2(const double *__restrict__ pv,
                                                      const int64_t *__restrict__ pi, int n_part, int64_t flat_begin,
-                                                     ArgminResult *__restrict__ result, unsigned *__restrict__ queue_count)
+                                                     ArgminResult *__restrict__ result, ArgminResult *__restrict__ host_mirror,
+                                                     unsigned *__restrict__ queue_count)
 {
     if (threadIdx.x == 0 && queue_count)
         *queue_count = 0; // the hand-back queue of the launch before (drained by ll_fix_list_kernel) starts empty again
@@ -241,14 +260,30 @@ __global__ __launch_bounds__(256) void argmin_stage2(const double *__restrict__ 
         c = better(c, o);
     }
     c = block_best(c);
-    if (threadIdx.x == 0) {
-        result->min_negll = c.v;
-        result->index = (c.i == INT64_MAX) ? -1 : c.i;
-        // the same as a pair of doubles with the GLOBAL flat index, for the cross-GPU exchange (flat indices
-        // stay below 2^53)
-        result->pair[0] = c.v;
-        result->pair[1] = (c.i == INT64_MAX) ? -1.0 : (double)(flat_begin + c.i);
+    if (threadIdx.x == 0)
+        publish(c, flat_begin, result, host_mirror);
+}
+
+// A small grid (optimize_grid's have a few thousand points, C1 2 500): both stages in ONE workgroup and one launch.
+__global__ __launch_bounds__(256) void argmin_small(const double *__restrict__ ll, int64_t n, int64_t flat_begin,
+                                                    ArgminResult *__restrict__ result, ArgminResult *__restrict__ host_mirror,
+                                                    unsigned *__restrict__ queue_count)
+{
+    if (threadIdx.x == 0 && queue_count)
+        *queue_count = 0;
+    Cand c;
+    c.v = INFINITY;
+    c.i = INT64_MAX;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { // ascending i within a thread: strict < keeps the first
+        const double v = -ll[i];
+        if (v < c.v) {
+            c.v = v;
+            c.i = i;
+        }
     }
+    c = block_best(c);
+    if (threadIdx.x == 0)
+        publish(c, flat_begin, result, host_mirror);
 }
 
 } // namespace
@@ -268,13 +303,17 @@ hipError_t launch_ll_fix_list(const DevModel &m, const TileView &tv, const Point
 }
 
 hipError_t launch_argmin(const double *ll, int64_t n, int64_t flat_begin, double *partial_val, int64_t *partial_idx,
-                         ArgminResult *result, unsigned *queue_count, hipStream_t stream)
+                         ArgminResult *result, ArgminResult *host_mirror, unsigned *queue_count, hipStream_t stream)
 {
+    if (n <= kArgminSmall) {
+        hipLaunchKernelGGL(argmin_small, dim3(1), dim3(256), 0, stream, ll, n, flat_begin, result, host_mirror, queue_count);
+        return hipGetLastError();
+    }
     // (a small grid needs no more workgroups than it has waves of points)
     const int blocks = (int)std::min<int64_t>(kArgminBlocks, std::max<int64_t>(1, (n + 255) / 256));
     hipLaunchKernelGGL(argmin_stage1, dim3(blocks), dim3(256), 0, stream, ll, n, partial_val, partial_idx);
     hipLaunchKernelGGL(argmin_stage2, dim3(1), dim3(256), 0, stream, partial_val, partial_idx, blocks, flat_begin, result,
-                       queue_count);
+                       host_mirror, queue_count);
     return hipGetLastError();
 }
 

@@ -147,6 +147,7 @@ struct covest_grid {
     const char *last_kernel = "none";
     int last_kernel_id = 0;
     hipStream_t last_stream = nullptr;
+    ArgminResult *result_host = nullptr; // page-locked mirror of `result`
     bool evaluated = false;
     bool configured = false; // false while (and after) a covest_grid_reset failed half way: the views may dangle
     // optional hipEvent bracketing of the likelihood kernel
@@ -1874,6 +1875,10 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
 
 static void grid_release(covest_grid *g)
 {
+    if (g->result_host) {
+        (void)hipHostFree(g->result_host);
+        g->result_host = nullptr;
+    }
     g->arena.release();
     g->plan_buf.release();
     for (covest_grid::Part &part : g->long_parts)
@@ -2005,8 +2010,10 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
     g->last_kernel_id = kern;
     if (e1)
         HIP_TRY(hipEventRecord(e1, st));
+    if (!g->result_host) // (page-locked, mapped: argmin_stage2 stores the winner there itself)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->result_host), sizeof(ArgminResult), hipHostMallocMapped));
     HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->flat_begin, g->partial_val.as<double>(),
-                          g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), g->sub_ctl.as<unsigned>(), st));
+                          g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), g->result_host, g->sub_ctl.as<unsigned>(), st));
     g->last_stream = st;
     g->evaluated = true;
     return COVEST_OK;
@@ -2022,9 +2029,8 @@ int covest_grid_argmin(covest_grid *g, double *min_negll, int64_t *argmin_flat)
     int rc = dev_guard.status();
     if (rc != COVEST_OK)
         return rc;
-    ArgminResult r;
-    HIP_TRY(hipMemcpyAsync(&r, g->result.ptr, sizeof(r), hipMemcpyDeviceToHost, g->last_stream));
     HIP_TRY(hipStreamSynchronize(g->last_stream));
+    const ArgminResult r = *g->result_host; // (the arg-min kernel's own store: covest_grid_eval)
     *min_negll = r.min_negll;
     *argmin_flat = r.index < 0 ? -1 : g->flat_begin + r.index;
     return COVEST_OK;

@@ -57,8 +57,10 @@ struct ArgminResult {
     double pair[2]; // {min_negll, GLOBAL flat index as a double (-1 if none)}: what the ranks exchange
 };
 // queue_count: the hand-back queue's counter to reset (nullptr: none).
+constexpr int64_t kArgminSmall = 16384; // grids up to this size: one workgroup, one launch
+// host_mirror: page-locked host memory the winner is stored to as well (nullptr: none)
 hipError_t launch_argmin(const double *ll, int64_t n, int64_t flat_begin, double *partial_val, int64_t *partial_idx,
-                         ArgminResult *result, unsigned *queue_count, hipStream_t stream);
+                         ArgminResult *result, ArgminResult *host_mirror, unsigned *queue_count, hipStream_t stream);
 
 // ---- K-kmer: k-mer abundance histogram (kmer_count.hip), SURVEY 8(f) row F1 ----
 // Open-addressing table in HBM, slots = 2^log2_slots, one 16-byte entry per slot: {key, count}
