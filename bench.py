@@ -17,7 +17,7 @@ quoted on (repeat model, 10k-bin histogram):
   c3  RepeatsModel, H10k_rep.hist (10 000 keys), 32x32x16x1x16 grid (c,e,q1,q2=0.5,q)
   c2  BasicModel,   H10k_basic.hist (10 000 keys), 1000x1000 grid (c,e)
   c1  BasicModel,   H256.hist, 50x50 grid (the reference's CPU-runnable case)
-  c5  (next row F1) canonical 21-mer histogram of synthetic reads, --kmer-gbp gigabases
+  c5  (next row F1) canonical 21-mer histogram of synthetic reads, --kmer-gbp gigabases (default 10: config 5)
   f2  (next row F2) the `-sp 20` L-BFGS-B multi-start refinement of the repeats model on H10k_rep
   f3  (next row F3) histogram down-sampling (K-thin) of H10k_rep by a factor of 2
   og  covest.grid.optimize_grid end to end (the reference's consumer of batched evaluations): time-to-argmin
@@ -655,7 +655,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5", "f2", "f3", "og"])
-    ap.add_argument("--kmer-gbp", type=float, default=1.0, help="c5: gigabases of synthetic reads")
+    ap.add_argument("--kmer-gbp", type=float, default=10.0,
+                    help="c5: gigabases of synthetic reads (BASELINE.json config 5: 10; ~65 GB of HBM)")
     ap.add_argument("--kmer-path", default="partitioned", choices=["partitioned", "table"],
                     help="c5: the partitioned path (round 3) or the table in HBM of rounds 1-2")
     ap.add_argument("--kernel", default="auto")

@@ -2221,7 +2221,13 @@ int covest_kmer_clear(covest_kmer *c, void *stream)
     else
         HIP_TRY(launch_kmer_fill_empty(c->table, static_cast<hipStream_t>(stream)));
     HIP_TRY(hipMemsetAsync(c->flag.ptr, 0, sizeof(int), static_cast<hipStream_t>(stream)));
-    c->bulk = false;
+    if (c->bulk) {
+        // what the partitioned path kept for its next call -- the buckets' records are gigabytes -- goes with the counts
+        // (covest_kmer_count_reads_device has returned: nothing of it is in flight)
+        c->bulk_recs.release();
+        c->bulk_ovf.release();
+        c->bulk = false;
+    }
     return COVEST_OK;
 }
 
@@ -2425,12 +2431,18 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     p.w = k - p.m + 1;
     p.log2_buckets = lg;
     const size_t n_buckets = (size_t)1 << lg;
-    // pass 0 looks at everything when that is little, else at one block of tiles (one read) in 16
-    if (d_offsets) {
-        p.sample = n_reads >= ((int64_t)1 << 16) ? 16 : 1;
-    } else {
-        const double blocks = (double)n_reads * (double)read_len / (double)kmer_bulk_block_bytes(p);
-        p.sample = blocks >= 4096.0 ? 16 : 1;
+    // pass 0 looks at everything when that is little, else at one block of tiles (one read) in 2 .. 16: as thin a
+    // sample as leaves the average bucket six sampled records (a record per ~5 windows) -- the room is the estimate
+    // plus three of its standard deviations, and below that the estimate is mostly deviation (1 Gbp with one block in
+    // 16: 2 % of the buckets overflowed their room and went through the table in HBM)
+    {
+        const double per_bucket = windows / 5.0 / (double)n_buckets;
+        int thin = 1;
+        while (thin < 16 && (double)(2 * thin) * 6.0 <= per_bucket)
+            thin *= 2;
+        const bool large = d_offsets ? n_reads >= ((int64_t)1 << 16)
+                                     : (double)n_reads * (double)read_len / (double)kmer_bulk_block_bytes(p) >= 4096.0;
+        p.sample = large ? thin : 1;
     }
 #ifdef COVEST_DIAG
     if (const char *e = std::getenv("COVEST_KMER_SAMPLE"))
@@ -2441,15 +2453,15 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     HIP_TRY(c->bulk_fill.reserve(n_buckets * sizeof(unsigned long long)));
     HIP_TRY(c->bulk_later.reserve((2 * n_buckets + 8) * sizeof(unsigned)));
     HIP_TRY(c->bulk_partial.reserve((n_buckets / 1024 + 1) * sizeof(unsigned long long)));
-    HIP_TRY(c->bulk_ctl.reserve(16 * sizeof(unsigned long long)));
+    HIP_TRY(c->bulk_ctl.reserve((16 + kOvfShards * kOvfStride) * sizeof(unsigned long long)));
     HIP_TRY(c->bulk_hist.reserve((size_t)kBulkHistLen * sizeof(unsigned long long)));
     HIP_TRY(c->bulk_big.reserve((size_t)kBulkBigCap * sizeof(unsigned long long)));
     p.sampled = c->bulk_sampled.as<unsigned>();
     p.ctl = c->bulk_cursor.as<ulonglong2>();
     p.fill = c->bulk_fill.as<KmerBulk::fill_t>();
-    // [0] overflow list length, [1] table bound, [2] room for records in all, [4..7] stats
+    // [2] room for records in all, [4..7] stats, [16 ..] the overflow list's counters (one per 128-byte line)
     unsigned long long *ctl = c->bulk_ctl.as<unsigned long long>();
-    p.ovf_count = ctl;
+    p.ovf_count = ctl + 16;
     c->bulk = false;
     for (hipEvent_t &e : c->bulk_ev)
         if (!e)
@@ -2457,23 +2469,23 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     HIP_TRY(hipEventRecord(c->bulk_ev[0], st));
     // pass 0: room per bucket from the sample, the buckets' places
     HIP_TRY(hipMemsetAsync(p.sampled, 0, n_buckets * sizeof(unsigned), st));
-    HIP_TRY(hipMemsetAsync(ctl, 0, 16 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(ctl, 0, (16 + kOvfShards * kOvfStride) * sizeof(unsigned long long), st));
     HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, p, true, st));
     HIP_TRY(launch_kmer_place_buckets(p, c->bulk_partial.as<unsigned long long>(), ctl + 2, st));
     HIP_TRY(hipEventRecord(c->bulk_ev[1], st));
     unsigned long long room = 0;
     HIP_TRY(hipMemcpyAsync(&room, ctl + 2, sizeof(room), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    p.overflow_cap = std::max<unsigned long long>(4096ull, room / 8ull);
+    p.overflow_cap = std::max<unsigned long long>(4096ull, room / 8ull) / kOvfShards; // (per part of the list)
     {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const size_t have = c->bulk_recs.cap + c->bulk_ovf.cap;
-        if (((double)room + (double)p.overflow_cap) * 16.0 > 0.85 * (double)(free_b + have))
+        if (((double)room + (double)p.overflow_cap * kOvfShards) * 16.0 > 0.85 * (double)(free_b + have))
             return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: the buckets do not fit the free device memory");
     }
     HIP_TRY(c->bulk_recs.reserve(std::max<size_t>((size_t)room, 1) * sizeof(ulonglong2)));
-    HIP_TRY(c->bulk_ovf.reserve((size_t)p.overflow_cap * sizeof(ulonglong2)));
+    HIP_TRY(c->bulk_ovf.reserve((size_t)p.overflow_cap * kOvfShards * sizeof(ulonglong2)));
     p.recs = c->bulk_recs.as<ulonglong2>();
     p.overflow = c->bulk_ovf.as<ulonglong2>();
     // [0] buckets left to a workgroup, [2..3] buckets left to the table and (64-bit) their k-mers; the lists behind
@@ -2497,12 +2509,18 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
                                      n_cu, st));
     HIP_TRY(hipEventRecord(c->bulk_ev[3], st));
     unsigned long long n_overflowed = 0, listed[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(&n_overflowed, ctl, sizeof(n_overflowed), hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> parts((size_t)kOvfShards * kOvfStride);
+    HIP_TRY(hipMemcpyAsync(parts.data(), p.ovf_count, parts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(c->bulk_stats, ctl + 4, sizeof(c->bulk_stats), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&c->bulk_later_n, later, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(listed, to_table, sizeof(listed), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (n_overflowed > p.overflow_cap)
+    bool part_full = false;
+    for (int i = 0; i < kOvfShards; ++i) {
+        n_overflowed += parts[(size_t)i * kOvfStride];
+        part_full = part_full || parts[(size_t)i * kOvfStride] > p.overflow_cap;
+    }
+    if (part_full)
         return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: the overflow list is full (the sample of the reads "
                                     "misjudged the buckets); use covest_kmer_add_device");
     if (c->bulk_stats[2] > kBulkBigCap)
@@ -2529,7 +2547,7 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
         }
         HIP_TRY(launch_kmer_fill_empty(c->table, st));
         HIP_TRY(hipMemsetAsync(c->flag.ptr, 0, sizeof(int), st));
-        HIP_TRY(launch_kmer_to_table(p, n_overflowed, c->table, c->flag.as<int>(), to_table, to_table_list, st));
+        HIP_TRY(launch_kmer_to_table(p, n_overflowed > 0, c->table, c->flag.as<int>(), to_table, to_table_list, st));
         HIP_TRY(hipStreamSynchronize(st));
         const int frc = kmer_check_overflow(c);
         if (frc != COVEST_OK)

@@ -87,6 +87,7 @@ hipError_t launch_kmer_histogram(const KmerTable &t, unsigned long long *hist, u
                                  hipStream_t stream);
 
 // ---- K-kmer, partitioned (kmer_bulk.hip): minimizer buckets of super-k-mer records in HBM, counted in LDS ----
+constexpr int kOvfShards = 64, kOvfStride = 16;
 struct KmerBulk {
     int k, m, w;          // k-mer length, minimizer length, m-mers per k-mer (k - m + 1)
     int canonical;
@@ -98,9 +99,12 @@ struct KmerBulk {
     ulonglong2 *ctl;      // [buckets] {first, end}: the bucket's places in recs
     fill_t *fill;         // [buckets] records sent to the bucket (beyond its room: it overflowed, the surplus is in `overflow`)
     ulonglong2 *recs;     // {bases as 2-bit codes, base i at bits 2i; number of bases}
-    ulonglong2 *overflow; // [overflow_cap]
-    unsigned long long *ovf_count; // [1] records sent to the list (beyond overflow_cap: lost -- the caller starts over)
-    unsigned long long overflow_cap;
+    // the overflow list, in kOvfShards parts with a counter each (ONE counter for all of it saturates at ~90 adds per
+    // microsecond: 10 ms for the 9e5 records that overflow at 10 Gbp); a workgroup writes to the part of its number
+    ulonglong2 *overflow;          // [kOvfShards][overflow_cap]
+    unsigned long long *ovf_count; // [kOvfShards * kOvfStride] records sent to a part (beyond overflow_cap: lost -- the
+                                   // caller starts over); a counter per 128-byte line
+    unsigned long long overflow_cap; // per part
 };
 int kmer_bulk_block_bytes(const KmerBulk &p); // bytes of reads of one length a workgroup of pass 0/1 answers for
 hipError_t launch_kmer_scatter(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, int64_t fixed_len,
@@ -118,7 +122,7 @@ hipError_t launch_kmer_bucket_count(const KmerBulk &p, unsigned long long *hist,
 hipError_t launch_kmer_scatter_rate(unsigned long long *words, unsigned long long slots, long long ops, unsigned long long *sink,
                                     hipStream_t stream);
 // the overflow list's records and the listed buckets' into the table in HBM
-hipError_t launch_kmer_to_table(const KmerBulk &p, unsigned long long n_overflowed, const KmerTable &t, int *overflow,
+hipError_t launch_kmer_to_table(const KmerBulk &p, bool any_overflowed, const KmerTable &t, int *overflow,
                                 const unsigned long long *to_table, const unsigned *to_table_list, hipStream_t stream);
 
 // ---- K-kmer for k > 31 (kmer_wide.hip): keys of w = 2, 4 or 8 words, slots of `stride` words {state/count, key[w]} ----

@@ -132,9 +132,10 @@ __device__ __forceinline__ void append_record(unsigned b, u64 code, int n_bases,
     if (pos < place.y) {
         p.recs[pos] = make_ulonglong2(code, (u64)n_bases);
     } else { // the bucket is full: the record goes to the list, and the WHOLE bucket to the table later (pass 2)
-        const u64 at = atomicAdd(p.ovf_count, 1ull);
+        const unsigned shard = blockIdx.x % kOvfShards;
+        const u64 at = atomicAdd(&p.ovf_count[shard * kOvfStride], 1ull);
         if (at < p.overflow_cap)
-            p.overflow[at] = make_ulonglong2(code, (u64)n_bases);
+            p.overflow[shard * p.overflow_cap + at] = make_ulonglong2(code, (u64)n_bases);
     }
 }
 
@@ -254,9 +255,10 @@ __global__ __launch_bounds__(kTile) void kmer_tile_kernel(const unsigned char *_
                     if (pos[u] < end[u]) {
                         p.recs[pos[u]] = rec;
                     } else { // the bucket is full: the record goes to the list, and the WHOLE bucket to the table later
-                        const u64 o = atomicAdd(p.ovf_count, 1ull);
+                        const unsigned shard = blockIdx.x % kOvfShards;
+                        const u64 o = atomicAdd(&p.ovf_count[shard * kOvfStride], 1ull);
                         if (o < p.overflow_cap)
-                            p.overflow[o] = rec;
+                            p.overflow[shard * p.overflow_cap + o] = rec;
                     }
                     for (int off = p.max_run; off < run[u]; off += p.max_run) { // (a run of more than max_run windows)
                         const int a = tid + off;
@@ -731,10 +733,12 @@ __global__ __launch_bounds__(256) void kmer_buckets_to_table_kernel(const KmerBu
 }
 
 // The records that found their bucket full: their k-mers into the table (their buckets' other records follow in pass 2).
-__global__ __launch_bounds__(256) void kmer_overflow_to_table_kernel(const KmerBulk p, u64 n, const KmerTable t, int *overflow)
+__global__ __launch_bounds__(256) void kmer_overflow_to_table_kernel(const KmerBulk p, const KmerTable t, int *overflow)
 {
+    const unsigned shard = blockIdx.y; // (a part of the list per grid row)
+    const u64 n = min(p.ovf_count[shard * kOvfStride], p.overflow_cap);
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
-        record_to_table(p.overflow[i], p, t, overflow);
+        record_to_table(p.overflow[shard * p.overflow_cap + i], p, t, overflow);
 }
 
 // What bounds pass 1, measured: returning 64-bit atomic adds at pseudo-random places of `slots` words -- a wave
@@ -845,14 +849,11 @@ hipError_t launch_kmer_bucket_count(const KmerBulk &p, unsigned long long *hist,
     return hipGetLastError();
 }
 
-hipError_t launch_kmer_to_table(const KmerBulk &p, unsigned long long n_overflowed, const KmerTable &t, int *overflow,
+hipError_t launch_kmer_to_table(const KmerBulk &p, bool any_overflowed, const KmerTable &t, int *overflow,
                                 const unsigned long long *to_table, const unsigned *to_table_list, hipStream_t stream)
 {
-    if (n_overflowed > 0) {
-        const unsigned long long blocks = std::min<unsigned long long>((n_overflowed + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(kmer_overflow_to_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, n_overflowed, t,
-                           overflow);
-    }
+    if (any_overflowed)
+        hipLaunchKernelGGL(kmer_overflow_to_table_kernel, dim3(64, kOvfShards), dim3(256), 0, stream, p, t, overflow);
     hipLaunchKernelGGL(kmer_buckets_to_table_kernel, dim3(2048), dim3(256), 0, stream, p, t, overflow, to_table, to_table_list);
     return hipGetLastError();
 }

@@ -234,7 +234,8 @@ int covest_kmer_partition_ms(const covest_kmer *c, double out[4]);
  * partitioned path (one such add per record) and, per occurrence, the table path.  `ops` adds are timed. */
 int covest_kmer_scatter_rate(int32_t device, int64_t slots, int64_t ops, double *ops_per_s);
 int64_t covest_kmer_slots(const covest_kmer *c);
-/* Forget every count (counts = defaultdict(int) again), keeping the table's size; asynchronous on `stream`. */
+/* Forget every count (counts = defaultdict(int) again), keeping the table's size; asynchronous on `stream`.  After
+ * covest_kmer_count_reads_device it also frees the buckets' records (gigabytes the handle keeps from call to call). */
 int covest_kmer_clear(covest_kmer *c, void *stream);
 
 /* ---- FASTA / FASTQ front-end of the k-mer histogram: bin/kmer_hist.py:44-54 preprocess, :67-74 load_reads ----

@@ -300,16 +300,17 @@ assert info["buckets_by_workgroup"] > 0, info
 # highly repetitive: 12 000 copies of 25 reads -- counts beyond the LDS bins
 rep = genome_reads(25, 100, 2000, err=0.0) * 12000
 run("repeats", rep, 21, True, fixed_len=100)
-# enough reads for pass 0 to SAMPLE them (one block of 1920 bytes / one read in 16)
+# enough reads for pass 0 to SAMPLE them (one block of 1920 bytes / one read in 2 .. 16)
 many = genome_reads(100000, 100, 200000)
 info = run("sampled", many, 21, True, fixed_len=100, expect="partitioned")
-assert info["sampled_1_in"] == 16, info
-# ... and a sample that misleads: outside the sampled blocks, one read in 20 is a copy of the same one -- its buckets
-# get far more records than they were given room for, overflow, and are counted through the table in HBM
+S = info["sampled_1_in"]
+assert S > 1, info
+# ... and a sample that misleads: outside the sampled blocks (one in S) and reads, one read in 20 is a copy of the same
+# one -- its buckets get far more records than they were given room for, overflow, and are counted through the table
 misled = list(many)
 block = 8 * (256 - 16)
 for r in range(len(misled)):
-    if (r * 100 // block) % 16 != 0 and ((r + 1) * 100 // block) % 16 != 0 and r % 16 != 0 and r % 20 == 1:
+    if (r * 100 // block) % S != 0 and ((r + 1) * 100 // block) % S != 0 and r % S != 0 and r % 20 == 1:
         misled[r] = many[7]
 info = run("misled sample", misled, 21, True, fixed_len=100, expect="partitioned")
 assert info["overflowed_records"] > 0 and info["buckets_through_table"] > 0, info
@@ -381,7 +382,7 @@ part = kh.KmerCounts(k, canonical=True, min_slots=1 << 20)
 assert part.count_reads_device(reads.data_ptr(), n, L) == "partitioned", getattr(part, "why_not_partitioned", "")
 h_part, d_part = part.histogram(), len(part)
 info = part.partition_info()
-assert info["sampled_1_in"] == 16 and info["records"] > n, info
+assert info["sampled_1_in"] > 1 and info["records"] > n, info
 table = kh.KmerCounts(k, canonical=True, min_slots=1 << 29)
 table.add_device(reads.data_ptr(), n, L, reserve=False)
 assert table.histogram() == h_part and len(table) == d_part, "1 Gbp: partitioned != table"
