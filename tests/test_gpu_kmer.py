@@ -329,6 +329,18 @@ flank = LUT[rng.integers(0, 4, size=(3000, 16), dtype=np.uint8)]
 around = ["".join(map(chr, f[:8])) + core_s + "".join(map(chr, f[8:])) for f in flank]
 info = run("one minimizer", around + genome_reads(3000, 29, 20000), 21, True, fixed_len=29, expect="partitioned")
 assert info["buckets_through_table"] > 0, info
+# random shapes: k, strand mode, read length (fixed and ragged), genome size, error rate
+for seed in range(16):
+    r2 = np.random.default_rng(1000 + seed)
+    k = int(r2.integers(19, 32))
+    L = int(r2.integers(k, 260))
+    n = int(r2.integers(50, 4000))
+    reads = genome_reads(n, L, int(r2.integers(L + 1, 60000)), err=float(r2.choice([0.0, 0.01, 0.1])))
+    if seed % 2:
+        reads = [r[:int(m)] for r, m in zip(reads, r2.integers(0, L + 1, size=n))]
+        run("fuzz %d ragged" % seed, reads, k, bool(seed & 2))
+    else:
+        run("fuzz %d" % seed, reads, k, bool(seed & 2), fixed_len=L, expect="partitioned")
 # k the partitioned path does not take
 run("k=12", genome_reads(3000, 60, 5000), 12, True, fixed_len=60, expect="table")
 assert any(p == "partitioned" for _, _, p in taken)
