@@ -2010,6 +2010,30 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
     g->last_kernel_id = kern;
     if (e1)
         HIP_TRY(hipEventRecord(e1, st));
+#ifdef COVEST_DIAG // diagnostic builds only: how many points the recurrence kernel handed back for the strict evaluation
+    if (std::getenv("COVEST_DIAG_QUEUE")) {
+        unsigned queued = 0;
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(&queued, g->sub_ctl.ptr, sizeof queued, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "covest_grid_eval: %u of %lld points handed back\n", queued, (long long)n);
+        if (queued > 0) { // the row ranges named: how long they are
+            std::vector<unsigned long long> words(queued);
+            HIP_TRY(hipMemcpy(words.data(), g->sub_word.ptr, (size_t)queued * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            double sum = 0;
+            long long mx = 0, mn = 1 << 30, first_sum = 0;
+            for (unsigned long long w : words) {
+                const long long unit = sub_units16(w) ? 16 : 1;
+                const long long len = ((long long)sub_last(w) - (long long)sub_first(w) + 1) * unit;
+                sum += (double)len;
+                mx = std::max(mx, len);
+                mn = std::min(mn, len);
+                first_sum += (long long)sub_first(w) * unit;
+            }
+            std::fprintf(stderr, "covest_grid_eval: rows named per point: min %lld mean %.1f max %lld; mean first row %.1f\n", mn,
+                         sum / queued, mx, (double)first_sum / queued);
+        }
+    }
+#endif
     if (!g->result_host) // (page-locked, mapped: argmin_stage2 stores the winner there itself)
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->result_host), sizeof(ArgminResult), hipHostMallocMapped));
     HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->flat_begin, g->partial_val.as<double>(),

@@ -43,7 +43,7 @@ def test_no_value_changing_knob_in_the_shipped_library(hip_lib):
     for knob in (b"COVEST_FACTORED_SKIP", b"COVEST_FACTORED_DIAG", b"COVEST_FACTORED_SHARE", b"COVEST_FACTORED_NBUF",
                  b"COVEST_NO_SUM_ITEMS", b"COVEST_FACTORED_BUILD_COST", b"COVEST_FACTORED_UNIT_OVERHEAD",
                  b"COVEST_FACTORED_SHARED_DIV", b"COVEST_FACTORED_MIN_SHARED", b"COVEST_KMER_EXP",
-                 b"COVEST_FACTORED_LAST_BUILDER_EXTRA", b"COVEST_KMER_M", b"COVEST_KMER_LG", b"COVEST_KMER_SAMPLE"):
+                 b"COVEST_FACTORED_LAST_BUILDER_EXTRA", b"COVEST_DIAG_QUEUE", b"COVEST_KMER_M", b"COVEST_KMER_LG", b"COVEST_KMER_SAMPLE"):
         assert knob not in blob, knob.decode()
     # what may stay: pure host-side I/O settings of the read parser (thread count, page-locked buffers)
     allowed = set(re.findall(rb"COVEST_[A-Z_]{4,}", blob)) - {b"COVEST_READER_THREADS", b"COVEST_READER_PINNED"}
