@@ -758,6 +758,18 @@ __global__ __launch_bounds__(256) void kmer_scatter_rate_kernel(u64 *__restrict_
         sink[0] = acc; // (never: keeps the returned values alive)
 }
 
+// out[0] = 0 if some read is not offsets[1] - offsets[0] bases long (out comes in as 1)
+__global__ __launch_bounds__(256) void kmer_one_length_kernel(const int64_t *__restrict__ offsets, int64_t n_reads,
+                                                              unsigned long long *__restrict__ out)
+{
+    const int64_t len0 = offsets[1] - offsets[0];
+    bool same = true;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x)
+        same = same && offsets[r + 1] - offsets[r] == len0;
+    if (__ballot(!same) != 0ull && (threadIdx.x & (kWave - 1)) == 0)
+        out[0] = 0ull;
+}
+
 template <bool COUNT>
 hipError_t launch_tiles(const unsigned char *bases, int64_t n_reads, int64_t len, const KmerBulk &p, hipStream_t stream)
 {
@@ -823,6 +835,12 @@ hipError_t launch_kmer_place_buckets(const KmerBulk &p, unsigned long long *part
     hipLaunchKernelGGL(kmer_caps_partial_kernel, dim3(n_blocks), dim3(256), 0, stream, p, partial);
     hipLaunchKernelGGL(kmer_caps_scan_kernel, dim3(1), dim3(256), 0, stream, partial, n_blocks, total);
     hipLaunchKernelGGL(kmer_caps_place_kernel, dim3(n_blocks), dim3(256), 0, stream, p, partial);
+    return hipGetLastError();
+}
+
+hipError_t launch_kmer_one_length(const int64_t *offsets, int64_t n_reads, unsigned long long *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(kmer_one_length_kernel, dim3(1024), dim3(256), 0, stream, offsets, n_reads, out);
     return hipGetLastError();
 }
 

@@ -1,0 +1,23 @@
+import os, sys, time
+import torch
+sys.path.insert(0, os.getcwd())
+from covest_amd import kmer_hist as kh
+dev = torch.device("cuda", 0)
+k, L, n = 21, 100, 10_000_000
+gen = torch.Generator(device=dev); gen.manual_seed(3)
+lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+g_len = n * L // 40
+genome = lut[torch.randint(0, 4, (g_len,), device=dev, generator=gen)]
+starts = torch.randint(0, g_len - L, (n,), device=dev, generator=gen)
+reads = genome[starts[:, None] + torch.arange(L, device=dev)[None, :]].reshape(-1).contiguous()
+offs = (torch.arange(n + 1, device=dev, dtype=torch.int64) * L)
+c = kh.KmerCounts(k, canonical=True, min_slots=1 << 20)
+for layout in ("fixed", "offsets"):
+    for rep in range(2):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        if layout == "fixed":
+            path = c.count_reads_device(reads.data_ptr(), n, L)
+        else:
+            path = c.count_reads_device(reads.data_ptr(), n, 0, d_offsets_ptr=offs.data_ptr(), n_bases=n * L)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        print(layout, path, "%.1f ms" % (1e3 * dt), c.partition_info()["ms"] if path == "partitioned" else "")
