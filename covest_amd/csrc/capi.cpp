@@ -2097,7 +2097,7 @@ struct covest_kmer {
     DevBuf slots, flag, stats, hist, ws_bases, ws_offsets;
     // the partitioned path (kmer_bulk.hip): its buffers, kept from call to call, and what it found
     bool bulk = false; // the counter holds the result of covest_kmer_count_reads_device (until covest_kmer_clear)
-    DevBuf bulk_sampled, bulk_cursor, bulk_fill, bulk_later, bulk_partial, bulk_recs, bulk_ovf, bulk_ctl, bulk_hist, bulk_big;
+    DevBuf bulk_sampled, bulk_cursor, bulk_fill, bulk_tile_reads, bulk_later, bulk_partial, bulk_recs, bulk_ovf, bulk_ctl, bulk_hist, bulk_big;
     unsigned long long bulk_stats[4] = {0, 0, 0, 0};
     int64_t bulk_info[5] = {0, 0, 0, 0, 0}; // buckets, m, sample, records there was room for, records that found none
     unsigned bulk_later_n = 0;              // buckets a workgroup (not a wave) counted
@@ -2216,6 +2216,7 @@ void covest_kmer_destroy(covest_kmer *c)
         }
     c->bulk_sampled.release();
     c->bulk_fill.release();
+    c->bulk_tile_reads.release();
     c->bulk_later.release();
     c->bulk_partial.release();
     c->bulk_cursor.release();
@@ -2435,7 +2436,8 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int k = c->k;
     // Reads that come with offsets but are all of one length (a sequencer's usually are) take the path of reads of one
-    // length: its tiles share the m-mer hashes between windows, the wave-per-read walk does not (2.4x in pass 1).
+    // length: its threads need not look up which read their byte belongs to.
+    int64_t ragged_base0 = 0, ragged_total = 0;
     if (d_offsets && n_reads > 0) {
         HIP_TRY(c->bulk_ctl.reserve((16 + kOvfShards * kOvfStride) * sizeof(unsigned long long)));
         unsigned long long *flag = c->bulk_ctl.as<unsigned long long>();
@@ -2444,10 +2446,17 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
         HIP_TRY(hipMemcpyAsync(flag, &one, sizeof one, hipMemcpyHostToDevice, st));
         HIP_TRY(launch_kmer_one_length(d_offsets, n_reads, flag, st));
         unsigned long long same = 0;
+        int64_t last = 0;
         HIP_TRY(hipMemcpyAsync(&same, flag, sizeof same, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(two, d_offsets, sizeof two, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&last, d_offsets + n_reads, sizeof last, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t len0 = two[1] - two[0];
+        ragged_base0 = two[0];
+        ragged_total = last - two[0];
+        if (ragged_total < 0 || n_reads >= ((int64_t)1 << 32))
+            return fail(COVEST_E_INVALID, "covest_kmer_count_reads_device: offsets do not ascend, or 2^32 reads and more");
+        n_bases_total = ragged_total;
         if (same && len0 >= k && len0 < ((int64_t)1 << 30)) {
             d_bases += two[0];
             d_offsets = nullptr;
@@ -2484,8 +2493,8 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
         int thin = 1;
         while (thin < 16 && (double)(2 * thin) * 6.0 <= per_bucket)
             thin *= 2;
-        const bool large = d_offsets ? n_reads >= ((int64_t)1 << 16)
-                                     : (double)n_reads * (double)read_len / (double)kmer_bulk_block_bytes(p) >= 4096.0;
+        const double bytes = d_offsets ? (double)ragged_total : (double)n_reads * (double)read_len;
+        const bool large = bytes / (double)kmer_bulk_block_bytes(p) >= 4096.0;
         p.sample = large ? thin : 1;
     }
 #ifdef COVEST_DIAG
@@ -2514,7 +2523,12 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     // pass 0: room per bucket from the sample, the buckets' places
     HIP_TRY(hipMemsetAsync(p.sampled, 0, n_buckets * sizeof(unsigned), st));
     HIP_TRY(hipMemsetAsync(ctl, 0, (16 + kOvfShards * kOvfStride) * sizeof(unsigned long long), st));
-    HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, p, true, st));
+    unsigned *first_read = nullptr;
+    if (d_offsets && n_reads > 0) { // reads of different lengths: the read of every tile's first byte (kmer_bulk.hip)
+        HIP_TRY(c->bulk_tile_reads.reserve((size_t)kmer_bulk_ragged_tiles(p, ragged_total) * sizeof(unsigned)));
+        first_read = c->bulk_tile_reads.as<unsigned>();
+    }
+    HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, ragged_base0, ragged_total, first_read, p, true, st));
     HIP_TRY(launch_kmer_place_buckets(p, c->bulk_partial.as<unsigned long long>(), ctl + 2, st));
     HIP_TRY(hipEventRecord(c->bulk_ev[1], st));
     unsigned long long room = 0;
@@ -2546,7 +2560,7 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
             n_cu = prop.multiProcessorCount;
     }
-    HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, p, false, st));
+    HIP_TRY(launch_kmer_scatter(d_bases, d_offsets, n_reads, read_len, ragged_base0, ragged_total, first_read, p, false, st));
     HIP_TRY(hipEventRecord(c->bulk_ev[2], st));
     HIP_TRY(launch_kmer_bucket_count(p, c->bulk_hist.as<unsigned long long>(), kBulkHistLen, ctl + 4,
                                      c->bulk_big.as<unsigned long long>(), kBulkBigCap, later, later_list, to_table, to_table_list,

@@ -107,8 +107,12 @@ struct KmerBulk {
     unsigned long long overflow_cap; // per part
 };
 int kmer_bulk_block_bytes(const KmerBulk &p); // bytes of reads of one length a workgroup of pass 0/1 answers for
+// offsets != nullptr: reads of any length -- base0 = offsets[0], total_bytes = offsets[n_reads] - base0, first_read: room
+// for kmer_bulk_ragged_tiles(p, total_bytes) words
+int64_t kmer_bulk_ragged_tiles(const KmerBulk &p, int64_t total_bytes);
 hipError_t launch_kmer_scatter(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, int64_t fixed_len,
-                               const KmerBulk &p, bool count_only, hipStream_t stream);
+                               int64_t base0, int64_t total_bytes, unsigned *first_read, const KmerBulk &p, bool count_only,
+                               hipStream_t stream);
 hipError_t launch_kmer_place_buckets(const KmerBulk &p, unsigned long long *partial, unsigned long long *total,
                                      hipStream_t stream);
 // stats: [0] max count, [1] distinct keys, [2] entries of `big` (counts >= hist_len), [3] records pass 1 sent

@@ -143,10 +143,49 @@ __device__ __forceinline__ void append_record(unsigned b, u64 code, int n_bases,
 // The read array as one run of bytes (`len` bytes a read, nothing between them): tile t covers bytes
 // [t * n_win, t * n_win + 256), its first n_win = 256 - max(16, w - 1) bytes are the window starts it answers for.
 // `positions`: bytes of this launch (whole reads, < 2^32); `avail`: bytes that may be read from `bases` on.
-template <bool COUNT, int U>
-__global__ __launch_bounds__(kTile) void kmer_tile_kernel(const unsigned char *__restrict__ bases, unsigned positions,
-                                                          u64 avail, unsigned len, unsigned n_tiles, const KmerBulk p)
+// RAGGED: the reads are of different lengths -- offsets[r] .. offsets[r + 1] of the byte run are read r -- and a thread
+// has to learn which read its byte belongs to: the tile's first read comes from a table made beforehand
+// (kmer_tile_first_read_kernel), the starts of the up to 32 reads behind it are brought into LDS, and the thread
+// searches those (a tile of shorter reads than that: the thread searches the offsets themselves).  `positions` and
+// the tiles then count from byte `pos0` of the run, which need not be a read's start.
+struct RaggedReads {
+    const int64_t *offsets; // [n_reads + 1], absolute in the caller's byte run
+    int64_t n_reads;
+    int64_t base0;          // offsets[0]
+    int64_t pos0;           // this launch's first byte, relative to base0
+    const unsigned *first_read; // [tiles of this launch] read of the tile's first byte
+};
+constexpr int kTileReads = 32;
+
+// largest r in [lo, n_reads) with offsets[r] - base0 <= pos (reads of no bases share their start with the next one)
+__device__ __forceinline__ int64_t read_of(const int64_t *__restrict__ offsets, int64_t n_reads, int64_t base0, int64_t pos,
+                                           int64_t lo)
 {
+    int64_t hi = n_reads; // offsets[hi] - base0 > pos (or hi == n_reads)
+    while (hi - lo > 1) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (offsets[mid] - base0 <= pos)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void kmer_tile_first_read_kernel(RaggedReads src, unsigned n_tiles, int n_win,
+                                                                   unsigned *__restrict__ first_read)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles)
+        first_read[t] = (unsigned)read_of(src.offsets, src.n_reads, src.base0, src.pos0 + (int64_t)t * n_win, 0);
+}
+
+template <bool COUNT, int U, bool RAGGED>
+__global__ __launch_bounds__(kTile) void kmer_tile_kernel(const unsigned char *__restrict__ bases, unsigned positions,
+                                                          u64 avail, unsigned len, unsigned n_tiles, const KmerBulk p,
+                                                          const RaggedReads src)
+{
+    __shared__ int64_t roff[RAGGED ? U : 1][RAGGED ? kTileReads + 2 : 1]; // starts of the tile's reads, relative to pos0
     // U tiles side by side (a wave that waits for the places of one tile's records would keep U times as many atomics
     // in flight: see kTilesAtOnce for what that bought)
     __shared__ unsigned hs[U][kTile]; // hash of the m-mer that starts at the byte
@@ -176,11 +215,36 @@ __global__ __launch_bounds__(kTile) void kmer_tile_kernel(const unsigned char *_
                     if ((u64)at + (u64)j < avail)
                         c16 |= base_code(bases[at + j]) << (2 * j);
             }
-            const unsigned i = at % len; // place in its read
-            const bool live = tile0 + u < n_tiles && at < positions;
-            hs[u][tid] = (live && i + (unsigned)p.m <= len) ? mmer_hash(mmer_canonical(c16 & mm, p.m, p.canonical)) : ~0u;
+            if (!RAGGED) {
+                const unsigned i = at % len; // place in its read
+                const bool live = tile0 + u < n_tiles && at < positions;
+                hs[u][tid] = (live && i + (unsigned)p.m <= len) ? mmer_hash(mmer_canonical(c16 & mm, p.m, p.canonical)) : ~0u;
+                valid[u] = live && tid < n_win && i + (unsigned)p.k <= len;
+            } else {
+                // the starts of the tile's first reads (and the end of the last of them), relative to pos0
+                const int64_t r0 = tile0 + u < n_tiles ? (int64_t)src.first_read[tile0 + u] : 0;
+                if (tid <= kTileReads) {
+                    const int64_t r = r0 + tid < src.n_reads ? r0 + tid : src.n_reads;
+                    roff[u][tid] = src.offsets[r] - src.base0 - src.pos0;
+                }
+                __syncthreads();
+                const int64_t here = (int64_t)at;
+                int j = 0; // the read of this byte: the last of the tile's reads that starts at or before it
+                for (int step = kTileReads / 2; step >= 1; step >>= 1)
+                    if (roff[u][j + step] <= here)
+                        j += step;
+                int64_t start = roff[u][j], end = roff[u][j + 1];
+                if (j == kTileReads - 1 && end <= here && r0 + kTileReads < src.n_reads) { // more reads than the table holds
+                    const int64_t r = read_of(src.offsets, src.n_reads, src.base0, src.pos0 + here, r0 + kTileReads - 1);
+                    start = src.offsets[r] - src.base0 - src.pos0;
+                    end = src.offsets[r + 1] - src.base0 - src.pos0;
+                }
+                // (the halo's bytes belong to reads too: only the WINDOWS are this launch's or not)
+                const bool in_run = tile0 + u < n_tiles && (u64)at < avail && here < end;
+                hs[u][tid] = (in_run && here + p.m <= end) ? mmer_hash(mmer_canonical(c16 & mm, p.m, p.canonical)) : ~0u;
+                valid[u] = in_run && at < positions && tid < n_win && here + p.k <= end && here >= start;
+            }
             cs[u][tid] = c16;
-            valid[u] = live && tid < n_win && i + (unsigned)p.k <= len;
         }
         __syncthreads();
 #pragma unroll
@@ -274,59 +338,28 @@ __global__ __launch_bounds__(kTile) void kmer_tile_kernel(const unsigned char *_
     }
 }
 
-// ---- pass 0 / 1, reads of any length: one wave per read, a window per lane, the bucket the slow way ------------------
+// ---- pass 0 / 1, reads of any length: the tiles above with RAGGED, and the reads SHORTER than k here ------------------
+// hash_kmer of what there is (bin/kmer_hist.py:36-37): an integer below 4^len -- the very key of the k-mer
+// "a" * (k - len) + read, which a window elsewhere may spell out (a read of k - 1 bases behind an 'a' in the genome:
+// one in four).  So it is counted AS that k-mer, through its bucket: a key must live in one place.  A thread a read.
 template <bool COUNT>
-__device__ __forceinline__ void scatter_wave(const unsigned char *__restrict__ seq, int64_t s, int64_t len, bool valid,
-                                             const KmerBulk &p)
+__global__ __launch_bounds__(256) void kmer_short_reads_kernel(const unsigned char *__restrict__ bases,
+                                                               const int64_t *__restrict__ offsets, int64_t n_reads,
+                                                               const KmerBulk p)
 {
-    const int lane = threadIdx.x & (kWave - 1);
-    unsigned b = kNoBucket;
-    if (valid)
-        b = bucket_of_le(pack_bases(seq, s, len, p.k), p);
-    const unsigned prev_b = __shfl_up(b, 1, kWave);
-    const bool head = valid && (lane == 0 || prev_b != b);
-    const u64 hm = __ballot(head), vm = __ballot(valid);
-    if (!head)
-        return;
-    const u64 stop = (hm | ~vm) & (lane == kWave - 1 ? 0ull : (~0ull << (lane + 1)));
-    const int run = (stop ? __ffsll((long long)stop) - 1 : kWave) - lane;
-    for (int off = 0; off < run; off += p.max_run) {
-        const int n_bases = min(p.max_run, run - off) + p.k - 1;
-        append_record<COUNT>(b, pack_bases(seq, s + off, len, n_bases), n_bases, p);
-    }
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(256) void kmer_scatter_reads_kernel(const unsigned char *__restrict__ bases,
-                                                                 const int64_t *__restrict__ offsets, int64_t n_reads,
-                                                                 const KmerBulk p)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    int64_t r = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (COUNT)
         r *= p.sample;
     if (r >= n_reads)
         return;
     const int64_t p0 = offsets[r];
-    const int64_t len = offsets[r + 1] - p0;
-    const unsigned char *seq = bases + p0;
-    if (len < p.k) {
-        // hash_kmer of what there is (bin/kmer_hist.py:36-37): an integer below 4^len -- the very key of the k-mer
-        // "a" * (k - len) + read, which a window elsewhere may spell out (a read of k - 1 bases behind an 'a' in the
-        // genome: one in four).  So it is counted AS that k-mer, through its bucket: a key must live in one place.
-        if (lane == 0) {
-            u64 le = 0;
-            for (int i = 0; i < (int)len; ++i)
-                le |= (u64)base_code(seq[i]) << (2 * (p.k - (int)len + i));
-            append_record<COUNT>(bucket_of_le(le, p), le, p.k, p);
-        }
+    const int len = (int)min(offsets[r + 1] - p0, (int64_t)p.k);
+    if (len >= p.k)
         return;
-    }
-    const int64_t n_windows = len - p.k + 1;
-    for (int64_t s0 = 0; s0 < n_windows; s0 += kWave) { // wave-uniform trip count
-        const int64_t s = s0 + lane;
-        scatter_wave<COUNT>(seq, s < n_windows ? s : 0, len, s < n_windows, p);
-    }
+    u64 le = 0;
+    for (int i = 0; i < len; ++i)
+        le |= (u64)base_code(bases[p0 + i]) << (2 * (p.k - len + i));
+    append_record<COUNT>(bucket_of_le(le, p), le, p.k, p);
 }
 
 // ---- pass 0: room per bucket and the buckets' places (a prefix sum over the buckets) -------------------------------
@@ -784,25 +817,42 @@ hipError_t launch_tiles(const unsigned char *bases, int64_t n_reads, int64_t len
         uint64_t blocks = (n_tiles + kTilesPerBlock - 1) / kTilesPerBlock;
         if (COUNT)
             blocks = (blocks + p.sample - 1) / p.sample;
-        hipLaunchKernelGGL((kmer_tile_kernel<COUNT, kTilesAtOnce>), dim3((unsigned)blocks), dim3(kTile), 0, stream, bases + first * len,
-                           (unsigned)positions, (u64)avail, (unsigned)len, (unsigned)n_tiles, p);
+        hipLaunchKernelGGL((kmer_tile_kernel<COUNT, kTilesAtOnce, false>), dim3((unsigned)blocks), dim3(kTile), 0, stream,
+                           bases + first * len, (unsigned)positions, (u64)avail, (unsigned)len, (unsigned)n_tiles, p, RaggedReads{});
     }
     return hipGetLastError();
 }
 
+// Reads of any length: the byte run offsets[0] .. offsets[n_reads] in launches of whole blocks of tiles (below 2^31
+// bytes each; a launch need not end with a read: a window belongs to the launch its first byte is in).  first_read:
+// room for a word per tile of the largest launch (kmer_bulk_ragged_tiles).
 template <bool COUNT>
-hipError_t launch_reads(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, const KmerBulk &p,
-                        hipStream_t stream)
+hipError_t launch_ragged(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, int64_t base0, int64_t total,
+                         unsigned *first_read, const KmerBulk &p, hipStream_t stream)
 {
-    const int reads_per_block = 4;
+    const int n_win = kTile - std::max(16, p.w - 1);
+    const int64_t block_bytes = (int64_t)kTilesPerBlock * n_win;
+    const int64_t per_launch = (((int64_t)1 << 31) / block_bytes) * block_bytes;
+    for (int64_t pos0 = 0; pos0 < total; pos0 += per_launch) {
+        const int64_t positions = std::min(total - pos0, per_launch);
+        const uint64_t n_tiles = (uint64_t)((positions + n_win - 1) / n_win);
+        uint64_t blocks = (n_tiles + kTilesPerBlock - 1) / kTilesPerBlock;
+        RaggedReads src{offsets, n_reads, base0, pos0, first_read};
+        // (both passes make the table again: a launch's table is gone once the next launch has made its own)
+        hipLaunchKernelGGL(kmer_tile_first_read_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, stream, src,
+                           (unsigned)n_tiles, n_win, first_read);
+        if (COUNT)
+            blocks = (blocks + p.sample - 1) / p.sample;
+        hipLaunchKernelGGL((kmer_tile_kernel<COUNT, kTilesAtOnce, true>), dim3((unsigned)blocks), dim3(kTile), 0, stream,
+                           bases + base0 + pos0, (unsigned)positions, (u64)(total - pos0), 0u, (unsigned)n_tiles, p, src);
+    }
     const int64_t step = COUNT ? p.sample : 1;
-    const int64_t reads_per_launch = ((int64_t)reads_per_block << 23) * step; // (a multiple of the sample's stride)
-    for (int64_t first = 0; first < n_reads; first += reads_per_launch) {
-        const int64_t n = std::min(n_reads - first, reads_per_launch);
-        const int64_t waves = (n + step - 1) / step;
-        const dim3 grid((unsigned)((waves + reads_per_block - 1) / reads_per_block));
-        hipLaunchKernelGGL(kmer_scatter_reads_kernel<COUNT>, grid, dim3(reads_per_block * kWave), 0, stream, bases, offsets + first,
-                           n, p);
+    const int64_t threads = (n_reads + step - 1) / step;
+    const int64_t per = (int64_t)1 << 30; // threads a launch
+    for (int64_t first = 0; first < threads; first += per) {
+        const int64_t n = std::min(threads - first, per);
+        hipLaunchKernelGGL(kmer_short_reads_kernel<COUNT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, bases,
+                           offsets + first * step, n_reads - first * step, p);
     }
     return hipGetLastError();
 }
@@ -814,16 +864,25 @@ int kmer_bulk_block_bytes(const KmerBulk &p)
     return kTilesPerBlock * (kTile - std::max(16, p.w - 1));
 }
 
+int64_t kmer_bulk_ragged_tiles(const KmerBulk &p, int64_t total_bytes)
+{
+    const int n_win = kTile - std::max(16, p.w - 1);
+    const int64_t block_bytes = (int64_t)kTilesPerBlock * n_win;
+    const int64_t per_launch = (((int64_t)1 << 31) / block_bytes) * block_bytes;
+    return (std::min(total_bytes, per_launch) + n_win - 1) / n_win + 1;
+}
+
 hipError_t launch_kmer_scatter(const unsigned char *bases, const int64_t *offsets, int64_t n_reads, int64_t fixed_len,
-                               const KmerBulk &p, bool count_only, hipStream_t stream)
+                               int64_t base0, int64_t total_bytes, unsigned *first_read, const KmerBulk &p, bool count_only,
+                               hipStream_t stream)
 {
     if (n_reads <= 0)
         return hipSuccess;
     if (!offsets) // (the host sends reads shorter than k to the table path)
         return count_only ? launch_tiles<true>(bases, n_reads, fixed_len, p, stream)
                           : launch_tiles<false>(bases, n_reads, fixed_len, p, stream);
-    return count_only ? launch_reads<true>(bases, offsets, n_reads, p, stream)
-                      : launch_reads<false>(bases, offsets, n_reads, p, stream);
+    return count_only ? launch_ragged<true>(bases, offsets, n_reads, base0, total_bytes, first_read, p, stream)
+                      : launch_ragged<false>(bases, offsets, n_reads, base0, total_bytes, first_read, p, stream);
 }
 
 // sampled[] -> ctl[] = {first place, end} of every bucket; total[0] = the records there is room for.  partial: a word

@@ -215,8 +215,8 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
  * buckets of super-k-mer records and counted bucket by bucket in LDS -- an occurrence costs no scattered memory
  * operation.  The counts are not kept as a dict: afterwards the counter answers covest_kmer_histogram (count-of-counts,
  * distinct keys -- exact) and nothing else, until covest_kmer_clear.  d_offsets NULL: every read is read_len bases;
- * else offsets[n_reads + 1] and n_bases_total = offsets[n_reads] - offsets[0] (reads of one length are recognised
- * and counted as such: twice as fast in the first pass).  Blocks until done.
+ * else offsets[n_reads + 1] (ascending, reads back to back; fewer than 2^32 reads); n_bases_total is a hint, the
+ * offsets decide.  Blocks until done.
  * COVEST_E_UNSUPPORTED: k outside 19..31 or reads shorter than k; COVEST_E_NOMEM: the buckets do not fit the device,
  * or a few minimizers hold most of the k-mers (low-complexity input) -- count with covest_kmer_add_device then. */
 int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_reads,

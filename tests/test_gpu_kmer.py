@@ -329,6 +329,24 @@ flank = LUT[rng.integers(0, 4, size=(3000, 16), dtype=np.uint8)]
 around = ["".join(map(chr, f[:8])) + core_s + "".join(map(chr, f[8:])) for f in flank]
 info = run("one minimizer", around + genome_reads(3000, 29, 20000), 21, True, fixed_len=29, expect="partitioned")
 assert info["buckets_through_table"] > 0, info
+# reads of different lengths through the tiles: more reads in a tile than its table holds (crumbs of 0 .. 6 bases between
+# long reads), reads longer than a tile, a byte run that does not start at 0
+crumbs = []
+for r in genome_reads(300, 400, 20000):
+    crumbs.append(r)
+    crumbs.extend(r[:int(m)] for m in rng.integers(0, 7, size=int(rng.integers(0, 120))))
+run("crumbs", crumbs, 21, True)
+run("long reads", genome_reads(200, 1500, 30000), 23, True)
+def run_shifted(reads, k):
+    blob = np.frombuffer(("ACGTACGTAC" + "".join(reads)).encode(), dtype=np.uint8)
+    lens = np.array([len(r) for r in reads], dtype=np.int64)
+    offs = np.full(len(reads) + 1, 10, dtype=np.int64); offs[1:] += np.cumsum(lens)
+    d_bases, d_offs = torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offs).to(dev)
+    c = kh.KmerCounts(k, canonical=True, min_slots=1 << 12)
+    assert c.count_reads_device(d_bases.data_ptr(), len(reads), 0, d_offsets_ptr=d_offs.data_ptr(), n_bases=int(lens.sum())) == "partitioned"
+    assert c.histogram() == ko.histogram(reads, k, canonical=True), "offsets[0] != 0"
+    c.close()
+run_shifted(ragged, 21)
 # random shapes: k, strand mode, read length (fixed and ragged), genome size, error rate
 for seed in range(16):
     r2 = np.random.default_rng(1000 + seed)
@@ -399,7 +417,22 @@ table = kh.KmerCounts(k, canonical=True, min_slots=1 << 29)
 table.add_device(reads.data_ptr(), n, L, reserve=False)
 assert table.histogram() == h_part and len(table) == d_part, "1 Gbp: partitioned != table"
 assert sum(i * v for i, v in enumerate(h_part)) == n * (L - k + 1) and sum(h_part) == d_part
-table.close(); del reads
+table.close()
+# the same bytes and 1.6 Gbp more, cut into reads of 30 .. 170 bases: 2.6e9 bytes = two launches of the tiles (a launch
+# takes less than 2^31); against the table again
+more = synthetic_reads(16_000_000, 13)
+both = torch.cat([reads, more]); del reads, more
+lens = torch.randint(30, 171, (int(both.numel() / 100 * 1.02),), device=dev, dtype=torch.int64)
+ends = torch.cumsum(lens, 0)
+n_r = int((ends <= both.numel()).sum().item())
+offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), ends[:n_r]])
+assert int(offs[-1].item()) > 2 ** 31
+assert part.count_reads_device(both.data_ptr(), n_r, 0, d_offsets_ptr=offs.data_ptr(), n_bases=int(offs[-1].item())) == "partitioned"
+h_r, d_r = part.histogram(), len(part)
+table = kh.KmerCounts(k, canonical=True, min_slots=1 << 30)
+table.add_device(both.data_ptr(), n_r, 0, d_offsets_ptr=offs.data_ptr(), reserve=False)
+assert table.histogram() == h_r and len(table) == d_r, "ragged 2.6 Gbp: partitioned != table"
+table.close(); del both, offs, ends, lens
 # 10 Gbp (BASELINE.json config 5's size): every window lands in exactly one bin, the bins add up to the distinct keys,
 # and counting twice gives the same histogram (the counter is emptied, the buckets' room is found again)
 if free < 200e9:
