@@ -217,8 +217,10 @@ int covest_kmer_histogram(covest_kmer *c, int64_t *out, int64_t out_len, int64_t
  * distinct keys -- exact) and nothing else, until covest_kmer_clear.  d_offsets NULL: every read is read_len bases;
  * else offsets[n_reads + 1] (ascending, reads back to back; fewer than 2^32 reads); n_bases_total is a hint, the
  * offsets decide.  Blocks until done.
- * COVEST_E_UNSUPPORTED: k outside 19..31 or reads shorter than k; COVEST_E_NOMEM: the buckets do not fit the device,
- * or a few minimizers hold most of the k-mers (low-complexity input) -- count with covest_kmer_add_device then. */
+ * COVEST_E_UNSUPPORTED: k outside 19..31, or reads of one length (no offsets) shorter than k; COVEST_E_NOMEM: the
+ * buckets do not fit the device, or the sample of the reads misjudged them beyond what the overflow list holds --
+ * covest_kmer_clear, then count with covest_kmer_add_device (whatever the counter held before the call is not part
+ * of the result either way: the call counts into an emptied counter). */
 int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const int64_t *d_offsets, int64_t n_reads,
                                    int64_t read_len, int64_t n_bases_total, void *stream);
 /* How the last covest_kmer_count_reads_device went (the counter still holds its result): out[0] buckets, [1] minimizer
