@@ -2564,7 +2564,7 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     HIP_TRY(hipEventRecord(c->bulk_ev[2], st));
     HIP_TRY(launch_kmer_bucket_count(p, c->bulk_hist.as<unsigned long long>(), kBulkHistLen, ctl + 4,
                                      c->bulk_big.as<unsigned long long>(), kBulkBigCap, later, later_list, to_table, to_table_list,
-                                     n_cu, st));
+                                     /*small_buckets=*/(double)room <= 128.0 * (double)n_buckets, n_cu, st));
     HIP_TRY(hipEventRecord(c->bulk_ev[3], st));
     unsigned long long n_overflowed = 0, listed[2] = {0, 0};
     std::vector<unsigned long long> parts((size_t)kOvfShards * kOvfStride);

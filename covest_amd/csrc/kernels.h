@@ -121,7 +121,7 @@ hipError_t launch_kmer_place_buckets(const KmerBulk &p, unsigned long long *part
 hipError_t launch_kmer_bucket_count(const KmerBulk &p, unsigned long long *hist, unsigned long long hist_len,
                                     unsigned long long *stats, unsigned long long *big, unsigned long long big_cap,
                                     unsigned *later, unsigned *later_list, unsigned long long *to_table, unsigned *to_table_list,
-                                    int n_cu, hipStream_t stream);
+                                    bool small_buckets, int n_cu, hipStream_t stream);
 // out[0] (1 on entry) = 0 unless every read is offsets[1] - offsets[0] bases long (n_reads >= 1)
 hipError_t launch_kmer_one_length(const int64_t *offsets, int64_t n_reads, unsigned long long *out, hipStream_t stream);
 // `ops` (rounded up to 64 per thread) returning atomic adds at pseudo-random places of words[slots]

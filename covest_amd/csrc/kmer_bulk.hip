@@ -469,7 +469,7 @@ __device__ __forceinline__ void record_to_table(ulonglong2 rec, const KmerBulk &
     }
 }
 
-constexpr int kWaveSlots = 1024;     // LDS hash table of a wave: 8 KB of keys + 4 KB of counts
+constexpr int kWaveSlots = 1024;     // LDS hash table of a wave: 8 KB of keys + 4 KB of counts (or half of it, see the launch)
 constexpr int kWaveRecs = 768;       // a bucket with more records than this goes to a workgroup instead
 constexpr int kLdsSlots = 4096;      // LDS hash table of a workgroup: 32 KB of keys + 16 KB of counts
 constexpr int kLdsHistBins = 1024;   // count-of-counts bins kept in LDS per workgroup
@@ -581,19 +581,20 @@ __device__ __forceinline__ void flush_stats(SweepAcc acc, const unsigned *bins, 
 // records pass 1 sent (to the buckets and to the overflow list).
 // hist: dense count-of-counts for counts < hist_len.  later[0]: buckets left to
 // kmer_bucket_count_kernel, listed in later_list.
+template <int SLOTS>
 __global__ __launch_bounds__(256) void kmer_wave_count_kernel(const KmerBulk p, u64 *__restrict__ hist, u64 hist_len,
                                                               u64 *__restrict__ stats, u64 *__restrict__ big, u64 big_cap,
                                                               unsigned *__restrict__ later, unsigned *__restrict__ later_list)
 {
-    __shared__ u64 all_keys[256 / kWave][kWaveSlots];
-    __shared__ unsigned all_cnts[256 / kWave][kWaveSlots];
+    __shared__ u64 all_keys[256 / kWave][SLOTS];
+    __shared__ unsigned all_cnts[256 / kWave][SLOTS];
     __shared__ unsigned bins[kLdsHistBins];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     u64 *keys = all_keys[wave];
     unsigned *cnts = all_cnts[wave];
     for (int i = tid; i < kLdsHistBins; i += blockDim.x)
         bins[i] = 0u;
-    for (int i = lane; i < kWaveSlots; i += kWave) {
+    for (int i = lane; i < SLOTS; i += kWave) {
         keys[i] = kLdsEmpty;
         cnts[i] = 0u;
     }
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(256) void kmer_wave_count_kernel(const KmerBulk p, 
         const ulonglong2 c = p.ctl[b_lane];
         const u64 first = c.x, filled = p.fill[b_lane], room = c.y - c.x;
         n_records += filled;
-        const bool skip = filled > room || filled > (u64)kWaveRecs;
+        const bool skip = filled > room || filled > (u64)(kWaveRecs * SLOTS / kWaveSlots);
         const u64 skipmask = __ballot(skip);
         if (skipmask) {
             unsigned at = 0;
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void kmer_wave_count_kernel(const KmerBulk p, 
                 n_next = (unsigned)__shfl((unsigned)filled, l_next, kWave);
             }
             unsigned slots = 64;
-            while (slots < 8u * n_b && slots < (unsigned)kWaveSlots)
+            while (slots < 8u * n_b && slots < (unsigned)SLOTS)
                 slots <<= 1;
             bool ok = true;
             for (unsigned i0 = 0; i0 < n_b; i0 += kWave) {
@@ -916,11 +917,17 @@ hipError_t launch_kmer_scatter_rate(unsigned long long *words, unsigned long lon
 hipError_t launch_kmer_bucket_count(const KmerBulk &p, unsigned long long *hist, unsigned long long hist_len,
                                     unsigned long long *stats, unsigned long long *big, unsigned long long big_cap,
                                     unsigned *later, unsigned *later_list, unsigned long long *to_table, unsigned *to_table_list,
-                                    int n_cu, hipStream_t stream)
+                                    bool small_buckets, int n_cu, hipStream_t stream)
 {
-    // a wave per bucket, three workgroups of four per CU (52 KB of LDS each); then a workgroup per bucket left over
-    hipLaunchKernelGGL(kmer_wave_count_kernel, dim3((unsigned)(3 * n_cu)), dim3(256), 0, stream, p, hist, hist_len, stats, big,
-                       big_cap, later, later_list);
+    // A wave per bucket: three workgroups of four per CU with tables of 1024 slots (52 KB of LDS each) -- or five with
+    // 512 slots where the buckets are small enough for them (1 Gbp: 7.2 -> 5.8 ms; the 200 records of a 10 Gbp bucket do
+    // not fit: 44 -> 92 ms with half a million buckets left to the workgroups).  Then a workgroup per bucket left over.
+    if (small_buckets)
+        hipLaunchKernelGGL(kmer_wave_count_kernel<kWaveSlots / 2>, dim3((unsigned)(5 * n_cu)), dim3(256), 0, stream, p, hist,
+                           hist_len, stats, big, big_cap, later, later_list);
+    else
+        hipLaunchKernelGGL(kmer_wave_count_kernel<kWaveSlots>, dim3((unsigned)(3 * n_cu)), dim3(256), 0, stream, p, hist, hist_len,
+                           stats, big, big_cap, later, later_list);
     hipLaunchKernelGGL(kmer_bucket_count_kernel, dim3((unsigned)(3 * n_cu)), dim3(256), 0, stream, p, hist, hist_len, stats, big,
                        big_cap, later, later_list, to_table, to_table_list);
     return hipGetLastError();
