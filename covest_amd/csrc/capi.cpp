@@ -84,6 +84,37 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(ptr); }
 };
 
+// Page-locked host memory that is kept from call to call: what a call stages for the device goes through here.  (A
+// pageable source makes hipMemcpy pin and unpin it, or bounce it, per call -- from a few hundred KB on that is most
+// of a point-list evaluation's time, and how much depends on the machine: 64 points took 214 us on one box of the pool
+// and 430 on another, 128 points 0.4 and 27 ms.)
+struct HostBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (ptr)
+            (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        if (e == hipSuccess)
+            cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(ptr); }
+};
+
 } // namespace
 
 struct covest_model {
@@ -110,6 +141,7 @@ struct covest_model {
     bool has_tiles = false;
     // scratch for covest_eval_points / covest_probabilities
     DevBuf ws_params, ws_t, ws_out, ws_p, ws_plan, ws_plan2, ws_partial, ws_items;
+    HostBuf ws_stage; // staging of a point list's tables (build_list_plan)
     DevBuf ws_sub_index, ws_sub_word, ws_sub_ctl; // the queue of handed-back points of a point-list launch (direct_point.h)
     std::mutex lock;
 };
@@ -1092,25 +1124,27 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     for (auto &pr : iparts)
         n_int += pr.second;
     HIP_TRY(buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
-    // one staging buffer, one copy
-    std::vector<char> stage(n_dbl * sizeof(double) + n_int * sizeof(int32_t));
+    // one staging buffer (page-locked, the model's), one copy
+    const size_t stage_bytes = n_dbl * sizeof(double) + n_int * sizeof(int32_t);
+    HIP_TRY(m->ws_stage.reserve(stage_bytes));
+    char *stage = m->ws_stage.as<char>();
     double *dbase = buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
     std::vector<const double *> dptr;
     std::vector<const int32_t *> iptr;
     size_t off = 0;
     for (auto &pr : dparts) {
-        std::memcpy(stage.data() + off * sizeof(double), pr.first, pr.second * sizeof(double));
+        std::memcpy(stage + off * sizeof(double), pr.first, pr.second * sizeof(double));
         dptr.push_back(dbase + off);
         off += pr.second;
     }
     off = 0;
     for (auto &pr : iparts) {
-        std::memcpy(stage.data() + n_dbl * sizeof(double) + off * sizeof(int32_t), pr.first, pr.second * sizeof(int32_t));
+        std::memcpy(stage + n_dbl * sizeof(double) + off * sizeof(int32_t), pr.first, pr.second * sizeof(int32_t));
         iptr.push_back(ibase + off);
         off += pr.second;
     }
-    HIP_TRY(hipMemcpy(buf.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(buf.ptr, stage, stage_bytes, hipMemcpyHostToDevice));
     pl = FactoredPlan{};
     pl.c_axis = dptr[0];
     pl.e_axis = dptr[0] + n;
@@ -1298,6 +1332,7 @@ void covest_model_destroy(covest_model *m)
     m->ws_p.release();
     m->ws_plan.release();
     m->ws_plan2.release();
+    m->ws_stage.release();
     m->ws_partial.release();
     m->ws_items.release();
     m->ws_sub_index.release();
