@@ -359,6 +359,11 @@ for seed in range(16):
         run("fuzz %d ragged" % seed, reads, k, bool(seed & 2))
     else:
         run("fuzz %d" % seed, reads, k, bool(seed & 2), fixed_len=L, expect="partitioned")
+# the smallest inputs: one read of exactly k bases, no read at all, reads of no bases, a read one base short of k
+run("one window", ["ACGTTGCAAGGCTTAACCGGT"], 21, True, fixed_len=21)
+run("no reads", [], 21, True)
+run("empty reads", ["", "", "A"], 21, True)
+run("k - 1 bases", ["A" * 20, "ACGTTGCAAGGCTTAACCGG"], 21, False)
 # k the partitioned path does not take
 run("k=12", genome_reads(3000, 60, 5000), 12, True, fixed_len=60, expect="table")
 assert any(p == "partitioned" for _, _, p in taken)
