@@ -90,3 +90,34 @@ def test_a_failing_evaluation_reaches_the_caller():
     except Boom:
         return
     raise AssertionError("the failure was swallowed")
+
+
+def test_restated_difference_scheme_is_scipys():
+    """The finite-difference steps and quotient of estimator._fd_steps against the installed scipy's approx_derivative:
+    the probe the estimator runs before it trusts them, then random points inside, on and within a step of the bounds,
+    and a whole refinement through either path."""
+    from scipy.optimize._numdiff import approx_derivative
+    from covest_amd import estimator as est_mod
+    lo = np.array([0.01, 0.0, 0.3, 0.0, 0.0])
+    hi = np.array([np.inf, 0.5, 1.0, 1.0, 1.0])
+    assert est_mod._fd_fast_matches_scipy(lo, hi, 1e-8)
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        x = np.where(np.isfinite(hi), lo + (hi - lo) * rng.random(5), lo + 100 * rng.random(5))
+        snap = rng.integers(0, 5, size=5)  # 1: on the lower bound, 2: on the upper, 3 / 4: half a step inside it
+        x = np.where(snap == 1, lo, x)
+        x = np.where((snap == 2) & np.isfinite(hi), hi, x)
+        x = np.where(snap == 3, lo + 0.5e-8, x)
+        x = np.where((snap == 4) & np.isfinite(hi), hi - 0.5e-8, x)
+        seen = []
+        approx_derivative(lambda z: seen.append(np.array(z)) or 0.0, x, method='2-point', abs_step=1e-8, f0=0.0, bounds=(lo, hi))
+        steps = est_mod._fd_steps(x, lo, hi, 1e-8)
+        for i, z in enumerate(seen):
+            want = x.copy()
+            want[i] = x[i] + steps[i]
+            assert np.array_equal(z, want), (trial, i, x, z, want)
+    for start in ([10.0, 0.05, 0.8, 0.5, 0.3], [0.01, 0.0, 0.3, 1.0, 0.0]):
+        fast, slow = CoverageEstimator(_StubModel()), CoverageEstimator(_StubModel())
+        slow._fd_fast = False  # scipy's approx_derivative twice per gradient, as before round 3
+        a, b = fast._optimize(start), slow._optimize(start)
+        assert fast._fd_fast is True and _same(a, b), (start, a.x, b.x)
