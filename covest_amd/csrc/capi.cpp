@@ -100,7 +100,7 @@ struct HostBuf {
         ptr = nullptr;
         cap = 0;
         const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 16);
-        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocPortable); // (any device of the process may copy from it)
         if (e == hipSuccess)
             cap = want;
         return e;
@@ -114,6 +114,19 @@ struct HostBuf {
     }
     template <class T> T *as() const { return static_cast<T *>(ptr); }
 };
+
+// ONE page-locked staging buffer for the uploads that handles make when they are created or re-configured (bins, tile
+// tables, axes, plans: tens to hundreds of KB, each copy blocking): kept for the life of the process, so that a
+// handle's creation pays neither a pageable copy nor a page-locked allocation of its own.
+struct SharedStage {
+    std::mutex mu;
+    HostBuf buf;
+};
+SharedStage &shared_stage()
+{
+    static SharedStage *s = new SharedStage; // (never freed: the runtime may be gone when statics are destroyed)
+    return *s;
+}
 
 } // namespace
 
@@ -347,11 +360,16 @@ int upload_bins(DevBuf &buf, BinView &view, const std::vector<double> &key,
         return COVEST_OK;
     HIP_TRY(buf.reserve(3 * n * sizeof(double)));
     double *base = buf.as<double>();
-    std::vector<double> stage(3 * n);
-    std::copy(key.begin(), key.end(), stage.begin());
-    std::copy(lgam.begin(), lgam.end(), stage.begin() + (std::ptrdiff_t)n);
-    std::copy(cnt.begin(), cnt.end(), stage.begin() + (std::ptrdiff_t)(2 * n));
-    HIP_TRY(hipMemcpy(base, stage.data(), stage.size() * sizeof(double), hipMemcpyHostToDevice));
+    {
+        SharedStage &ss = shared_stage();
+        std::lock_guard<std::mutex> hold(ss.mu);
+        HIP_TRY(ss.buf.reserve(3 * n * sizeof(double)));
+        double *stage = ss.buf.as<double>();
+        std::copy(key.begin(), key.end(), stage);
+        std::copy(lgam.begin(), lgam.end(), stage + n);
+        std::copy(cnt.begin(), cnt.end(), stage + 2 * n);
+        HIP_TRY(hipMemcpy(base, stage, 3 * n * sizeof(double), hipMemcpyHostToDevice));
+    }
     view.key = base;
     view.lgam = base + n;
     view.cnt = base + 2 * n;
@@ -536,8 +554,11 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     HIP_TRY(m->tiles_buf.reserve(bytes));
     double *base = m->tiles_buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(base + n_dbl);
-    std::vector<char> stage(bytes); // one copy instead of five
-    char *sp = stage.data();
+    SharedStage &ss = shared_stage();
+    std::lock_guard<std::mutex> hold(ss.mu);
+    HIP_TRY(ss.buf.reserve(bytes)); // one copy instead of five
+    char *const stage = ss.buf.as<char>();
+    char *sp = stage;
     auto put = [&](const void *src, size_t n) {
         std::memcpy(sp, src, n);
         sp += n;
@@ -556,7 +577,7 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     put(item_ntiles.data(), ni * sizeof(int32_t));
     put(item_sum.data(), ni * sizeof(int32_t));
     put(row_bin.data(), nt * kTileBins * sizeof(int32_t));
-    HIP_TRY(hipMemcpy(base, stage.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base, stage, bytes, hipMemcpyHostToDevice));
     m->tv = tile_view_from((int32_t)nt, (int32_t)ni, base, ibase);
     m->has_tiles = true;
     return COVEST_OK;
@@ -830,8 +851,11 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
     {
         // staged on the host in the device layout, ONE copy (a dozen small copies cost ~150 us of the plan build)
-        std::vector<char> stage(n_dbl * sizeof(double) + n_int * sizeof(int32_t));
-        double *sd = reinterpret_cast<double *>(stage.data());
+        const size_t stage_bytes = n_dbl * sizeof(double) + n_int * sizeof(int32_t);
+        SharedStage &ss = shared_stage();
+        std::lock_guard<std::mutex> hold(ss.mu);
+        HIP_TRY(ss.buf.reserve(stage_bytes));
+        double *sd = ss.buf.as<double>();
         int32_t *si = reinterpret_cast<int32_t *>(sd + n_dbl);
         std::copy(r4.begin(), r4.end(), sd);
         std::copy(piece_w.begin(), piece_w.end(), sd + n_slots);
@@ -846,7 +870,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         std::copy(unit_len.begin(), unit_len.end(), sp + 4 * n_unit);
         std::copy(unit_cont.begin(), unit_cont.end(), sp + 5 * n_unit);
         std::copy(unit_nsh.begin(), unit_nsh.end(), sp + 6 * n_unit);
-        HIP_TRY(hipMemcpy(buf.ptr, stage.data(), stage.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(buf.ptr, sd, stage_bytes, hipMemcpyHostToDevice));
     }
     pl = FactoredPlan{};
     pl.c_axis = g->src.axis[0];
@@ -1849,8 +1873,12 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
     HIP_TRY(g->arena.reserve(bytes));
     char *base = g->arena.as<char>();
     {
-        std::vector<char> stage(o_ll, 0);
-        double *sa = reinterpret_cast<double *>(stage.data());
+        SharedStage &ss = shared_stage();
+        std::lock_guard<std::mutex> hold(ss.mu);
+        HIP_TRY(ss.buf.reserve(o_ll));
+        char *stage = ss.buf.as<char>();
+        std::memset(stage, 0, o_ll);
+        double *sa = reinterpret_cast<double *>(stage);
         for (int d = 0; d < n_axes; ++d) {
             g->len[d] = axis_len[d];
             std::copy(axes[d], axes[d] + axis_len[d], sa);
@@ -1859,8 +1887,8 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
         for (int d = n_axes; d < kMaxParams; ++d)
             g->len[d] = 1;
         if (nq)
-            std::memcpy(stage.data() + o_table, table.data(), (size_t)nq * sizeof(int32_t));
-        HIP_TRY(hipMemcpy(base, stage.data(), stage.size(), hipMemcpyHostToDevice));
+            std::memcpy(stage + o_table, table.data(), (size_t)nq * sizeof(int32_t));
+        HIP_TRY(hipMemcpy(base, stage, o_ll, hipMemcpyHostToDevice));
     }
     g->axes.ptr = base + o_axes;
     g->sub_ctl.ptr = base + o_ctl;
