@@ -2533,10 +2533,13 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
     p.m = std::min(k - 8, 13);
     p.canonical = c->canonical;
     p.max_run = 32 - k + 1;
-    // ~256 windows per bucket (a wave's LDS table of pass 2 holds 1024 keys), at least 2^10 buckets, at most an eighth
-    // of the minimizers there are
+    // 1000-2000 windows per bucket, at least 2^10 buckets, at most an eighth of the minimizers there are.  Measured
+    // (diagnostic build, COVEST_KMER_LG): 1 Gbp 2^22 / 2^21 / 2^20 / 2^19 buckets 20.3 / 18.2 / 17.8 / 16.5 ms, 10 Gbp
+    // 2^25 / 2^24 / 2^23 / 2^22 / 2^21 205 / 174 / 141-155 / 143-145 / 146 ms: fewer, fuller buckets keep the sectors
+    // that pass 1 writes into within the caches' reach and the sample of pass 0 thin; a bucket of 2000 windows still
+    // fits a workgroup's LDS table when every one of them is a different key.
     int lg = 10;
-    while (lg < 2 * p.m - 3 && (double)((int64_t)1 << lg) * 256.0 < windows)
+    while (lg < 2 * p.m - 3 && (double)((int64_t)1 << lg) * 2048.0 < windows)
         ++lg;
 #ifdef COVEST_DIAG // diagnostic builds only: the shipped library has no knobs
     if (const char *e = std::getenv("COVEST_KMER_M"))
