@@ -126,7 +126,9 @@ __device__ __forceinline__ void append_record(unsigned b, u64 code, int n_bases,
         return;
     }
     // (the cursors are an array of their own, touched by atomics only: atomics on lines that plain loads of the same
-    // kernel keep in the caches run at a tenth of the rate -- measured)
+    // kernel keep in the caches run at a tenth of the rate -- measured, DESIGN.md 6b.  Also measured: {cursor, end} in
+    // one element with the end read by an agent-scope atomic load -- one line a record instead of two -- is SLOWER,
+    // 137-141 against 102-103 ms at 10 Gbp)
     const ulonglong2 place = p.ctl[b];
     const u64 pos = place.x + (u64)atomicAdd(&p.fill[b], (KmerBulk::fill_t)1);
     if (pos < place.y) {
