@@ -340,11 +340,12 @@ def bench_kmer(args):
         "roofline": dict({"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                           "frac": dominant["achieved"] / HBM_PEAK_GBPS, "traffic": None}, **dominant),
     }
-    counts.clear(stream)  # (from_file counts through the table: an ordinary counter again)
-    out["config"]["from_file"] = kmer_from_file(reads, n_reads, read_len, k, counts)
+    if not args.compact:
+        counts.clear(stream)  # (from_file counts through the table: an ordinary counter again)
+        out["config"]["from_file"] = kmer_from_file(reads, n_reads, read_len, k, counts)
     if args.cpu_budget > 0:
         from oracle import kmer_oracle as ko
-        n_s = 20000
+        n_s = 5000 if args.compact else 20000
         sample = [bytes(reads[i * read_len:(i + 1) * read_len].cpu().numpy()).decode() for i in range(n_s)]
         t0 = time.perf_counter()
         ko.histogram(sample, k, canonical=True)
@@ -600,6 +601,54 @@ def strong_variant(cls, hist, args, world, rank, local_rank, xdev, on_device, st
     return out
 
 
+def other_configs(args):
+    """The default (driver-timed) run carries every single-GPU configuration of BASELINE.json, not only C3: config 2
+    (basic model, 10^6 points), config 5 (k-mer histogram; 10 Gbp when >= 200 GB of HBM are free, else 1 Gbp) and the
+    reference's consumer of batched evaluations (optimize_grid), each run as a CHILD process of this one -- its own
+    model handles and HBM, its own JSON line -- and reported in compact form under variants.{c2,c5,og}.  The children
+    run one after the other after this process's own timed region; their CPU baselines are capped at 4 s each."""
+    import subprocess
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    gbp = 10.0 if free_b >= 200e9 else 1.0
+    runs = [("c2", ["--workload", "c2", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-budget", "4"]),
+            ("c5", ["--workload", "c5", "--kmer-gbp", str(gbp), "--steps", "3", "--warmup", "1", "--cpu-budget", "1"]),
+            ("og", ["--workload", "og", "--steps", "3"])]
+    out = {}
+    for name, extra in runs:
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--compact"] + extra, capture_output=True,
+                               text=True, timeout=240)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                out[name] = {"error": "rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-300:])}
+                continue
+            r = json.loads(line[-1])
+        except (subprocess.TimeoutExpired, ValueError) as e:
+            out[name] = {"error": repr(e)[:300]}
+            continue
+        roof = r.get("roofline", {})
+        c = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+             "workload": r["config"]["workload"], "kernel": roof.get("kernel"), "kernel_ms_avg": roof.get("kernel_ms_avg"),
+             "roofline": {"bound": roof.get("bound"), "frac": roof.get("frac"), "achieved": roof.get("achieved"),
+                          "unit": roof.get("unit")},
+             "cpu_baseline": {k: r["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")} if "cpu_baseline" in r else None,
+             "wall_s": time.perf_counter() - t0}
+        if "executed" in roof:
+            c["roofline"]["executed_frac"] = roof["executed"]["frac"]
+        if "atomics" in roof:
+            c["roofline"]["atomics_frac"] = roof["atomics"]["frac"]
+            c["passes_ms"] = roof.get("passes_ms")
+        if "argmin" in r:
+            c["argmin"] = r["argmin"]
+        if "cases" in r:
+            c["cases"] = [{k: case[k] for k in ("histogram", "iterations", "points_evaluated", "time_to_argmin_s", "split_ms")}
+                          for case in r["cases"]]
+        out[name] = c
+    return out
+
+
 def bench_optimize_grid(args):
     """Workload og: the reference's actual consumer of batched evaluations -- covest.grid.optimize_grid
     (covest/grid.py:17-79), repeats model, free (c, e, q1, q2, q).  Case A: the reference's own 15-bin test
@@ -667,6 +716,11 @@ def main():
                     help="process-group backend (nccl == RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal: every rank uses device 0 (needs --backend gloo)")
+    ap.add_argument("--compact", action="store_true",
+                    help="(set by the default run for its child runs) leave out the legs that only feed profiles/: c5's "
+                         "from-file leg, c3's tail variant and the children themselves")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="c3, one GPU: do not run the other single-GPU configurations (c2, c5, og) as child processes")
     args = ap.parse_args()
     if args.workload == "c5":
         return bench_kmer(args)
@@ -807,8 +861,10 @@ def main():
         torch.cuda.synchronize()
         exchange_us = 1e6 * (time.perf_counter() - t1) / 20
     variants = None
-    if rank == 0 and world == 1 and args.workload == "c3" and args.scaling == "weak":
+    if rank == 0 and world == 1 and args.workload == "c3" and args.scaling == "weak" and not args.compact:
         variants = {"tail": tail_variant(cls, axes, args, local_rank, stream)}
+        if not args.no_variants:
+            variants.update(other_configs(args))
     if world > 1 and args.workload == "c3" and args.scaling == "weak":  # (every rank takes part)
         variants = {"strong": strong_variant(cls, hist, args, world, rank, local_rank, xdev, on_device, stream)}
 
@@ -858,6 +914,9 @@ def main():
                                          "78.6 TFLOP/s is both the fp64 vector and the dense fp64 MFMA peak of MI355X",
                 "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_from": None if traffic is None else "profiles/pmc_traffic.json: PMC passes of the same kernel "
+                                "and workload under rocprofv3 (tools/pmc_profile.sh), 2 x FETCH_SIZE + WRITE_SIZE per "
+                                "launch; NOT counted in this run",
                 "kernel": kernel_name, "kernel_ms_avg": 1e3 * avg_kernel_s, "launches": launches,
                 "algorithmic_flops_per_launch": flops, "pmf_terms_per_launch": terms,
                 "hbm": {"achieved": alg_bytes / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -13,9 +13,9 @@ LIB_PATH = os.environ.get("COVEST_AMD_LIB", os.path.join(_HERE, "lib", "libcoves
 
 MAX_PARAMS = 5
 MODEL_BASIC, MODEL_REPEATS = 0, 1
-KERNEL_AUTO, KERNEL_DIRECT, KERNEL_RECUR, KERNEL_FACTORED = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_DIRECT, KERNEL_RECUR, KERNEL_FACTORED, KERNEL_DIRECT_REF = 0, 1, 2, 3, 4
 KERNELS = {"auto": KERNEL_AUTO, "direct": KERNEL_DIRECT, "recur": KERNEL_RECUR,
-           "factored": KERNEL_FACTORED}
+           "factored": KERNEL_FACTORED, "direct_ref": KERNEL_DIRECT_REF}
 
 # every symbol include/covest_amd.h declares (tests check the library exports them all)
 EXPORTS = (

@@ -1438,6 +1438,8 @@ static int resolve_kernel(const covest_model *m, int32_t kernel, const covest_gr
         return COVEST_KERNEL_DIRECT;
     case COVEST_KERNEL_DIRECT:
         return COVEST_KERNEL_DIRECT;
+    case COVEST_KERNEL_DIRECT_REF:
+        return COVEST_KERNEL_DIRECT_REF;
     case COVEST_KERNEL_RECUR:
         if (basic_fast)
             return COVEST_KERNEL_RECUR;
@@ -1505,6 +1507,10 @@ static SubList sub_list_of(const covest_model *m, int t_max, void *index, void *
     l.index = static_cast<int64_t *>(index);
     l.word = static_cast<unsigned long long *>(word);
     l.index_offset = 0;
+#ifdef COVEST_DIAG // diagnostic builds only (direct_point.h SubList::diag_class): the shipped library has no knobs
+    const char *dc = std::getenv("COVEST_DIAG_BASIC_CLASS");
+    l.diag_class = dc ? std::atoi(dc) : 0;
+#endif
     return l;
 }
 
@@ -1527,8 +1533,8 @@ static hipError_t launch_ll(const covest_model *m, int kernel, const PointSource
         return e != hipSuccess ? e : launch_ll_fix_list(m->dm, m->tv, src, out, sub, st);
     }
     if (name)
-        *name = "ll_direct";
-    return launch_ll_direct(m->dm, src, n, out, nullptr, st);
+        *name = kernel == COVEST_KERNEL_DIRECT_REF ? "ll_direct_ref" : "ll_direct";
+    return launch_ll_direct(m->dm, src, n, out, nullptr, st, kernel == COVEST_KERNEL_DIRECT_REF);
 }
 
 // Workspace of a point-list launch's queue (direct_point.h): room for n entries, counters zeroed on first use.

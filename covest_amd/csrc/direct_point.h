@@ -42,6 +42,17 @@ namespace covest {
 // contribution by h_j safe_log(p_j).
 constexpr unsigned long long kSubFieldMask = 0xFFFFFull; // 20 bits: rows < 2^20 (16384 keys, one tile each, at worst)
 constexpr double kClampPerTerm = 7e-317; // see above
+// WHEN IS p_j ZERO IN THE REFERENCE?  (round 4: found by comparing K-basic with K-direct on ALL 10^6 points of C2 -- one
+// point, p_j = 0.9987 x 2^-1075, was -inf here and finite there and in the reference.)  The reference rounds every
+// term onto the 4.94e-324 grid on its way: the extension's cast to double (c_src/covest_poissonmodule.c:32, ties to even:
+// anything above half a grid step survives), then a_os * TP (covest/models.py:93,238: survives if a_os > 1/2), then, repeats
+// model, b_o * (sum over s) (:237-241: survives if b_o > 1/2).  So the reference's p_j can be ONE GRID STEP when the exact
+// value is as small as 1/4 of a step (basic model) or 1/8 (repeats model) -- and h_j log(4.94e-324) is finite where
+// h_j log(0) is -inf.  A recurrence kernel's own product, rounded once, is 0 below 1/2 step: it must not decide.  Below
+// kZeroSteps grid steps (EXACT value, tested before the product underflows) a p_j is zero in the reference whatever the
+// roundings were; between that and p_clamp the row is handed back to the term-by-term evaluation.
+constexpr double kZeroSteps = 0.12;
+constexpr double kGridStep = 4.94065645841246544e-324;
 
 __host__ __device__ inline unsigned long long sub_word(unsigned first, unsigned last, bool units16)
 {
@@ -58,6 +69,13 @@ struct SubList {
     int64_t *index;           // [capacity] index into the launch's LL buffer
     unsigned long long *word; // [capacity]
     int64_t index_offset;     // added by the launcher when it cuts a launch into parts
+#ifdef COVEST_DIAG
+    // DIAGNOSTIC builds only (tiles.h): K-basic writes, INSTEAD of the log-likelihood, 1: the class of the point's
+    // route through its closed form (ll_basic.hip kClass*), 2: the smaller of log p_j at the first and at the last
+    // counted key the closed form was asked about (NaN where it was not asked).  tools/dump_c2_classes.py uses it to
+    // choose WHERE the reference is asked (tests/golden/make_golden.py section c2classes); env COVEST_DIAG_BASIC_CLASS.
+    int diag_class;
+#endif
 #ifdef __HIPCC__
     __device__ __forceinline__ void push(int64_t idx, unsigned long long w) const
     {
@@ -121,8 +139,17 @@ __device__ __forceinline__ double strict_pj_wave(const DevModel &m, const double
     return p;
 }
 
+// ln(LDBL_MAX) of the x87 long double the reference's product lives in (c_src/covest_poissonmodule.c:19-24)
+constexpr double kLnLdblMax = 11356.523406294143949492;
+
 // All 64 lanes of a wave call this with the same point; every lane returns the point's LL.
-template <int P, bool WRITE_P>
+// REF_OVF (COVEST_KERNEL_DIRECT_REF): the reference's OVERFLOW reproduced.  truncated_poisson forms the whole product
+// prod_{i <= j} (x / i) in long double before any scaling (c_src/covest_poissonmodule.c:22-24) and returns +inf once the
+// running product passes LDBL_MAX -- it grows until i = floor(x), so the term of (x, j) is +inf iff
+// m ln x - ln m! > ln LDBL_MAX for m = min(j, floor(x)).  Then p_j = +inf, log p_j = +inf, and the likelihood is +inf,
+// or NaN where another counted key has p_j = 0 (inf - inf); sp_j = min(1, fsum(...)) = 1 and the tail term is dropped
+// (covest/models.py:103-105).  optimize_grid WOULD select such a point (covest/grid.py:65-70: -(+inf) < anything).
+template <int P, bool WRITE_P, bool REF_OVF = false>
 __device__ __forceinline__ double direct_point_ll(const DevModel &m, const PointSource &src, int64_t pt,
                                                   double *__restrict__ out_p)
 {
@@ -144,6 +171,7 @@ __device__ __forceinline__ double direct_point_ll(const DevModel &m, const Point
     double acc_ll = 0.0;
     CompSum acc_sp = {0.0, 0.0};
     const int64_t n_bins = m.bins.n;
+    bool saw_special = false; // REF_OVF: a p_j that is +inf (or NaN) -- sp_j is then not < 1
 
     for (int64_t base = 0; base < n_bins; base += (int64_t)kWave * kBinsPerLane) {
         double key[kBinsPerLane], nlg[kBinsPerLane], p[kBinsPerLane], inner[kBinsPerLane];
@@ -178,6 +206,14 @@ __device__ __forceinline__ double direct_point_ll(const DevModel &m, const Point
             }
             if (!live)
                 a_os = 0.0;
+            // REF_OVF: can this component's product overflow at all (its largest value, at i = floor(x)), and from
+            // which key on is that value reached
+            double fx = INFINITY;
+            if (REF_OVF && live && x >= 1.0) {
+                const double top = floor(x);
+                if (fma(top, lx, -lgamma(top + 1.0)) > kLnLdblMax)
+                    fx = top;
+            }
 
             // ---- every lane accumulates all components for its own bins ----
             const int n_comp = min(OT, T - o0) * S;
@@ -186,9 +222,19 @@ __device__ __forceinline__ double direct_point_ll(const DevModel &m, const Point
                 if (a_i != 0.0) { // wave-uniform; NaN falls through and poisons p_j as in the reference
                     const double l_i = wave_bcast(lx, i);
                     const double d_i = wave_bcast(nd, i);
+                    const double fx_i = REF_OVF ? wave_bcast(fx, i) : INFINITY;
+                    if (REF_OVF && fx_i < INFINITY) { // (wave-uniform, rare) this component overflows somewhere
 #pragma unroll
-                    for (int b = 0; b < kBinsPerLane; ++b)
-                        inner[b] += a_i * exp(fma(key[b], l_i, d_i + nlg[b]));
+                        for (int b = 0; b < kBinsPerLane; ++b) {
+                            // the running product grows up to i = floor(x): past LDBL_MAX at this key?
+                            const bool ovf = key[b] >= fx_i || fma(key[b], l_i, nlg[b]) > kLnLdblMax;
+                            inner[b] += a_i * (ovf ? INFINITY : exp(fma(key[b], l_i, d_i + nlg[b])));
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < kBinsPerLane; ++b)
+                            inner[b] += a_i * exp(fma(key[b], l_i, d_i + nlg[b]));
+                    }
                 }
                 if ((i + 1) % S == 0) { // end of one copy-number class: p_j += b_o * inner  models.py:237
                     const double b_i = wave_bcast(b_o, i);
@@ -207,7 +253,10 @@ __device__ __forceinline__ double direct_point_ll(const DevModel &m, const Point
             const int64_t idx = base + (int64_t)b * kWave + lane;
             if (idx < n_bins) {
                 const double h = m.bins.cnt[idx];
-                acc_sp.add(p[b]);
+                if (REF_OVF && !(p[b] < INFINITY))
+                    saw_special = true; // (+inf or NaN: kept out of the compensated sum, whose error terms it would poison)
+                else
+                    acc_sp.add(p[b]);
                 if (h != 0.0)
                     acc_ll += h * ((p[b] <= 0.0) ? -INFINITY : log(p[b]));
                 if (WRITE_P)
@@ -224,6 +273,8 @@ __device__ __forceinline__ double direct_point_ll(const DevModel &m, const Point
             sp = 1.0; // min(1, fsum(...)), NaN -> 1
         if (sp < 1.0)
             tail_term = m.tail * log(1.0 - sp);
+        if (REF_OVF && __any(saw_special))
+            tail_term = 0.0; // min(1, fsum(...)) of a sum with +inf (or NaN) in it is 1: covest/models.py:103-104
     }
     return acc_ll + tail_term;
 }

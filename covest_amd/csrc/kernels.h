@@ -12,8 +12,9 @@ namespace covest {
 // K-direct: one wavefront per grid point, one exp per pmf term (ll_direct.hip).
 // out_ll[n]; when out_p != nullptr (n must be 1) also writes p_j for every bin
 // of `m.bins`.
+// ref_overflow: the reference's long-double overflow reproduced (direct_point.h REF_OVF; out_p must be nullptr).
 hipError_t launch_ll_direct(const DevModel &m, const PointSource &src, int64_t n, double *out_ll,
-                            double *out_p, hipStream_t stream);
+                            double *out_p, hipStream_t stream, bool ref_overflow = false);
 
 // K-basic: basic model, one lane per grid point, pmf recurrence (ll_basic.hip).
 // Needs n_err == 8 and a tile table (keys in 1..16384).

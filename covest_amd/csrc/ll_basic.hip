@@ -70,9 +70,11 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     const double p_clamp = sub_list.p_clamp;
     CompSum acc_sp = {0.0, 0.0};
 
-    // one key's p_j (flushed like the reference's double): into sp_j, and its log (all branches
-    // wave-uniform)
-    auto account = [&](double p, double h, int row) {
+    // one key's p_j = g * sc (the streams' scaled sum times the key's scale: flushed like the reference's double): into
+    // sp_j, and its log (all branches wave-uniform)
+    const double zero_thr = kZeroSteps * kGridStep * 0x1p64; // direct_point.h kZeroSteps, against g * 2^64 * sc
+    auto account = [&](double g, double sc, double h, int row) {
+        const double p = g * sc;
         if (TAIL)
             acc_sp.add(p); // (filler keys have scale 0: p == 0)
         if (h != 0.0) { // filler keys and zero counts: no log (`if h`, covest/models.py:106)
@@ -82,9 +84,13 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
             // one compare per key for everything out of the ordinary (lanes already dead have nothing to add)
             const uint64_t low = __ballot(p < p_clamp) & ~dead;
             if (__builtin_expect(low != 0, 0)) { // wave-uniform, cold
-                // utils.safe_log: p_j <= 0 makes the whole sum -inf -- remembered as a lane mask in SGPRs
-                dead |= __ballot(p <= 0.0);
-                if (p > 0.0 && p < p_clamp) // deep in the subnormal range: name the row (rows come in ascending order)
+                // utils.safe_log: p_j <= 0 makes the whole sum -inf -- remembered as a lane mask in SGPRs.  Decided on
+                // the EXACT value (g * 2^64 cannot overflow here: p < p_clamp bounds g by 1e-12), not on the product's
+                // own flush to 0 below half a grid step: the reference's roundings keep p_j alive down to a quarter
+                // of one (direct_point.h kZeroSteps); what lies between is a row for the strict evaluation
+                const bool zero = ldexp(g, 64) * sc <= zero_thr; // (NaN: not a zero -- a NaN stays a NaN)
+                dead |= __ballot(zero);
+                if (!zero && p < p_clamp) // deep in the subnormal range: name the row (rows come in ascending order)
                     subw = subw ? sub_word(sub_first(subw), (unsigned)row, false) : sub_word((unsigned)row, (unsigned)row, false);
             }
         }
@@ -146,13 +152,13 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
                 for (int b = 0; b < 16; b += 2) {
                     double g1, g2;
                     st.template step2n<N>(xx, g1, g2);
-                    account(g1 * sc[b], hc[b], t * kTileBins + 16 * half + b);
-                    account(g2 * sc[b + 1], hc[b + 1], t * kTileBins + 16 * half + b + 1);
+                    account(g1, sc[b], hc[b], t * kTileBins + 16 * half + b);
+                    account(g2, sc[b + 1], hc[b + 1], t * kTileBins + 16 * half + b + 1);
                 }
             }
         } else {
             for (int b = 0; b < nb; ++b)
-                account(st.template step_n<N>() * scal[b], cnt[b], t * kTileBins + b);
+                account(st.template step_n<N>(), scal[b], cnt[b], t * kTileBins + b);
         }
         st.template leave_tile_n<N>(tv.renorm[t]);
     };
@@ -183,6 +189,12 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     // its WAVE through the key-by-key walk, which names the rows for the strict evaluation; in a grid that is a band
     // a few points wide.  C2 spends 330 of its 367 keys here.
     bool walk_rest = t < tv.n_tiles;
+#ifdef COVEST_DIAG
+    // the point's route, for tools/dump_c2_classes.py: 0 the closed form was never asked (every tile walked with all
+    // streams, a tail, or no counted key left), 1 closed form taken, 2 -inf by its bound, 3 a lane that would have taken
+    // 1 or 2 but whose WAVE walks because of another lane, 4 a lane that sends its wave through the walk
+    double diag_class = 0.0, diag_lp = NAN;
+#endif
     if (!TAIL && walk_rest) {
         const double first = tv.suf_first[t];
         if (first == 0.0) {
@@ -194,6 +206,11 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
             const double lp_min = fmin(lp_first, lp_last);
             const bool fine = lp_min > sub_list.log_p_clamp + 0.5;
             const bool none = lp_first < -746.5 || lp_last < -746.5; // (a stream that is off has c_0 = -inf)
+#ifdef COVEST_DIAG
+            diag_lp = lp_min;
+            const bool diag_walks = __any(finite && !fine && !none);
+            diag_class = (finite && !fine && !none) ? 4.0 : diag_walks ? 3.0 : fine ? 1.0 : 2.0;
+#endif
             if (!__any(finite && !fine && !none)) { // wave-uniform
                 walk_rest = false;
                 dead |= __ballot(none && !fine);
@@ -223,6 +240,12 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     }
     if (!isfinite(ll))
         subw = 0; // -inf (or NaN) whatever the handed-back keys are worth
+#ifdef COVEST_DIAG
+    if (sub_list.diag_class != 0) {
+        ll = sub_list.diag_class == 1 ? diag_class : diag_lp;
+        subw = 0;
+    }
+#endif
     if (live) {
         out_ll[pt] = ll;
         if (subw != 0) // (rare) queue the point for ll_fix_list_kernel

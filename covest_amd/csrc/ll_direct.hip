@@ -35,7 +35,7 @@ namespace covest {
 
 namespace {
 
-template <int P, bool WRITE_P>
+template <int P, bool WRITE_P, bool REF_OVF = false>
 __global__ __launch_bounds__(256) void ll_direct_kernel(const DevModel m, const PointSource src,
                                                         const int64_t n, double *__restrict__ out_ll,
                                                         double *__restrict__ out_p)
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ll_direct_kernel(const DevModel m, const 
     const int64_t pt = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
     if (pt >= n)
         return; // wave-uniform
-    const double ll = direct_point_ll<P, WRITE_P>(m, src, pt, out_p);
+    const double ll = direct_point_ll<P, WRITE_P, REF_OVF>(m, src, pt, out_p);
     if (lane == 0)
         out_ll[pt] = ll;
 }
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void ll_direct_kernel(const DevModel m, const 
 } // namespace
 
 hipError_t launch_ll_direct(const DevModel &m, const PointSource &src, int64_t n, double *out_ll,
-                            double *out_p, hipStream_t stream)
+                            double *out_p, hipStream_t stream, bool ref_overflow)
 {
     if (n <= 0)
         return hipSuccess;
@@ -71,7 +71,12 @@ hipError_t launch_ll_direct(const DevModel &m, const PointSource &src, int64_t n
             part.t_list = src.t_list ? src.t_list + first : nullptr;
         }
         double *out = out_ll + first;
-        if (m.kind == 0) {
+        if (ref_overflow && !out_p) { // COVEST_KERNEL_DIRECT_REF (direct_point.h REF_OVF)
+            if (m.kind == 0)
+                hipLaunchKernelGGL((ll_direct_kernel<2, false, true>), grid, block, 0, stream, m, part, cnt, out, out_p);
+            else
+                hipLaunchKernelGGL((ll_direct_kernel<5, false, true>), grid, block, 0, stream, m, part, cnt, out, out_p);
+        } else if (m.kind == 0) {
             if (out_p)
                 hipLaunchKernelGGL((ll_direct_kernel<2, true>), grid, block, 0, stream, m, part, cnt, out, out_p);
             else

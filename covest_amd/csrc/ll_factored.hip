@@ -66,6 +66,11 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// The chunks' shares of p_j (list modes 2 and 3, tiles.h) travel through HBM TIMES 2^128: p_j <= 2.5, so nothing
+// overflows, and a p_j below half a grid step -- which the reference's roundings may still keep alive, direct_point.h
+// kZeroSteps -- does not flush to 0 on the way: finish_point decides on the exact value.
+constexpr double kShareScale = 0x1p128;
+
 
 // One MFMA step of the first N accumulator slots of a wave (they are sorted by length, so the active
 // slots are always a prefix): all A fragments first -- N independent LDS reads in flight -- then per
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const double p_clamp = plan.p_clamp; // direct_point.h
-    const double zero_frac = 0.45 * (4.94065645841246544e-324 / p_clamp); // 0.9 x 2^-1075 in units of p_clamp
+    const double zero_frac = kZeroSteps * (kGridStep / p_clamp); // direct_point.h kZeroSteps, in units of p_clamp
     const int list_mode = PLAIN ? 0 : plan.list_mode;
 
     // ---- the (c, e) of this workgroup ----
@@ -573,8 +578,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     if (qslot[k] >= 0 && !cont[k] && col == 0) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            plan.partial[(ce * tv.n_items + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] =
-                                acc[k][r] * rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0];
+                            plan.partial[(ce * tv.n_items + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] = // (x 2^128: kShareScale)
+                                acc[k][r] * (rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0] * kShareScale);
                     }
                     continue;
                 }
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                                       16 * uhalf[k] + kq;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const double share = acc[k][r] * rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0];
+                            const double share = acc[k][r] * (rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0] * kShareScale);
                             row[4 * r] = plan.o_base == 0 ? share : row[4 * r] + share;
                         }
                     }
@@ -632,9 +637,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                         for (int r = 0; r < 4; ++r) {
                             // p_j = 0 in the reference: every term of its sum is at most the sum, and a term below
                             // 2^-1075 is flushed by the extension's cast to double (c_src/covest_poissonmodule.c:32) --
-                            // so a row whose p_j (row value x scale) is safely below 2^-1075 is a zero, not a candidate
-                            // for the strict evaluation.  (The unscaled row value itself never underflows: half of the
-                            // C3 grid is -inf this way, and would otherwise queue up for the strict kernel.)
+                            // so a row whose p_j (row value x scale) is safely below 1/8 of a grid step (the roundings
+                            // on the reference's way can keep anything above that alive: direct_point.h kZeroSteps) is a
+                            // zero, not a candidate for the strict evaluation.  (The unscaled row value itself never
+                            // underflows: half of the C3 grid is -inf this way, and would otherwise queue up for the
+                            // strict kernel.)
                             const uint64_t z = __ballot(acc[k][r] <= c4[r] * zero_frac) & low[r];
                             zero |= z;
                             subm |= low[r] & ~z;
@@ -796,9 +803,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 #ifndef COVEST_FACTORED_VARIANT // (the finishing kernels live in the common translation unit only)
 // One wave finishes ONE point whose p_j lie in HBM, summed over chunks of copy numbers (tiles.h list modes 2, 3):
 // LL = sum_j h_j log p_j + tail log(1 - sp), covest/models.py:100-107.  read_pj(row): the p_j of row `row` of the
-// items (tiles.h: a key, or the sum over a count-less tile).  A subnormal p_j at a key with h_j != 0 is replaced on
-// the spot by its strict evaluation (direct_point.h: the whole wave, K-direct's arithmetic).  par: the point's
-// parameters, clamped; every lane returns the value.
+// items (tiles.h: a key, or the sum over a count-less tile), TIMES kShareScale.  A subnormal p_j at a key with h_j != 0
+// -- down to kZeroSteps of a grid step, below which it is 0 in the reference whatever the roundings (direct_point.h) -- is
+// replaced on the spot by its strict evaluation (direct_point.h: the whole wave, K-direct's arithmetic).  par: the
+// point's parameters, clamped; every lane returns the value.
 template <class ReadPj>
 __device__ __forceinline__ double finish_point(const DevModel &m, const TileView &tv, const double *par, int T,
                                                ReadPj read_pj)
@@ -811,9 +819,11 @@ __device__ __forceinline__ double finish_point(const DevModel &m, const TileView
     for (int64_t base = 0; base < n_rows; base += kWave) { // wave-uniform trip count
         const int64_t row = base + lane;
         const bool valid = row < n_rows;
-        double pj = valid ? read_pj(row) : 0.0;
+        const double pj_scaled = valid ? read_pj(row) : 0.0;
+        double pj = pj_scaled * (1.0 / kShareScale); // (one rounding, onto the doubles' grid)
         const double h = valid ? tv.item_cnt[row] : 0.0;
-        uint64_t sub = __ballot(h != 0.0 && pj > 0.0 && pj < 2.2250738585072014e-308); // a subnormal p_j
+        uint64_t sub = __ballot(h != 0.0 && pj_scaled > kZeroSteps * kGridStep * kShareScale &&
+                                pj < 2.2250738585072014e-308); // a subnormal p_j, or one the product above flushed
         while (sub) { // wave-uniform, rare
             const int who = __builtin_ctzll(sub);
             sub &= sub - 1;

@@ -24,6 +24,7 @@ with it every iterate -- is bit-identical to what `minimize(..., jac=None)` comp
 likelihood values.  The kernels are deterministic per point, whatever else shares the launch.
 """
 import threading
+import itertools
 import time
 
 import numpy as np
@@ -94,8 +95,13 @@ def _fd_fast_matches_scipy(lo, hi, h0):
 class CoverageEstimator:
     ERROR_RATE = 1  # index of the parameter that err_scale applies to
 
-    def __init__(self, model, err_scale=1, fix=None, batched=True, lock_step=False):
+    def __init__(self, model, err_scale=1, fix=None, batched=True, lock_step=False, reference_specials=False):
         self.model = model
+        # True: where the reference's long-double pmf product overflows (c_src/covest_poissonmodule.c:19-24) the
+        # objective is what the REFERENCE returns there -- -(+inf) or NaN -- instead of the finite value the formula
+        # defines, so that a search ends where the reference's ends (covest/grid.py:65-70 selects -inf).  Off by
+        # default: the overflow is a defect of the reference, not a feature of the model.
+        self.reference_specials = reference_specials
         self.fix = fix
         self.err_scale = err_scale
         self.batched = batched      # value and gradient from one launch (else scipy differences a scalar objective)
@@ -130,6 +136,8 @@ class CoverageEstimator:
     # ------------------------------------------------------------------ objective
     def likelihood_f(self, x):
         """The scalar objective handed to scipy and to optimize_grid: -LL."""
+        if self.reference_specials:
+            return float(self.negll_points([x])[0])
         return -self.model.compute_loglikelihood(*self._model_args(x))
 
     def negll_grid(self, axes, kernel="auto"):
@@ -152,6 +160,9 @@ class CoverageEstimator:
             grid.argmin()  # (wait for the kernels: the split below is only meaningful with a sync here)
         t2 = time.perf_counter() if t is not None else 0.0
         out = -grid.loglikelihoods()
+        if self.reference_specials:
+            pts = np.array(list(itertools.product(*axes)), dtype=np.float64).reshape(-1, self.model.param_count)
+            out = self._with_reference_specials(pts, out)
         if t is not None:
             t3 = time.perf_counter()
             t.append({"points": len(grid), "create_s": t1 - t0, "eval_s": t2 - t1, "readback_s": t3 - t2,
@@ -161,7 +172,19 @@ class CoverageEstimator:
     def negll_points(self, xs):
         """likelihood_f of several optimiser-space vectors in one launch: ndarray."""
         pts = np.array([self._model_args(x) for x in xs], dtype=np.float64)
-        return -self.model.loglikelihood_points(pts)
+        out = -self.model.loglikelihood_points(pts)
+        return self._with_reference_specials(pts, out) if self.reference_specials else out
+
+    def _with_reference_specials(self, pts, negll):
+        """-LL with the reference's own result substituted where its pmf product overflows: the points the host
+        test flags (model.reference_overflows: the largest rate against the largest key) go through
+        COVEST_KERNEL_DIRECT_REF, which returns +inf / NaN / the value without the tail term exactly where the
+        reference does (direct_point.h REF_OVF)."""
+        flagged = np.flatnonzero(self.model.reference_overflows(pts))
+        if len(flagged):
+            negll = np.array(negll, dtype=np.float64)
+            negll[flagged] = -self.model.loglikelihood_points(pts[flagged], kernel="direct_ref")
+        return negll
 
     # ------------------------------------------------------------------ refinement
     FD_STEP = 1e-8  # scipy's default `eps` of L-BFGS-B, what the reference runs with

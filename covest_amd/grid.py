@@ -334,11 +334,23 @@ def _batched_negll(fn):
 
 
 def optimize_grid(fn, initial_guess, bounds=None, maximize=False, fix=None,
-                  n_threads=constants.DEFAULT_THREAD_COUNT, trace=None):
+                  n_threads=constants.DEFAULT_THREAD_COUNT, trace=None, reference_specials=None):
     """covest/grid.py:17-79.  n_threads is accepted and ignored on the GPU path.  `trace`: a list the caller
     owns; one record per iteration is appended to it (what the reference prints through verbose_print,
     covest/grid.py:60,73-74) -- per call, so concurrent searches (the lock-step refinement runs threads) never
-    share one."""
+    share one.  `reference_specials` (fn = CoverageEstimator.likelihood_f only): True makes the search see what the
+    REFERENCE's objective returns where its long-double pmf product overflows -- -(+inf), which the scan of
+    covest/grid.py:65-70 selects, or NaN -- for the duration of this call (CoverageEstimator.reference_specials);
+    None leaves the estimator as it is."""
+    est = getattr(fn, "__self__", None)
+    if reference_specials is not None and hasattr(est, "reference_specials"):
+        before = est.reference_specials
+        est.reference_specials = bool(reference_specials)
+        try:
+            return optimize_grid(fn, initial_guess, bounds=bounds, maximize=maximize, fix=fix, n_threads=n_threads,
+                                 trace=trace, reference_specials=None)
+        finally:
+            est.reference_specials = before
     def generate_axes(args, step, max_depth):
         def single(var, fixed=None):
             if fixed is None:

@@ -51,6 +51,11 @@ extern "C" {
 #define COVEST_KERNEL_DIRECT 1   /* one wavefront per grid point, one exp per pmf term        */
 #define COVEST_KERNEL_RECUR 2    /* one wavefront per grid point, pmf recurrence along j      */
 #define COVEST_KERNEL_FACTORED 3 /* repeats, dense grids: (c,e)-outer / (q1,q2,q)-inner reuse */
+/* K-direct with the reference's long-double OVERFLOW reproduced: truncated_poisson (c_src/covest_poissonmodule.c:19-24)
+ * forms its whole product before scaling and returns +inf once it passes LDBL_MAX, the likelihood becomes +inf / NaN
+ * (covest/models.py:100-107) and optimize_grid would select -(+inf) (covest/grid.py:65-70).  The other kernels
+ * return the finite value the formula defines; this one returns what the reference returns, specials included. */
+#define COVEST_KERNEL_DIRECT_REF 4
 
 typedef struct covest_model covest_model; /* opaque */
 typedef struct covest_grid covest_grid;   /* opaque */

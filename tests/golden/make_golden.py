@@ -14,8 +14,9 @@ One session-local alias is needed: covest/models.py:10 does
 copied.  Interpreter-dependent semantics are recorded in every fixture's "env".
 
 Usage:  python tests/golden/make_golden.py [section ...]
-Sections: tp basic repeats threshold hists c1 c2 c3 c3tail c3trim c3argmin gridtrace   (default: all)
-(c3argmin reads c3_candidates_gpu.json: flat indices written on the GPU box by tools/dump_c3_candidates.py)
+Sections: tp basic repeats threshold hists c1 c2 c2classes c2trim c3 c3tail c3trim c3argmin gridtrace overflow   (default: all)
+(c3argmin reads c3_candidates_gpu.json: flat indices written on the GPU box by tools/dump_c3_candidates.py;
+ c2classes reads c2_classes_gpu.json: flat indices written on the GPU box by tools/dump_c2_classes.py)
 """
 import itertools
 import json
@@ -357,6 +358,97 @@ def section_c2(pool):
                             "cpu_seconds_per_point": [t for _, t in res]})
 
 
+def c2_axes():
+    return linspace(2000.0, 6000.0, 1000), linspace(0.001, 0.1, 1000)
+
+
+def c2_point(i):
+    cs, es = c2_axes()
+    return (cs[i // 1000], es[i % 1000])
+
+
+def section_c2classes(pool):
+    """Config 2 where K-basic's closed form (round 3) decides: tools/dump_c2_classes.py, run on a GPU box with the
+    diagnostic library, names flat indices of the C2 grid per ROUTE of the kernel -- lanes that walk key by key
+    (themselves between the -inf bound and the clamp, or dragged along by their wave), closed-form lanes closest to
+    the clamp and far from it, -inf-by-bound lanes closest to the bound and far from it, and the walking lanes whose
+    smallest p_j is closest to half a grid step of the doubles (where the reference's term-by-term roundings decide
+    between 4.94e-324 and 0, i.e. between a finite value and -inf).  Only the indices are taken
+    from that file; the values are the reference's (BasicModel.compute_loglikelihood, covest/models.py:81-107)."""
+    hist = synth_hist("H10k_basic", pool)
+    src = os.environ.get("COVEST_C2_CLASSES", os.path.join(HERE, "c2_classes_gpu.json"))
+    with open(src) as f:
+        picked = json.load(f)
+    classes = ["walk_self", "walk_dragged", "closed_edge", "closed_far", "neginf_edge", "neginf_far", "flush_edge"]
+    idx = sorted(set(int(i) for c in classes for i in picked[c]))
+    res = pool.map(_ll_job, [("basic", hist, 0, c2_point(i)) for i in idx], chunksize=2)
+    at = {i: k for k, i in enumerate(idx)}
+    for c in classes:
+        vals = [res[at[int(i)]][0] for i in picked[c]]
+        print("c2classes", c, len(vals), "finite", sum(1 for v in vals if math.isfinite(v)),
+              "-inf", sum(1 for v in vals if v == -math.inf), flush=True)
+    dump("c2_classes.json", {"what": "config 2 at K-basic's class boundaries: BasicModel on H10k_basic.hist at flat "
+                                     "indices of the 1000x1000 grid chosen per route of the kernel "
+                                     "(tools/dump_c2_classes.py); values: the reference's",
+                             "hist": "H10k_basic", "k": 21, "r": 100, "max_error": 8, "tail": 0,
+                             "class_counts_gpu": picked.get("class_counts"),
+                             "classes": {c: [int(i) for i in picked[c]] for c in classes},
+                             "flat_index": idx, "points": [list(c2_point(i)) for i in idx],
+                             "ll": [v for v, _ in res]})
+
+
+def section_c2trim(pool):
+    """Config 2 on the histogram the reference's own pipeline would hand the model (as section c3trim): H10k_basic
+    trimmed by get_trim(ignore_last=True) / trim_hist (covest/histogram.py:105-134), tail = the trimmed mass.
+    COVEST_C2TRIM_POINTS (default 1024) seeded points of the C2 grid with the reference's LL and sp_j, and the
+    reference's values at the best 96 points of the grid + the axis neighbours of the best one (chosen with the
+    oracle's log-domain mode; the reference decides the winner under the scan of covest/grid.py:65-70)."""
+    import covest.histogram as H
+    import numpy as np
+    hist = synth_hist("H10k_basic", pool)
+    trim = H.get_trim(hist, ignore_last=True)
+    thist, tail = H.trim_hist(hist, trim)
+    save_hist(os.path.join(HERE, "H10k_basic_trim.hist"), thist,
+              "H10k_basic trimmed by the reference (get_trim(ignore_last=True) = %d, trim_hist): tail = %d" % (trim, tail))
+    n = 10 ** 6
+    idx = sorted(random.Random(20241004).sample(range(n), int(os.environ.get("COVEST_C2TRIM_POINTS", "1024"))))
+    res = pool.map(_ll_sp_job, [("basic", thist, tail, c2_point(i)) for i in idx], chunksize=8)
+    sys.path.insert(0, REPO)
+    from oracle import covest_oracle as orc
+    om = orc.OracleModel("basic", 21, 100, thist, tail, max_error=8)
+    cs, es = c2_axes()
+    fast = np.concatenate([om.compute_loglikelihood_many_fast(
+        np.array([(cs[ic], e) for ic in range(a, min(a + 50, 1000)) for e in es]), n_threads=8) for a in range(0, 1000, 50)])
+    negll = np.where(np.isnan(fast), np.inf, -fast)
+    order = np.argsort(negll, kind="stable")
+    cand = set(int(i) for i in order[:96])
+    top = np.unravel_index(int(order[0]), (1000, 1000))
+    for d in range(2):
+        for step in (-1, 1):
+            j = list(top)
+            j[d] += step
+            if 0 <= j[d] < 1000:
+                cand.add(int(np.ravel_multi_index(j, (1000, 1000))))
+    cand = sorted(cand)
+    cres = pool.map(_ll_sp_job, [("basic", thist, tail, c2_point(i)) for i in cand], chunksize=1)
+    best, arg = None, -1
+    for i, (v, _, _) in zip(cand, cres):
+        if v == v and (best is None or -v < best):
+            best, arg = -v, i
+    print("c2trim: trim", trim, "keys", len(thist), "tail", tail, "reference winner", arg, best,
+          "finite sample values", sum(1 for v, _, _ in res if math.isfinite(v)), flush=True)
+    dump("c2_trim.json", {"what": "config 2 on H10k_basic trimmed as the reference's process_histogram trims it: "
+                                  "BasicModel, seeded points of the 1000x1000 (c,e) grid with LL and sp_j = fsum(p_j), "
+                                  "and the arg-min candidates",
+                          "hist": "H10k_basic_trim", "source_hist": "H10k_basic", "trim": trim, "k": 21, "r": 100,
+                          "max_error": 8, "tail": tail, "n_keys": len(thist),
+                          "flat_index": idx, "ll": [v for v, _, _ in res], "sp": [sp for _, _, sp in res],
+                          "cpu_seconds_total": sum(t for _, t, _ in res),
+                          "candidates": {"flat_index": cand, "ll": [v for v, _, _ in cres],
+                                         "sp": [sp for _, _, sp in cres],
+                                         "reference_argmin_flat": arg, "reference_min_negll": best}})
+
+
 def c3_axes():
     return (linspace(15.0, 30.0, 32), linspace(0.005, 0.08, 32), linspace(0.3, 0.95, 16), linspace(0.05, 0.95, 16))
 
@@ -579,14 +671,68 @@ def section_gridtrace():
                              "traces": out})
 
 
+# ----------------------------------------------------------------------------- (8) the overflow domain
+OVF_HISTS = {
+    # keys at the top of the 10 000-key range: truncated_poisson(l, j) overflows to +inf once
+    # j ln l - ln j! > ln LDBL_MAX = 11356.5 (c_src/covest_poissonmodule.c:19-24), i.e. l > ~11 459 at j = 10 000
+    "ovf_top": {9990: 5, 9995: 12, 10000: 7},
+    # ... plus a counted key far below: its p_j is 0 there (log -> -inf), so the sum is inf - inf = NaN
+    "ovf_nan": {100: 3, 9990: 5, 9995: 12, 10000: 7},
+}
+
+
+def section_overflow():
+    """Where the reference's long-double product overflows: its LL is +inf or NaN there and
+    optimize_grid selects -(+inf) (covest/grid.py:65-70).  LL values across the band for both models, and the
+    reference's own optimize_grid trace walking into it (basic model, free (c, e))."""
+    import covest.grid as G
+    cases = []
+    rnd = random.Random(20241004)
+    for hname, hist in OVF_HISTS.items():
+        for tail in (0, 50):
+            m = BasicModel(21, 100, hist, tail, max_error=8)
+            pts = [(c, e) for c in (12000.0, 13000.0, 14000.0, 14200.0, 14300.0, 14350.0, 14400.0, 14500.0, 15000.0,
+                                    16000.0, 20000.0, 40000.0) for e in (0.0, 0.001, 0.01)]
+            pts += [(rnd.uniform(13500, 15500), rnd.uniform(0, 0.004)) for _ in range(24)]
+            cases.append({"model": "basic", "hist": hname, "hist_items": [[j, v] for j, v in hist.items()], "k": 21,
+                          "r": 100, "tail": tail, "max_error": 8, "points": [list(p) for p in pts],
+                          "ll": [m.compute_loglikelihood(*p) for p in pts]})
+        m = RepeatsModel(21, 100, hist, 0, max_error=8)
+        pts = [(c, 0.001, q1, 0.5, q) for c in (60.0, 90.0, 100.0, 105.0, 110.0, 150.0) for q1, q in
+               ((0.5, 0.1), (0.7, 0.2), (0.9, 0.05))]
+        cases.append({"model": "repeats", "hist": hname, "hist_items": [[j, v] for j, v in hist.items()], "k": 21,
+                      "r": 100, "tail": 0, "max_error": 8, "points": [list(p) for p in pts],
+                      "ll": [m.compute_loglikelihood(*p) for p in pts]})
+    traces = []
+    for hname, guess in (("ovf_top", [13500.0, 0.001]), ("ovf_top", [11000.0, 0.002]), ("ovf_nan", [13500.0, 0.001])):
+        hist = OVF_HISTS[hname]
+        m = BasicModel(21, 100, hist, 0, max_error=8)
+        fn = NegLogLikelihood(m)
+        log = []
+        G.verbose_print = log.append
+        res = G.optimize_grid(fn, list(guess), bounds=list(m.bounds), fix=None, n_threads=8)
+        traces.append({"model": "basic", "hist": hname, "hist_items": [[j, v] for j, v in hist.items()], "k": 21,
+                       "r": 100, "tail": 0, "max_error": 8, "initial_guess": guess,
+                       "bounds": [list(b) for b in m.bounds], "result": list(res), "result_negll": fn(res), "log": log})
+        print("overflow trace", hname, guess, "->", list(res), fn(res), len([l for l in log if "Grid size" in l]),
+              "iterations", flush=True)
+    for c in cases:
+        print("overflow", c["model"], c["hist"], "tail", c["tail"], "finite",
+              sum(1 for v in c["ll"] if math.isfinite(v)), "+inf", sum(1 for v in c["ll"] if v == math.inf),
+              "-inf", sum(1 for v in c["ll"] if v == -math.inf), "nan", sum(1 for v in c["ll"] if v != v), flush=True)
+    dump("overflow.json", {"what": "the reference where its long-double pmf product overflows: compute_loglikelihood "
+                                   "values (+inf / NaN included) and covest.grid.optimize_grid traces",
+                           "cases": cases, "traces": traces})
+
+
 def main():
-    wanted = sys.argv[1:] or ["tp", "basic", "repeats", "threshold", "hists", "c1", "c2", "c3", "c3tail", "c3trim",
-                              "c3argmin", "gridtrace"]
+    wanted = sys.argv[1:] or ["tp", "basic", "repeats", "threshold", "hists", "c1", "c2", "c2classes", "c2trim", "c3", "c3tail", "c3trim",
+                              "c3argmin", "gridtrace", "overflow"]
     pool = multiprocessing.Pool(int(os.environ.get("COVEST_GOLDEN_PROCS", "8")))
     for name in wanted:
         t0 = time.time()
         fn = globals()["section_" + name]
-        if name in ("hists", "c1", "c2", "c3", "c3tail", "c3trim", "c3argmin"):
+        if name in ("hists", "c1", "c2", "c2classes", "c2trim", "c3", "c3tail", "c3trim", "c3argmin"):
             fn(pool)
         else:
             fn()

@@ -219,6 +219,109 @@ def test_config2_sample_and_argmin(hip_lib, oracle, kernel):
     _verify_argmin_with_oracle(oracle, _oracle_model(oracle, "basic", g), grid, ll, arg, top=24)
 
 
+def _c2_grid(m):
+    from covest_amd import DenseGrid
+    return DenseGrid(m, [np.linspace(2000.0, 6000.0, 1000), np.linspace(0.001, 0.1, 1000)])
+
+
+def test_config2_whole_grid_recur_against_direct(hip_lib):
+    """Every one of C2's 10^6 points: K-basic (closed form / -inf by its bound / key-by-key walk, ll_basic.hip)
+    against K-direct (one exp per term, itself pinned to the reference's values by the fixtures) at 1e-11, IEEE
+    specials in the same places, the same arg-min.  What test_config3_* has had for K-factored since round 2."""
+    g = load_golden("c2_sample.json")
+    m = _gpu_model("basic", g)
+    grid = _c2_grid(m)
+    grid.evaluate(kernel="recur")
+    assert grid.work()[2] == "ll_basic"
+    fast = grid.loglikelihoods()
+    best = grid.argmin()
+    grid.evaluate(kernel="direct")
+    assert grid.work()[2] == "ll_direct"
+    ref = grid.loglikelihoods()
+    assert np.array_equal(np.isneginf(fast), np.isneginf(ref)) and np.array_equal(np.isnan(fast), np.isnan(ref))
+    fin = np.isfinite(ref)
+    assert 400000 < int(fin.sum()) < 700000  # the grid does exercise both outcomes
+    err = np.abs(fast[fin] - ref[fin]) / np.abs(ref[fin])
+    worst = float(err.max())
+    assert worst <= 1e-11, (worst, int(np.flatnonzero(fin)[int(err.argmax())]))
+    assert grid.argmin()[1] == best[1]
+    print("C2 whole grid, K-basic vs K-direct: worst rel err %.3g over %d finite points, %d -inf" % (
+        worst, int(fin.sum()), int(np.isneginf(ref).sum())))
+    grid.close()
+    m.close()
+
+
+def test_config2_class_boundaries_against_reference(hip_lib):
+    """The reference's values where K-basic's closed form DECIDES (tests/golden/c2_classes.json: flat indices named
+    per route by tools/dump_c2_classes.py on a GPU box with the diagnostic library -- >= 64 lanes each that walk key
+    by key themselves, that are dragged into the walk by their wave, closed-form lanes closest to the clamp,
+    -inf-by-bound lanes closest to the bound, and seeded lanes of both far from the boundaries)."""
+    g = load_golden("c2_classes.json")
+    m = _gpu_model("basic", g)
+    grid = _c2_grid(m)
+    grid.evaluate(kernel="recur")
+    ll = grid.loglikelihoods()
+    at = {i: k for k, i in enumerate(g["flat_index"])}
+    for i, p in zip(g["flat_index"], g["points"]):
+        assert np.allclose(grid.point(i), p, rtol=1e-15, atol=0)
+    worst = {}
+    for name, idx in g["classes"].items():
+        assert len(idx) >= 64, (name, len(idx))
+        want = [g["ll"][at[i]] for i in idx]
+        worst[name] = (_check(ll[idx], want, "C2 class " + name), sum(1 for v in want if math.isfinite(v)))
+    # the classes are what they say: the walk and the closed form end finite (mostly), the bound ends at -inf
+    assert all(g["ll"][at[i]] == -math.inf for i in g["classes"]["neginf_far"])
+    assert all(math.isfinite(g["ll"][at[i]]) for i in g["classes"]["closed_far"])
+    # the list API (one lane per point of ANOTHER wave composition) agrees with the reference as well
+    pts = np.array(g["points"])
+    _check(m.loglikelihood_points(pts, kernel="recur"), g["ll"], "C2 classes, point list")
+    _check(m.loglikelihood_points(pts, kernel="direct"), g["ll"], "C2 classes, K-direct")
+    print("C2 class boundaries: worst rel err (finite values) per class", worst)
+    grid.close()
+    m.close()
+
+
+def test_config2_trimmed_histogram_with_its_tail(hip_lib):
+    """Config 2 on the histogram the reference's pipeline hands the model: H10k_basic trimmed by the reference's own
+    get_trim / trim_hist (covest/histogram.py:105-134) -- K-basic WITH a tail at C2's scale (the closed form is off,
+    every key enters sp_j).  Seeded grid points with the reference's LL and sp_j (graded slack, _tail_slack), the
+    whole grid against K-direct on a seeded subset, the arg-min confirmed by the reference among the best 96 points
+    and the axis neighbours of the best (tests/golden/c2_trim.json)."""
+    from covest_amd import BasicModel
+    g = load_golden("c2_trim.json")
+    hist = load_hist(g["hist"])
+    assert len(hist) == g["n_keys"] and g["tail"] > 0
+    m = BasicModel(g["k"], g["r"], hist, g["tail"], max_error=g["max_error"])
+    assert m.bins_evaluated == g["n_keys"]
+    grid = _c2_grid(m)
+    grid.evaluate(kernel="recur")
+    assert grid.work()[2] == "ll_basic" and grid.total == 10 ** 6
+    ll = grid.loglikelihoods()
+    idx = np.array(g["flat_index"])
+    want = np.array(g["ll"])
+    assert int(np.isfinite(want).sum()) >= 256
+    slack = _slack_of(g["tail"], g["ll"], g["sp"], g["n_keys"])
+    n_flip = sum(1 for c in slack.classes if c == "flip")
+    assert n_flip <= 0.05 * len(idx), n_flip
+    _slack_budget("C2 trimmed sample", slack)
+    worst = _check(ll[idx], want, "C2 trimmed (recur)", slack=slack)
+    pts = np.array([grid.point(int(i)) for i in idx])
+    worst = max(worst, _check(m.loglikelihood_points(pts, kernel="direct"), want, "C2 trimmed (direct)", slack=slack))
+    val, arg = grid.argmin()
+    assert val == -ll[arg] and arg == int(np.argmin(np.where(np.isnan(ll), np.inf, -ll)))
+    fix = g["candidates"]
+    cand = _argmin_candidates(grid, ll, arg, top=64)
+    assert set(cand) <= set(fix["flat_index"]), "arg-min candidates outside the fixture: regenerate tests/golden/c2_trim.json"
+    cslack = _slack_of(g["tail"], fix["ll"], fix["sp"], g["n_keys"])
+    _slack_budget("C2 trimmed arg-min candidates", cslack)
+    _check(ll[fix["flat_index"]], fix["ll"], "C2 trimmed arg-min candidates", slack=cslack)
+    assert fix["reference_argmin_flat"] == arg
+    assert rel_err(val, fix["reference_min_negll"]) <= TOL
+    print("C2 trimmed: worst rel err", worst, "flip class", n_flip, "of", len(idx), "arg-min", arg, val)
+    grid.close()
+    m.close()
+
+
 def _verify_argmin_with_oracle(oracle, om, grid, ll, arg, top):
     """SURVEY 8(d) parity procedure: the GPU's best candidates and the axis
     neighbours of its arg-min, re-evaluated by the faithful CPU oracle, must
@@ -902,6 +1005,65 @@ def test_optimize_grid_trace(hip_lib):
         sizes = [int(line.split("Grid size:")[1]) for line in tr["log"] if "Grid size" in line]
         assert [t["grid_size"] for t in trace] == sizes
         assert list(res) == tr["result"], (tr["model"], res, tr["result"])
+
+
+def test_reference_overflow_mode(hip_lib):
+    """The reference-faithful overflow mode (COVEST_KERNEL_DIRECT_REF, CoverageEstimator(reference_specials=True),
+    optimize_grid(..., reference_specials=True)) against tests/golden/overflow.json: the reference's likelihoods where
+    its long-double pmf product overflows (c_src/covest_poissonmodule.c:19-24) -- +inf, NaN (inf - inf), -inf and the
+    finite values beside them, tail term dropped where sp_j is not < 1 -- and its own optimize_grid traces that walk
+    into the band and stop at the first -(+inf) (covest/grid.py:65-70).  The default behaviour stays: finite values."""
+    from covest_amd import BasicModel, CoverageEstimator, DenseGrid, RepeatsModel, optimize_grid
+    g = load_golden("overflow.json")
+    classes = {"nan": 0, "+inf": 0, "-inf": 0, "finite": 0}
+    for c in g["cases"]:
+        hist = {int(j): int(v) for j, v in c["hist_items"]}
+        cls = BasicModel if c["model"] == "basic" else RepeatsModel
+        m = cls(c["k"], c["r"], hist, c["tail"], max_error=c["max_error"])
+        pts = np.array(c["points"])
+        got = m.loglikelihood_points(pts, kernel="direct_ref")
+        _check(got, c["ll"], "overflow %s %s tail=%s" % (c["model"], c["hist"], c["tail"]))
+        for b in c["ll"]:
+            classes["nan" if b != b else "+inf" if b == math.inf else "-inf" if b == -math.inf else "finite"] += 1
+        # the estimator's substitution reaches the same values through the host's flags
+        est = CoverageEstimator(m, reference_specials=True)
+        _check(-est.negll_points([list(p) for p in c["points"]]), c["ll"], "overflow via the estimator")
+        # every point the reference overflows at is flagged by the host test, and the DEFAULT kernels stay finite
+        # (or -inf) there
+        flags = m.reference_overflows(pts)
+        want = np.array(c["ll"])
+        assert flags[np.isposinf(want) | np.isnan(want)].all()
+        plain = m.loglikelihood_points(pts)
+        assert not np.isposinf(plain).any() and not np.isnan(plain).any()
+        same = ~flags
+        _check(plain[same], want[same], "outside the band the default kernels agree")
+        m.close()
+    assert min(classes.values()) > 0, classes
+    for tr in g["traces"]:
+        hist = {int(j): int(v) for j, v in tr["hist_items"]}
+        m = BasicModel(tr["k"], tr["r"], hist, tr["tail"], max_error=tr["max_error"])
+        est = CoverageEstimator(m)
+        trace = []
+        res = optimize_grid(est.likelihood_f, list(tr["initial_guess"]), bounds=est.bounds, trace=trace,
+                            reference_specials=True)
+        assert est.reference_specials is False  # (for the duration of the call only)
+        sizes = [int(line.split("Grid size:")[1]) for line in tr["log"] if "Grid size" in line]
+        assert [t["grid_size"] for t in trace] == sizes
+        assert list(res) == tr["result"], (tr["hist"], res, tr["result"])
+        assert trace[-1]["value"] == tr["result_negll"] == -math.inf
+        # the same grid on the device: K-direct-ref + the arg-min kernel pick the first -(+inf) as the scan does
+        plain = optimize_grid(est.likelihood_f, list(tr["initial_guess"]), bounds=est.bounds)
+        assert math.isfinite(est.likelihood_f(plain)) and list(plain) != tr["result"]
+        axes = [np.linspace(0.9 * tr["result"][0], 1.1 * tr["result"][0], 24), np.linspace(0.0, 0.004, 8)]
+        grid = DenseGrid(m, axes)
+        grid.evaluate(kernel="direct_ref")
+        ll = grid.loglikelihoods()
+        val, arg = grid.argmin()
+        first = int(np.flatnonzero(np.isposinf(ll))[0])
+        assert val == -math.inf and arg == first
+        grid.close()
+        m.close()
+    print("overflow mode: classes checked", classes, "traces", len(g["traces"]))
 
 
 @pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("COVEST_FUZZ_SEEDS", "50")))))

@@ -135,6 +135,22 @@ def test_config3_trimmed_fixture(oracle):
     assert all(abs(1.0 - sp) > 1e-6 for sp in c["sp"])
 
 
+def test_overflow_domain(oracle):
+    """Where the reference's long-double pmf product overflows (c_src/covest_poissonmodule.c:19-24) its likelihood is
+    +inf or NaN (tests/golden/overflow.json, make_golden.py section overflow): the oracle's faithful mode returns the
+    same specials in the same places, and the finite values beside them."""
+    g = load_golden("overflow.json")
+    seen = set()
+    for c in g["cases"]:
+        hist = {int(j): int(v) for j, v in c["hist_items"]}
+        om = oracle.OracleModel(c["model"], c["k"], c["r"], hist, c["tail"], max_error=c["max_error"])
+        got = om.compute_loglikelihood_many(np.array(c["points"]), n_threads=4)
+        for a, b, p in zip(got, c["ll"], c["points"]):
+            assert rel_err(float(a), b) <= 1e-13, (c["model"], c["hist"], c["tail"], p, float(a), b)
+            seen.add("nan" if b != b else "+inf" if b == math.inf else "-inf" if b == -math.inf else "finite")
+    assert seen == {"nan", "+inf", "-inf", "finite"}
+
+
 def test_synthetic_histograms_match_survey():
     # SURVEY 8(d): H256 has 73 non-zero bins and sum 10 000 003; H10k_basic 367 non-zero bins
     h = load_hist("H256")
