@@ -7,6 +7,7 @@ raises CovestHipError -- it never silently computes elsewhere.
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COVEST_AMD_LIB", os.path.join(_HERE, "lib", "libcovest_amd.so"))
@@ -59,6 +60,10 @@ class ModelDesc(ctypes.Structure):
 
 
 _lib = None
+# One process hosts ONE HIP runtime only if torch (which ships its own copy of libamdhip64) was imported BEFORE this
+# library was loaded: then the loader binds this library to the runtime torch brought.  The other way round the
+# process ends up with two runtimes, and device pointers of one mean nothing to the other.
+_loaded_before_torch = False
 
 
 def lib():
@@ -70,6 +75,8 @@ def lib():
         raise CovestHipError(
             "HIP library %s is missing: run `python -m covest_amd.build` "
             "(there is no CPU fallback)" % LIB_PATH)
+    global _loaded_before_torch
+    _loaded_before_torch = "torch" not in sys.modules
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:
@@ -171,6 +178,16 @@ def lib():
 COVEST_E_INVALID = -1
 COVEST_E_NOMEM = -4
 COVEST_E_UNSUPPORTED = -5
+
+
+def require_shared_runtime(what):
+    """Called wherever device memory of this library is handed to torch (or torch's to it): fails loudly if the
+    process imported torch AFTER the library was loaded -- two HIP runtimes, the pointers would be garbage."""
+    if _lib is not None and _loaded_before_torch and "torch" in sys.modules:
+        raise CovestHipError(
+            "%s: torch was imported after libcovest_amd.so was loaded, so this process hosts two HIP runtimes and "
+            "device pointers cannot be shared between them -- `import torch` before the first covest_amd call "
+            "(INTEGRATION.md)" % what)
 
 
 def last_error():

@@ -17,7 +17,9 @@ LIB_PATH = os.path.join(LIB_DIR, "libcovest_amd.so")
 # (source, extra flags, object name).  K-factored is compiled once per template variant, each into a translation unit
 # of its own (csrc/ll_factored.hip, COVEST_FACTORED_VARIANT): the HIP runtime loads a translation unit's code object
 # when one of its kernels is first launched, so a process only pays for the variants it uses.
-SOURCES = [("capi.cpp", (), "capi"), ("reads_io.cpp", (), "reads_io"), ("ll_direct.hip", (), "ll_direct"),
+SOURCES = [("host_common.cpp", (), "host_common"), ("tiles_host.cpp", (), "tiles_host"), ("plan_factored.cpp", (), "plan_factored"),
+           ("abi_model.cpp", (), "abi_model"), ("abi_grid.cpp", (), "abi_grid"), ("kmer_host.cpp", (), "kmer_host"),
+           ("thin_host.cpp", (), "thin_host"), ("reads_io.cpp", (), "reads_io"), ("ll_direct.hip", (), "ll_direct"),
            ("ll_basic.hip", (), "ll_basic"), ("ll_factored.hip", (), "ll_factored"), ("argmin.hip", (), "argmin"),
            ("kmer_count.hip", (), "kmer_count"), ("kmer_wide.hip", (), "kmer_wide"), ("kmer_bulk.hip", (), "kmer_bulk"), ("thin_hist.hip", (), "thin_hist")]
 SOURCES += [("ll_factored.hip", ("-DCOVEST_FACTORED_VARIANT=%d" % v,), "ll_factored_v%d" % v) for v in range(8)]

@@ -1,0 +1,382 @@
+// abi_grid.cpp -- the grid handle of the C ABI (include/covest_amd.h): covest_grid_*.
+#include "host.h"
+
+using namespace covest;
+
+// optimize_grid re-configures a handle every iteration (21 times 0.2 ms of allocations and copies otherwise).
+static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *axes, const int64_t *axis_len,
+                          int64_t flat_begin, int64_t flat_end, const char *who)
+{
+    covest_model *m = g->model;
+    if (!axes || !axis_len)
+        return fail(COVEST_E_INVALID, std::string(who) + ": null argument");
+    if (n_axes != m->n_par)
+        return fail(COVEST_E_INVALID, std::string(who) + ": n_axes must equal the model's param_count");
+    int64_t total = 1, n_values = 0;
+    for (int d = 0; d < n_axes; ++d) {
+        if (axis_len[d] < 1 || !axes[d])
+            return fail(COVEST_E_INVALID, std::string(who) + ": every axis needs at least one value");
+        if (total > (int64_t)1 << 40)
+            return fail(COVEST_E_INVALID, std::string(who) + ": grid too large");
+        total *= axis_len[d];
+        n_values += axis_len[d];
+    }
+    if (flat_end < 0)
+        flat_end = total;
+    if (flat_begin < 0 || flat_begin > flat_end || flat_end > total)
+        return fail(COVEST_E_INVALID, std::string(who) + ": bad flat index range");
+    g->configured = false; // (set again at the very end: a failure below leaves views into a freed arena behind)
+    g->flat_begin = flat_begin;
+    g->flat_end = flat_end;
+    g->evaluated = false;
+    g->ev_used = 0;
+    const int64_t n = flat_end - flat_begin;
+    const int64_t n1 = n_axes == 5 ? axis_len[2] : 1, n2 = n_axes == 5 ? axis_len[3] : 1, n3 = n_axes == 5 ? axis_len[4] : 1;
+    const int64_t nq = n_axes == 5 ? n1 * n2 * n3 : 0;
+
+    // threshold_o over the (q1, q2, q) sub-grid (host, libm)
+    std::vector<int32_t> table((size_t)nq);
+    for (int64_t a = 0; a < n1 && nq; ++a)
+        for (int64_t b = 0; b < n2; ++b)
+            for (int64_t c = 0; c < n3; ++c) {
+                const double par[5] = {0, 0, axes[2][a], axes[3][b], axes[4][c]};
+                table[(size_t)((a * n2 + b) * n3 + c)] = threshold_for_point(m, par);
+            }
+
+    // arena layout: [axes | queue counter (8 B) | t_table] uploaded together, then the outputs
+    auto up8 = [](size_t v) { return (v + 7) / 8 * 8; };
+    const size_t o_axes = 0, o_ctl = o_axes + (size_t)n_values * sizeof(double), o_table = o_ctl + 8;
+    const size_t o_ll = up8(o_table + (size_t)nq * sizeof(int32_t)), n_pts = (size_t)(n > 0 ? n : 1);
+    const size_t o_idx = o_ll + n_pts * sizeof(double), o_word = o_idx + n_pts * sizeof(int64_t);
+    const size_t o_pv = o_word + n_pts * sizeof(unsigned long long), o_pi = o_pv + kArgminBlocks * sizeof(double);
+    const size_t o_res = o_pi + kArgminBlocks * sizeof(int64_t), bytes = o_res + sizeof(ArgminResult);
+    HIP_TRY(g->arena.reserve(bytes));
+    char *base = g->arena.as<char>();
+    {
+        SharedStage &ss = shared_stage();
+        std::lock_guard<std::mutex> hold(ss.mu);
+        HIP_TRY(ss.buf.reserve(o_ll));
+        char *stage = ss.buf.as<char>();
+        std::memset(stage, 0, o_ll);
+        double *sa = reinterpret_cast<double *>(stage);
+        for (int d = 0; d < n_axes; ++d) {
+            g->len[d] = axis_len[d];
+            std::copy(axes[d], axes[d] + axis_len[d], sa);
+            sa += axis_len[d];
+        }
+        for (int d = n_axes; d < kMaxParams; ++d)
+            g->len[d] = 1;
+        if (nq)
+            std::memcpy(stage + o_table, table.data(), (size_t)nq * sizeof(int32_t));
+        HIP_TRY(hipMemcpy(base, stage, o_ll, hipMemcpyHostToDevice));
+    }
+    g->axes.ptr = base + o_axes;
+    g->sub_ctl.ptr = base + o_ctl;
+    g->t_table.ptr = base + o_table;
+    g->ll.ptr = base + o_ll;
+    g->sub_index.ptr = base + o_idx;
+    g->sub_word.ptr = base + o_word;
+    g->partial_val.ptr = base + o_pv;
+    g->partial_idx.ptr = base + o_pi;
+    g->result.ptr = base + o_res;
+    PointSource &src = g->src;
+    src = PointSource{};
+    src.is_grid = 1;
+    src.flat_begin = flat_begin;
+    {
+        int64_t off = 0;
+        for (int d = 0; d < kMaxParams; ++d) {
+            src.len[d] = d < n_axes ? axis_len[d] : 1;
+            src.axis[d] = d < n_axes ? g->axes.as<double>() + off : nullptr;
+            if (d < n_axes)
+                off += axis_len[d];
+        }
+    }
+
+    // the block's sum of (T - 1), and the K-factored plan
+    g->sum_t_minus_1 = (double)n; // basic: T = 2 everywhere
+    g->q_sum_t_minus_1 = 0.0;
+    g->has_plan = false;
+    if (m->n_par == 5) {
+        src.t_table = g->t_table.as<int32_t>();
+        // sum of (T-1) over flat indices [begin, end): whole (c,e) rows plus two ragged ends
+        std::vector<double> prefix((size_t)nq + 1, 0.0);
+        for (int64_t i = 0; i < nq; ++i)
+            prefix[(size_t)i + 1] = prefix[(size_t)i] + (double)(table[(size_t)i] > 1 ? table[(size_t)i] - 1 : 0);
+        auto upto = [&](int64_t flat) { // sum over flat indices [0, flat)
+            return (double)(flat / nq) * prefix[(size_t)nq] + prefix[(size_t)(flat % nq)];
+        };
+        g->sum_t_minus_1 = upto(flat_end) - upto(flat_begin);
+        g->q_sum_t_minus_1 = prefix[(size_t)nq];
+        const int prc = build_factored_plan(g, axes, axis_len, table);
+        if (prc != COVEST_OK)
+            return prc;
+    }
+    g->configured = true;
+    return COVEST_OK;
+}
+
+static void grid_release(covest_grid *g)
+{
+    if (g->result_host) {
+        (void)hipHostFree(g->result_host);
+        g->result_host = nullptr;
+    }
+    g->arena.release();
+    g->plan_buf.release();
+    for (covest_grid::Part &part : g->long_parts)
+        part.buf.release();
+    g->long_parts.clear();
+    g->long_q_orig.release();
+    g->long_partial.release();
+    for (hipEvent_t e : g->ev_begin)
+        (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->ev_end)
+        (void)hipEventDestroy(e);
+    g->ev_begin.clear();
+    g->ev_end.clear();
+}
+
+extern "C" {
+
+int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axes,
+                       const int64_t *axis_len, int64_t flat_begin, int64_t flat_end,
+                       covest_grid **out)
+{
+    if (!m || !out)
+        return fail(COVEST_E_INVALID, "covest_grid_create: null argument");
+    *out = nullptr;
+    covest_grid *g = new (std::nothrow) covest_grid();
+    if (!g)
+        return fail(COVEST_E_NOMEM, "covest_grid_create: out of host memory");
+    g->model = m;
+    std::lock_guard<std::mutex> guard(m->lock);
+    DeviceGuard dev_guard(m->device);
+    int rc = dev_guard.status();
+    if (rc == COVEST_OK)
+        rc = grid_configure(g, n_axes, axes, axis_len, flat_begin, flat_end, "covest_grid_create");
+    if (rc != COVEST_OK) {
+        grid_release(g);
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return COVEST_OK;
+}
+
+int covest_grid_reset(covest_grid *g, int32_t n_axes, const double *const *axes, const int64_t *axis_len,
+                      int64_t flat_begin, int64_t flat_end)
+{
+    if (!g)
+        return fail(COVEST_E_INVALID, "covest_grid_reset: null grid");
+    covest_model *m = g->model;
+    std::lock_guard<std::mutex> guard(m->lock);
+    DeviceGuard dev_guard(m->device);
+    if (dev_guard.status() != COVEST_OK)
+        return dev_guard.status();
+    if (g->last_stream || g->evaluated)
+        HIP_TRY(hipStreamSynchronize(g->last_stream)); // nothing of the last evaluation may still be in flight
+    return grid_configure(g, n_axes, axes, axis_len, flat_begin, flat_end, "covest_grid_reset");
+}
+
+void covest_grid_destroy(covest_grid *g)
+{
+    if (!g)
+        return;
+    DeviceGuard dev_guard(g->model->device);
+    grid_release(g);
+    delete g;
+}
+
+int covest_grid_profile(covest_grid *g, int32_t enable)
+{
+    if (!g)
+        return fail(COVEST_E_INVALID, "covest_grid_profile: null grid");
+    g->profiling = enable != 0;
+    g->ev_used = 0;
+    return COVEST_OK;
+}
+
+int covest_grid_kernel_ms(covest_grid *g, double *total_ms, int64_t *launches)
+{
+    if (!g || !total_ms || !launches)
+        return fail(COVEST_E_INVALID, "covest_grid_kernel_ms: null argument");
+    DeviceGuard dev_guard(g->model->device);
+    int rc = dev_guard.status();
+    if (rc != COVEST_OK)
+        return rc;
+    double sum = 0.0;
+    for (size_t i = 0; i < g->ev_used; ++i) {
+        HIP_TRY(hipEventSynchronize(g->ev_end[i]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g->ev_begin[i], g->ev_end[i]));
+        sum += (double)ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)g->ev_used;
+    return COVEST_OK;
+}
+
+int64_t covest_grid_size(const covest_grid *g) { return g ? g->flat_end - g->flat_begin : COVEST_E_INVALID; }
+
+int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
+{
+    if (!g)
+        return fail(COVEST_E_INVALID, "covest_grid_eval: null grid");
+    if (!g->configured)
+        return fail(COVEST_E_INVALID, "covest_grid_eval: the last covest_grid_reset of this handle failed; reset it again");
+    covest_model *m = g->model;
+    const int kern = resolve_kernel(m, kernel, g);
+    if (kern < 0)
+        return kern;
+    std::lock_guard<std::mutex> guard(m->lock);
+    DeviceGuard dev_guard(m->device);
+    int rc = dev_guard.status();
+    if (rc != COVEST_OK)
+        return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n = g->flat_end - g->flat_begin;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g->profiling) {
+        if (g->ev_used == g->ev_begin.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            g->ev_begin.push_back(a);
+            g->ev_end.push_back(b);
+        }
+        e0 = g->ev_begin[g->ev_used];
+        e1 = g->ev_end[g->ev_used];
+        g->ev_used++;
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    HIP_TRY(launch_ll(m, kern, g->src, n, g->ll.as<double>(), sub_list_of(m, g->has_plan ? g->t_max : 2, g->sub_index.ptr, g->sub_word.ptr, g->sub_ctl.ptr), st,
+                      &g->last_kernel, g));
+    g->last_kernel_id = kern;
+    if (e1)
+        HIP_TRY(hipEventRecord(e1, st));
+#ifdef COVEST_DIAG // diagnostic builds only: how many points the recurrence kernel handed back for the strict evaluation
+    if (std::getenv("COVEST_DIAG_QUEUE")) {
+        unsigned queued = 0;
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(&queued, g->sub_ctl.ptr, sizeof queued, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "covest_grid_eval: %u of %lld points handed back\n", queued, (long long)n);
+        if (queued > 0) { // the row ranges named: how long they are
+            std::vector<unsigned long long> words(queued);
+            HIP_TRY(hipMemcpy(words.data(), g->sub_word.ptr, (size_t)queued * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            double sum = 0;
+            long long mx = 0, mn = 1 << 30, first_sum = 0;
+            for (unsigned long long w : words) {
+                const long long unit = sub_units16(w) ? 16 : 1;
+                const long long len = ((long long)sub_last(w) - (long long)sub_first(w) + 1) * unit;
+                sum += (double)len;
+                mx = std::max(mx, len);
+                mn = std::min(mn, len);
+                first_sum += (long long)sub_first(w) * unit;
+            }
+            std::fprintf(stderr, "covest_grid_eval: rows named per point: min %lld mean %.1f max %lld; mean first row %.1f\n", mn,
+                         sum / queued, mx, (double)first_sum / queued);
+        }
+    }
+#endif
+    if (!g->result_host) // (page-locked, mapped: argmin_stage2 stores the winner there itself)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->result_host), sizeof(ArgminResult), hipHostMallocMapped));
+    HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->flat_begin, g->partial_val.as<double>(),
+                          g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), g->result_host, g->sub_ctl.as<unsigned>(), st));
+    g->last_stream = st;
+    g->evaluated = true;
+    return COVEST_OK;
+}
+
+int covest_grid_argmin(covest_grid *g, double *min_negll, int64_t *argmin_flat)
+{
+    if (!g || !min_negll || !argmin_flat)
+        return fail(COVEST_E_INVALID, "covest_grid_argmin: null argument");
+    if (!g->evaluated)
+        return fail(COVEST_E_INVALID, "covest_grid_argmin: covest_grid_eval has not run");
+    DeviceGuard dev_guard(g->model->device);
+    int rc = dev_guard.status();
+    if (rc != COVEST_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(g->last_stream));
+    const ArgminResult r = *g->result_host; // (the arg-min kernel's own store: covest_grid_eval)
+    *min_negll = r.min_negll;
+    *argmin_flat = r.index < 0 ? -1 : g->flat_begin + r.index;
+    return COVEST_OK;
+}
+
+const double *covest_grid_ll_device(const covest_grid *g) { return g ? g->ll.as<double>() : nullptr; }
+
+const double *covest_grid_argmin_pair_device(const covest_grid *g)
+{
+    return g ? g->result.as<ArgminResult>()->pair : nullptr; // (address arithmetic only: nothing is read here)
+}
+
+int covest_grid_ll_host(covest_grid *g, double *out_ll)
+{
+    if (!g || !out_ll)
+        return fail(COVEST_E_INVALID, "covest_grid_ll_host: null argument");
+    if (!g->evaluated)
+        return fail(COVEST_E_INVALID, "covest_grid_ll_host: covest_grid_eval has not run");
+    DeviceGuard dev_guard(g->model->device);
+    int rc = dev_guard.status();
+    if (rc != COVEST_OK)
+        return rc;
+    const int64_t n = g->flat_end - g->flat_begin;
+    HIP_TRY(hipStreamSynchronize(g->last_stream));
+    if (n > 0)
+        HIP_TRY(hipMemcpy(out_ll, g->ll.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return COVEST_OK;
+}
+
+
+int64_t covest_grid_diag(covest_grid *g, int64_t *out, int64_t n)
+{
+    if (!g || !g->has_plan || !g->plan.diag)
+        return 0;
+    const int nw = g->plan.n_threads / 64;
+    const int64_t total = (g->plan.ce_end - g->plan.ce_begin) * g->plan.n_qblocks * nw * 8;
+    if (out && n > 0) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(out, g->plan.diag, (size_t)std::min(n, total) * sizeof(int64_t), hipMemcpyDeviceToHost);
+    }
+    return total;
+}
+
+int covest_grid_work(const covest_grid *g, double *pmf_terms, double *flops, const char **kernel)
+{
+    if (!g)
+        return fail(COVEST_E_INVALID, "covest_grid_work: null grid");
+    const covest_model *m = g->model;
+    const double n = (double)(g->flat_end - g->flat_begin);
+    const double bins = (double)m->dm.bins.n;
+    const double S = (double)m->dm.n_err;
+    // SURVEY 8(d) unit: pmf terms of the per-point formulation, bins * S * sum(T - 1)
+    const double terms = bins * S * g->sum_t_minus_1;
+    if (pmf_terms)
+        *pmf_terms = terms;
+    if (flops) {
+        if (g->last_kernel_id == COVEST_KERNEL_FACTORED) {
+            // algorithmic minimum of the factored formulation (ll_factored.hip header):
+            // per (c,e): G build 2 flop per (key, o, s), contraction 2 flop per (row, q, o < T_q) -- a row is a key,
+            // or the sum of a whole count-less tile (tail != 0, tiles.h); where the plan shares steps between the
+            // columns of a q-tile (tiles.h) the shared sums count once --, one log (25 flop) per
+            // (counted key, q), prologue exps 25 per (o, s)
+            const double n_ce = (double)(g->plan.ce_end - g->plan.ce_begin);
+            const double max_o = (double)(g->t_max - 1);
+            const double rows = m->tail_is_zero ? bins : m->rows_contracted;
+            const double logged = m->tail_is_zero ? bins : m->keys_logged;
+            *flops = n_ce * (bins * S * max_o * 2.0 + rows * g->contract_flops_per_row +
+                             logged * (double)g->plan.n_q * 25.0 + 25.0 * S * max_o);
+        } else {
+            // 4 flop per pmf term + 25 per log + 25 per exp of the prologue
+            *flops = 4.0 * terms + 25.0 * bins * n + 25.0 * S * g->sum_t_minus_1;
+        }
+    }
+    if (kernel)
+        *kernel = g->last_kernel;
+    return COVEST_OK;
+}
+
+
+} // extern "C"

@@ -1,4 +1,4 @@
-// device_model.h -- plain-data views shared by the host side (capi.cpp) and the
+// device_model.h -- plain-data views shared by the host side (host.h and the *_host.cpp, abi_*.cpp files) and the
 // gfx950 kernels.  Everything here is passed to kernels BY VALUE as a kernel
 // argument (well under the 4 KB kernarg limit), so the scalar unit serves the
 // per-model constants from SGPRs / the scalar cache.
@@ -29,7 +29,7 @@ struct DevModel {
     double lo[kMaxParams];   // self.bounds, NaN = None            covest/models.py:23,179
     double hi[kMaxParams];
     double tail;
-    BinView bins; // bins that must be evaluated (see capi.cpp: all keys iff tail != 0)
+    BinView bins; // bins that must be evaluated (see abi_model.cpp: all keys iff tail != 0)
 };
 
 // Where the grid points of one launch come from.

@@ -52,7 +52,11 @@ constexpr double kClampPerTerm = 7e-317; // see above
 // kZeroSteps grid steps (EXACT value, tested before the product underflows) a p_j is zero in the reference whatever the
 // roundings were; between that and p_clamp the row is handed back to the term-by-term evaluation.
 constexpr double kZeroSteps = 0.12;
-constexpr double kGridStep = 4.94065645841246544e-324;
+constexpr double kGridStep = 4.94065645841246544e-324; // 2^-1074
+// kZeroSteps grid steps TIMES 2^sh, for values carried with that factor (K-basic's p_j 2^64, the chunks' shares
+// 2^128).  Multiplied in THIS order: kZeroSteps * kGridStep alone rounds to 0 (round 4, first cut: every row below
+// the clamp went to the strict kernel, 78 instead of 29 us on C2)
+constexpr double zero_steps_scaled(double two_to_sh) { return kZeroSteps * (kGridStep * two_to_sh); }
 
 __host__ __device__ inline unsigned long long sub_word(unsigned first, unsigned last, bool units16)
 {

@@ -70,27 +70,30 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     const double p_clamp = sub_list.p_clamp;
     CompSum acc_sp = {0.0, 0.0};
 
-    // one key's p_j = g * sc (the streams' scaled sum times the key's scale: flushed like the reference's double): into
-    // sp_j, and its log (all branches wave-uniform)
-    const double zero_thr = kZeroSteps * kGridStep * 0x1p64; // direct_point.h kZeroSteps, against g * 2^64 * sc
-    auto account = [&](double g, double sc, double h, int row) {
-        const double p = g * sc;
+    // one key's p_j, TIMES 2^64 (tiles.h kBasicShift: the scales of the tile table carry the factor, so the product
+    // of the streams' sum and the key's scale does not flush to 0 below half a grid step of the doubles -- the
+    // reference's own roundings keep a p_j alive down to a quarter of one, direct_point.h kZeroSteps): into sp_j, and
+    // its log, the 2^-64 folded into the log's exponent arithmetic (all branches wave-uniform)
+    const double clamp_s = p_clamp * kBasicScale;
+    const double zero_s = zero_steps_scaled(kBasicScale);
+    auto account = [&](double ps, double h, int row) {
         if (TAIL)
-            acc_sp.add(p); // (filler keys have scale 0: p == 0)
+            acc_sp.add(ps); // (filler keys have scale 0: p == 0)
         if (h != 0.0) { // filler keys and zero counts: no log (`if h`, covest/models.py:106)
             // log(max(p_j, p_clamp)): what a p_j deep in the subnormal range contributes is then a known constant,
-            // which the strict evaluation of that key replaces later (direct_point.h); p_j <= 0 is remembered below
-            acc_ll = fma(h, fast_log(fmax(p, p_clamp), log_tab), acc_ll);
+            // which the strict evaluation of that key replaces later (direct_point.h); p_j = 0 is remembered below
+            const double xs[1] = {max_raw(ps, clamp_s)};
+            double lg[1];
+            fast_log_bits_n<1, 5, kBasicShift>(xs, lg, log_tab);
+            acc_ll = fma(h, lg[0], acc_ll);
             // one compare per key for everything out of the ordinary (lanes already dead have nothing to add)
-            const uint64_t low = __ballot(p < p_clamp) & ~dead;
+            const uint64_t low = __ballot(ps < clamp_s) & ~dead;
             if (__builtin_expect(low != 0, 0)) { // wave-uniform, cold
-                // utils.safe_log: p_j <= 0 makes the whole sum -inf -- remembered as a lane mask in SGPRs.  Decided on
-                // the EXACT value (g * 2^64 cannot overflow here: p < p_clamp bounds g by 1e-12), not on the product's
-                // own flush to 0 below half a grid step: the reference's roundings keep p_j alive down to a quarter
-                // of one (direct_point.h kZeroSteps); what lies between is a row for the strict evaluation
-                const bool zero = ldexp(g, 64) * sc <= zero_thr; // (NaN: not a zero -- a NaN stays a NaN)
+                // utils.safe_log: p_j = 0 makes the whole sum -inf -- remembered as a lane mask in SGPRs; decided on
+                // the EXACT value (kZeroSteps).  Between that and the clamp: a row for the strict evaluation
+                const bool zero = ps <= zero_s; // (NaN: not a zero -- a NaN stays a NaN)
                 dead |= __ballot(zero);
-                if (!zero && p < p_clamp) // deep in the subnormal range: name the row (rows come in ascending order)
+                if (!zero && ps < clamp_s) // deep in the subnormal range: name the row (rows come in ascending order)
                     subw = subw ? sub_word(sub_first(subw), (unsigned)row, false) : sub_word((unsigned)row, (unsigned)row, false);
             }
         }
@@ -152,13 +155,13 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
                 for (int b = 0; b < 16; b += 2) {
                     double g1, g2;
                     st.template step2n<N>(xx, g1, g2);
-                    account(g1, sc[b], hc[b], t * kTileBins + 16 * half + b);
-                    account(g2, sc[b + 1], hc[b + 1], t * kTileBins + 16 * half + b + 1);
+                    account(g1 * sc[b], hc[b], t * kTileBins + 16 * half + b);
+                    account(g2 * sc[b + 1], hc[b + 1], t * kTileBins + 16 * half + b + 1);
                 }
             }
         } else {
             for (int b = 0; b < nb; ++b)
-                account(st.template step_n<N>(), scal[b], cnt[b], t * kTileBins + b);
+                account(st.template step_n<N>() * scal[b], cnt[b], t * kTileBins + b);
         }
         st.template leave_tile_n<N>(tv.renorm[t]);
     };
@@ -225,7 +228,7 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
 
     double tail_term = 0.0;
     if (TAIL) {
-        double sp = acc_sp.hi + acc_sp.lo;
+        double sp = (acc_sp.hi + acc_sp.lo) * (1.0 / kBasicScale); // (the p_j were summed times 2^64: exact)
         if (!(sp < 1.0))
             sp = 1.0;
         if (sp < 1.0)

@@ -228,6 +228,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU], a_off0[MU], nsh[MU];
     double r4[MU], llacc[MU];
     uint64_t dead[MU]; // lanes that met a p_j <= 0 with h_j != 0
+    // (round 4) slots whose unit is DEAD: every one of its 16 weight vectors has met a p_j = 0 at a counted key, so
+    // each of their sums is -inf whatever the later keys are worth (utils.safe_log; a tail term is finite or 0) --
+    // the unit's remaining shared steps, MFMA steps and logs are skipped.  The units that die are the short ones
+    // (small threshold_o against large keys): 13 % of C3's logs.  Wave-uniform, bit k = slot k and its pieces.
+    unsigned off_slots = 0;
     CompSum spacc[MU];
     // wave w's block of MU slots in the unit tables
     auto wave_block = [&](int w) -> int {
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
         }
         st.template leave_tile_n<N>(renorm);
-        return gsum;
+        return gsum * (1.0 / kBasicScale); // (tv.scal carries 2^kBasicShift, tiles.h)
     };
     auto build_tile_sum = [&](int t, bool seg_start) __attribute__((always_inline)) -> double {
         const double k0 = tv.first_key[t];
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         for (int b = 0; b < nb; ++b)
             gsum = fma(st.step(), scal[b], gsum);
         st.leave_tile(tv.renorm[t]);
-        return gsum;
+        return gsum * (1.0 / kBasicScale);
     };
     // One item into `dst`: a plain tile, or (TAIL) the per-tile sums of up to 32 count-less tiles as its rows.
     auto build_item = [&](int it, double *dst) __attribute__((always_inline)) {
@@ -507,6 +512,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 a0[k] = cur[a_off0[k]]; // (an idle slot reads a valid address and uses nothing)
 #pragma unroll
             for (int k = 0; k < MU; ++k) {
+                if (PLAIN && ((off_slots >> k) & 1u)) { // wave-uniform: a dead unit (its len[k] is 0 by now)
+                    acc[k] = zero4;
+                    continue;
+                }
                 if (!PLAIN || nsh[k] == 0 || COVEST_SKIP_PHASE(plan, 8)) { // wave-uniform
                     acc[k] = len[k] > 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], wfirst[k], zero4, 0, 0, 0) : zero4;
                     continue;
@@ -598,13 +607,15 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     continue;
                 }
                 if (TAIL && item_is_sum) { // rows are sums over count-less tiles (scaled ones): they only enter sp_j
-                    if (qslot[k] >= 0 && !cont[k]) {
+                    if (qslot[k] >= 0 && !cont[k] && !(PLAIN && ((off_slots >> k) & 1u))) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             spacc[k].add(acc[k][r]);
                     }
                     continue;
                 }
+                if (PLAIN && ((off_slots >> k) & 1u))
+                    continue; // a dead unit: nothing it could add changes its -inf
                 if (qslot[k] >= 0 && !cont[k] && !COVEST_SKIP_PHASE(plan, 4)) { // wave-uniform: first slot of a unit
                     // Everything out of the ordinary -- p_j <= 0, or deep in the subnormal range (below p_clamp,
                     // direct_point.h), at a key with h_j != 0 -- is caught by ONE compare per row against the clamp in
@@ -677,6 +688,18 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     for (int r = 0; r < 4; ++r)
                         llacc[k] = fma(h4[r], lg4[r], llacc[k]);
                     __builtin_amdgcn_sched_barrier(0); // ... one unit at a time: registers
+                }
+            }
+            if (PLAIN) { // retire the units that died in this item: the first slot and the pieces behind it
+#pragma unroll
+                for (int k = 0; k < MU; ++k) {
+                    const bool first_dead = !cont[k] && dead[k] == ~0ull && qslot[k] >= 0;
+                    const bool piece_dead = k > 0 && cont[k] && ((off_slots >> (k - 1)) & 1u);
+                    if (first_dead || piece_dead) { // wave-uniform
+                        off_slots |= 1u << k;
+                        len[k] = 0; // (the step loops below stay correct with a zero among the sorted lengths: every
+                                    // live slot k still gets max(len[k..5]) = len[k] steps)
+                    }
                 }
             }
             STAMP(dg_c)
@@ -822,7 +845,7 @@ __device__ __forceinline__ double finish_point(const DevModel &m, const TileView
         const double pj_scaled = valid ? read_pj(row) : 0.0;
         double pj = pj_scaled * (1.0 / kShareScale); // (one rounding, onto the doubles' grid)
         const double h = valid ? tv.item_cnt[row] : 0.0;
-        uint64_t sub = __ballot(h != 0.0 && pj_scaled > kZeroSteps * kGridStep * kShareScale &&
+        uint64_t sub = __ballot(h != 0.0 && pj_scaled > zero_steps_scaled(kShareScale) &&
                                 pj < 2.2250738585072014e-308); // a subnormal p_j, or one the product above flushed
         while (sub) { // wave-uniform, rare
             const int who = __builtin_ctzll(sub);

@@ -36,7 +36,7 @@
 #include "../../include/covest_amd.h"
 
 namespace covest {
-int set_error(int code, const std::string &msg); // capi.cpp: records the message for covest_last_error
+int set_error(int code, const std::string &msg); // host_common.cpp: records the message for covest_last_error
 }
 
 namespace {

@@ -1,5 +1,5 @@
 // tiles.h -- the tile table of the pmf recurrence (see streams.h), shared by the
-// host builder (capi.cpp: build_tiles) and the fast kernels.
+// host builder (tiles_host.cpp: build_tiles) and the fast kernels.
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -10,9 +10,14 @@ constexpr int kTileBins = 32;
 constexpr int kScaleBits = 540;
 constexpr double kScaleLn = 540.0 * 0.693147180559945309417232121458; // ln 2^SC
 constexpr double kWindowLn = -760.0; // terms below e^-760 are 0 in double
+// TileView::scal carries 2^kBasicShift on top: K-basic's p_j (streams' sum x key's scale) are p_j 2^64 -- nothing
+// overflows (p_j <= 2.5), and a p_j below half a grid step of the doubles does not flush to 0 in the product, so the
+// kernel can tell a zero of the reference from a row for the strict evaluation (direct_point.h kZeroSteps)
+constexpr int kBasicShift = 64;
+constexpr double kBasicScale = 0x1p64;
 
 // Tiles of <= 32 consecutive keys over the evaluated bins (built on the host,
-// capi.cpp: build_tiles).  All arrays live in one device buffer; everything
+// tiles_host.cpp: build_tiles).  All arrays live in one device buffer; everything
 // indexed by tile is wave-uniform and read through the scalar cache.
 //
 // ITEMS: what a kernel walks is a list of items, each one LDS buffer's worth of K-factored's phases B/C.  A
@@ -37,7 +42,7 @@ struct TileView {
     const double *lgam_prev;   // [n_tiles] lgamma(k0)       = ln (k0-1)!
     const double *lgam_last;   // [n_tiles] lgamma(k0 + nb)  = ln (k0+nb-1)!
     const double *renorm;      // [n_tiles] (k0-1)! / (k0+nb-1)!   carries v into the next tile
-    const double *scal;        // [n_tiles][32] 2^-SC (k0-1)!/(k0+b)!; 0 for filler keys (gaps of the histogram the
+    const double *scal;        // [n_tiles][32] 2^(kBasicShift-SC) (k0-1)!/(k0+b)!; 0 for filler keys (gaps of the histogram the
                                //   recurrence walks through) and padding: their p_j is exactly 0, so they add nothing to sp_j
     const double *cnt;         // [n_tiles][32] h_j (0 for padding and filler keys)
     const double *item_cnt;    // [n_items][32] the counts of an item's 32 rows: its tile's for a plain item, 0 for a sum item
@@ -61,7 +66,7 @@ struct TileView {
                                //   recurrence kernel names a key it hands back (direct_point.h)
 };
 
-// The layout of capi.cpp: build_tiles.
+// The layout of tiles_host.cpp: build_tiles.
 inline __host__ __device__ TileView tile_view_from(int32_t nt, int32_t ni, const double *dbl, const int32_t *ints)
 {
     TileView tv;

@@ -195,6 +195,8 @@ class DenseGrid:
     def evaluate(self, kernel="auto", stream=None):
         """Launch LL + arg-min for the block (asynchronous on `stream`, a raw
         hipStream_t value such as torch.cuda.current_stream().cuda_stream)."""
+        if stream:
+            _capi.require_shared_runtime("DenseGrid.evaluate(stream=...)")
         _capi.check(_capi.lib().covest_grid_eval(self._handle, _capi.KERNELS[kernel],
                                                  ctypes.c_void_p(stream or 0)), "covest_grid_eval")
 
@@ -222,6 +224,7 @@ class DenseGrid:
         tensor {min -LL, GLOBAL flat index (-1: none)} aliasing the handle's 16 bytes in HBM (no copy, no
         synchronisation: consume it on the stream evaluate() ran on)."""
         import torch
+        _capi.require_shared_runtime("DenseGrid.argmin_pair_tensor")
         ptr = _capi.lib().covest_grid_argmin_pair_device(self._handle)
 
         class _View:  # the CUDA array interface is how torch adopts foreign device memory (HIP included)

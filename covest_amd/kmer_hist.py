@@ -155,6 +155,7 @@ class KmerCounts:
             self._reserve_for(n_new)
         else:  # still occurrences inserted since the last measurement: later batches must see them in the bound
             self._added += n_new
+        _capi.require_shared_runtime("KmerCounts.add_device")
         _capi.check(_capi.lib().covest_kmer_add_device(
             self._handle, ctypes.c_void_p(d_bases_ptr), ctypes.c_void_p(d_offsets_ptr or 0),
             int(n_reads), int(read_len), ctypes.c_void_p(stream or 0)), "covest_kmer_add_device")
@@ -167,6 +168,7 @@ class KmerCounts:
         the counter answers histogram() / len() exactly; after the partitioned path it holds no dict to add to
         (clear() first).  Returns the name of the path taken."""
         n_bases = int(n_bases if n_bases is not None else int(n_reads) * max(int(read_len), 0))
+        _capi.require_shared_runtime("KmerCounts.count_reads_device")
         rc = _capi.lib().covest_kmer_count_reads_device(
             self._handle, ctypes.c_void_p(d_bases_ptr), ctypes.c_void_p(d_offsets_ptr or 0), int(n_reads), int(read_len),
             n_bases, ctypes.c_void_p(stream or 0))

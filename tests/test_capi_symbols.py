@@ -89,3 +89,28 @@ def test_model_surface_without_device():
     # picklable (covest/grid.py:48 pickles the bound likelihood function), handle never travels
     r2 = pickle.loads(pickle.dumps(r))
     assert r2.hist == hist and r2._handle is None and r2.bounds == r.bounds
+
+
+def test_import_order_guard():
+    """One process, one HIP runtime: torch must be imported BEFORE libcovest_amd.so is loaded.  The
+    other order is refused loudly wherever device memory would cross between the two (covest_amd._capi
+    .require_shared_runtime) instead of handing torch a pointer of another runtime."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from covest_amd import _capi\n"
+            "%s"
+            "_capi.lib()\n"
+            "%s"
+            "try:\n"
+            "    _capi.require_shared_runtime('test')\n"
+            "    print('ok')\n"
+            "except _capi.CovestHipError as e:\n"
+            "    print('refused', 'two HIP runtimes' in str(e))\n")
+    late = subprocess.run([sys.executable, "-c", code % (repo, "", "import torch\n")], capture_output=True, text=True)
+    assert late.stdout.strip() == "refused True", (late.stdout, late.stderr[-500:])
+    early = subprocess.run([sys.executable, "-c", code % (repo, "import torch\n", "")], capture_output=True, text=True)
+    assert early.stdout.strip() == "ok", (early.stdout, early.stderr[-500:])
+    none = subprocess.run([sys.executable, "-c", code % (repo, "", "")], capture_output=True, text=True)
+    assert none.stdout.strip() == "ok", (none.stdout, none.stderr[-500:])

@@ -86,3 +86,40 @@ def test_four_rank_tie_across_non_adjacent_ranks():
     for rank in range(4):
         assert got[rank][:-1] == want, (rank, got[rank])
         assert got[rank][-1] == (250 * rank, 250 * (rank + 1))
+
+
+def test_eight_rank_exchange_and_balanced_partition():
+    """World size 8 -- the node the north star names (8 x MI355X): the exchange over gloo with the minimum on several
+    ranks, NaN / empty blocks among them, every rank agreeing; and the C3-shaped partition cut for 8 ranks by the
+    cost weights (sum(T - 1) per (q1, q2, q) sub-index) is contiguous, complete and balanced to 2 %."""
+    import numpy as np
+    from covest_amd.grid import partition_flat_range, scan_min_pairs
+    inf, nan = math.inf, math.nan
+    cases = [
+        [(9.0, 10), (8.0, 130), (7.0, 260), (6.0, 380), (5.0, 510), (4.0, 640), (3.0, 760), (2.0, 880)],
+        [(2.0, 10), (2.0, 130), (2.0, 260), (2.0, 380), (2.0, 510), (2.0, 640), (2.0, 760), (2.0, 880)],
+        [(inf, -1), (nan, 130), (3.0, 260), (inf, -1), (3.0, 500), (nan, 640), (inf, -1), (3.5, 880)],
+        [(inf, -1)] * 8,
+        [(5.0, 124), (5.0, 249), (-inf, 300), (5.0, 499), (-inf, 500), (1.0, 700), (0.0, 800), (nan, 900)],
+    ]
+    want = [(2.0, 880), (2.0, 10), (3.0, 260), (inf, -1), (-inf, 300)]
+    assert [scan_min_pairs(c) for c in cases] == want
+    got = _run(8, cases)
+    for rank in range(8):
+        assert got[rank][:-1] == want, (rank, got[rank])
+        assert got[rank][-1] == (125 * rank, 125 * (rank + 1))
+    # the partition of a repeats grid: weights per (q1, q2, q) sub-index, repeated for every (c, e)
+    rng = np.random.default_rng(8)
+    w = np.sort(rng.integers(8, 285, size=256)).astype(np.float64)[::-1].copy()
+    total = 128 * 128 * 256
+    bounds = partition_flat_range(total, 8, w)
+    assert bounds[0] == 0 and bounds[-1] == total and all(a < b for a, b in zip(bounds[:-1], bounds[1:]))
+    csum = np.concatenate(([0.0], np.cumsum(np.tile(w, 64))))  # cost of 64 (c, e) pairs: the pattern repeats
+    per = len(w) * 64
+
+    def cost(a, b):
+        full, ra, rb = (b // per) - (a // per), a % per, b % per
+        return full * csum[-1] + csum[rb] - csum[ra]
+
+    costs = [cost(a, b) for a, b in zip(bounds[:-1], bounds[1:])]
+    assert max(costs) <= 1.02 * (sum(costs) / 8), costs

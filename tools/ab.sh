@@ -6,7 +6,7 @@ for i in 1 2; do
   for lib in "$a" "$b"; do
     for w in $wl; do
       echo -n "$(basename $lib) $w: "
-      COVEST_AMD_LIB=$PWD/$lib python bench.py --workload $w --steps 20 --warmup 3 --cpu-budget 0 2>/dev/null |
+      COVEST_AMD_LIB=$PWD/$lib python bench.py --workload $w --steps 20 --warmup 3 --cpu-budget 0 --no-variants 2>/dev/null |
         python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'])"
     done
   done
