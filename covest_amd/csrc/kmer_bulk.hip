@@ -712,7 +712,9 @@ __global__ __launch_bounds__(256) void kmer_bucket_count_kernel(const KmerBulk p
         const u64 n = filled < room ? filled : room;
         const ulonglong2 *recs = p.recs + first;
         // records of this bucket in the overflow list too, or more distinct keys than the table holds: to the table
-        bool fall_back = filled > room;
+        // ... or so many records that one key's count could pass the 32 bits of the LDS counters (a low-complexity input
+        // with 2^32 windows and more in one bucket): the table's counters are 64-bit
+        bool fall_back = filled > room || filled * (u64)p.max_run >= (1ull << 32);
         u64 n_kmers = 0;
         if (!fall_back) {
             unsigned slots = 1024;
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(256) void kmer_bucket_count_kernel(const KmerBulk p
             __syncthreads();
         }
         if (fall_back) {
-            if (filled > room) // (not read yet)
+            if (n_kmers == 0) // (not read yet)
                 for (u64 i = tid; i < n; i += blockDim.x)
                     n_kmers += (u64)((int)recs[i].y - p.k + 1);
             for (int off = 32; off >= 1; off >>= 1)

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // ---- phase-B/C state: this wave's (q-tile, half) units ----
     const int col = lane & 15; // q column inside a tile / key row of the A fragment
     const int kq = lane >> 4;  // which of the 4 o of an MFMA step
-    int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off[MU], a_off0[MU], nsh[MU];
+    int len[MU], cont[MU], uhalf[MU], qslot[MU], cut[MU], a_off0[MU], nsh[MU];
     double r4[MU], llacc[MU];
     uint64_t dead[MU]; // lanes that met a p_j <= 0 with h_j != 0
     // (round 4) slots whose unit is DEAD: every one of its 16 weight vectors has met a p_j = 0 at a counted key, so
@@ -256,7 +256,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // then run over step 0 and the steps AFTER them, which is what a_off, cut and len are counted in
         nsh[k] = PLAIN ? __builtin_amdgcn_readfirstlane(on ? plan.unit_nsh[at] : 0) : 0;
         a_off0[k] = (16 * uhalf[k] + col) * LD + kq + 4 * first_step; // this lane's A fragment of the piece's first step
-        a_off[k] = a_off0[k] + 4 * nsh[k];                            // ... counted from the first step after the shared ones
         // iterations of the piece during which this lane's copy number o0 + 4 i + kq (o0: the piece's first one,
         // counted from the chunk's start) is below T (the chunk's local one)
         const int t_lane = on ? plan.q_T[slot] : 0;
@@ -553,6 +552,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             STAMP(dg_b0)
             // the remaining steps, specialised on the number of slots still running (len is sorted)
             if (!COVEST_SKIP_PHASE(plan, 2)) {
+                int a_off[MU]; // this lane's A fragments counted from the first step after the shared ones (per tile: 6 adds
+                               // instead of 6 registers held through the other phases)
+#pragma unroll
+                for (int k = 0; k < MU; ++k)
+                    a_off[k] = a_off0[k] + 4 * nsh[k];
                 int i = 1;
                 for (; i < len[5]; ++i)
                     contract_step<6, MU>(i, cur, a_off, cut, r4, wrun, acc);
@@ -575,8 +579,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     asm volatile("" ::: "memory");
                     acc[k - 1] += acc[k];
                 }
-            load_weights(); // for the next key tile
-
             STAMP(dg_b)
             // ================= phase C: h_j * log p_j from the accumulators =================
             const bool item_is_sum = TAIL && tv.item_sum[t] != 0; // wave-uniform
@@ -690,6 +692,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     __builtin_amdgcn_sched_barrier(0); // ... one unit at a time: registers
                 }
             }
+            // the weights of the next key tile, behind the logs (round 4: issued before them -- where their latency hides
+            // best -- the 24 registers they land in were live through the logs and the kernel spilled 18-74; here it
+            // spills none and measures the same, 0.856 against 0.856-0.862 ms: the builders' phase A and the barrier hide
+            // the loads just as well)
+            load_weights();
             if (PLAIN) { // retire the units that died in this item: the first slot and the pieces behind it
 #pragma unroll
                 for (int k = 0; k < MU; ++k) {
