@@ -146,6 +146,9 @@ struct covest_reads {
     const uint8_t *map = nullptr;
     size_t size = 0, pos = 0; // pos: the next unparsed byte -- the file's start, or a record's first byte
     bool fastq = false;
+    bool wrapped = false; // FASTQ whose sequence / quality run over several lines (Bio.SeqIO reads those too): the general
+                          // grammar, one record after the other, single-threaded (see parse_fastq_wrapped)
+    const uint8_t *strict_malformed = nullptr; // where the 4-line parser gave up and handed over to the general grammar
     int n_strategy = 0;
     uint64_t seed = 0;
     int n_threads = 1;
@@ -242,8 +245,8 @@ void parse_piece(const covest_reads *r, const uint8_t *b, const uint8_t *e, Piec
             if (in_record)
                 pc.lens.push_back((int64_t)pc.bases.n - start);
         } else {
-            // Strict 4-line records (what sequencers write; wrapped sequence lines are NOT supported -- the reference
-            // delegates to Bio.SeqIO, which accepts them): @id / sequence / + / quality.  Blank lines between records
+            // Strict 4-line records (what sequencers write, and what can be cut into pieces for the threads; a file with
+            // wrapped sequence lines goes through parse_fastq_wrapped instead): @id / sequence / + / quality.  Blank lines between records
             // (and at the end of the file) are skipped; a record whose first line does not start with '@' or whose
             // third does not start with '+' is reported with its byte offset instead of being counted as garbage.
             int line = 0; // 0 = @id, 1 = sequence, 2 = +, 3 = quality
@@ -272,6 +275,129 @@ void parse_piece(const covest_reads *r, const uint8_t *b, const uint8_t *e, Piec
     } catch (const std::bad_alloc &) {
         pc.oom = true;
     }
+}
+
+// FASTQ by its GENERAL grammar, what the reference's Bio.SeqIO accepts (round 4; rounds 2-3 refused it): '@' header,
+// sequence lines up to the line that starts with '+', then quality lines until they hold as many characters as the
+// sequence did.  Quality lines may start with '@' or '+', which is why record boundaries cannot be found by looking at
+// line starts alone -- a wrapped file is parsed one record after the other, from a known record start: whole records of
+// [b, e) into `pc` until `max_bases` bases are there (at least one record); returns where it stopped (a record's first
+// byte, or e), nullptr on an error (pc.malformed / pc.bad / pc.oom say which).
+inline size_t line_chars(const uint8_t *p, const uint8_t *stop) // characters of a line that are not white space
+{
+    size_t n = 0;
+    for (; p < stop; ++p)
+        n += kBytes.cls[*p] != kSpace;
+    return n;
+}
+
+const uint8_t *parse_fastq_wrapped(const covest_reads *r, const uint8_t *b, const uint8_t *e, Piece &pc, int64_t max_bases)
+{
+    try {
+        const uint8_t *p = b;
+        auto next_line = [&](const uint8_t *&stop) { // [p, stop) = the line at p; p moves behind it
+            const uint8_t *line = p;
+            const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(p, '\n', (size_t)(e - p)));
+            stop = nl ? nl : e;
+            p = nl ? nl + 1 : e;
+            return line;
+        };
+        while (p < e) {
+            const uint8_t *rec = p, *stop;
+            const uint8_t *line = next_line(stop);
+            if (stop == line || (stop == line + 1 && *line == '\r'))
+                continue; // a blank line between records
+            if (*line != '@') {
+                pc.malformed = line;
+                return nullptr;
+            }
+            const int64_t start = (int64_t)pc.bases.n;
+            size_t seq_chars = 0;
+            bool plus = false;
+            while (p < e) {
+                line = next_line(stop);
+                if (line < stop && *line == '+') {
+                    plus = true;
+                    break;
+                }
+                seq_chars += line_chars(line, stop);
+                if (!put_line(r, pc, line, stop))
+                    return nullptr;
+            }
+            if (!plus) { // the file ends inside the sequence
+                pc.malformed = rec;
+                return nullptr;
+            }
+            size_t qual_chars = 0;
+            while (qual_chars < seq_chars && p < e) {
+                line = next_line(stop);
+                qual_chars += line_chars(line, stop);
+            }
+            if (qual_chars != seq_chars) { // shorter (the file ends) or longer (a line too many) than the sequence
+                pc.malformed = rec;
+                return nullptr;
+            }
+            pc.lens.push_back((int64_t)pc.bases.n - start);
+            if ((int64_t)pc.bases.n >= max_bases)
+                break;
+        }
+        return p;
+    } catch (const std::bad_alloc &) {
+        pc.oom = true;
+        return nullptr;
+    }
+}
+
+// Does the file look wrapped?  The first records by the general grammar: one whose sequence takes more than one line says
+// yes.  (A file that starts with 4-line records and wraps later is caught when the strict parser meets the first such
+// record: covest_reads_next then goes over to the general grammar from that batch on.)
+bool fastq_looks_wrapped(const covest_reads *r)
+{
+    const uint8_t *p = r->map, *e = r->map + std::min<size_t>(r->size, (size_t)1 << 20);
+    int records = 0;
+    while (p < e && records < 256) {
+        const uint8_t *nl = static_cast<const uint8_t *>(std::memchr(p, '\n', (size_t)(e - p)));
+        const uint8_t *stop = nl ? nl : e;
+        if (stop == p || (stop == p + 1 && *p == '\r')) {
+            p = nl ? nl + 1 : e;
+            continue;
+        }
+        if (*p != '@')
+            return false; // (not a record start: let the strict parser report it)
+        p = nl ? nl + 1 : e;
+        int seq_lines = 0;
+        size_t seq_chars = 0;
+        bool plus = false;
+        while (p < e) {
+            nl = static_cast<const uint8_t *>(std::memchr(p, '\n', (size_t)(e - p)));
+            stop = nl ? nl : e;
+            const uint8_t *line = p;
+            p = nl ? nl + 1 : e;
+            if (line < stop && *line == '+') {
+                plus = true;
+                break;
+            }
+            ++seq_lines;
+            seq_chars += line_chars(line, stop);
+        }
+        if (!plus)
+            return false;
+        if (seq_lines > 1)
+            return true;
+        size_t qual_chars = 0;
+        int qual_lines = 0;
+        while (qual_chars < seq_chars && p < e) {
+            nl = static_cast<const uint8_t *>(std::memchr(p, '\n', (size_t)(e - p)));
+            stop = nl ? nl : e;
+            qual_chars += line_chars(p, stop);
+            p = nl ? nl + 1 : e;
+            ++qual_lines;
+        }
+        if (qual_lines > 1)
+            return true;
+        ++records;
+    }
+    return false;
 }
 
 // The first byte of the first record that starts at or after p (the end of the file if there is none).
@@ -342,6 +468,7 @@ int covest_reads_open(const char *path, int32_t n_strategy, uint64_t seed, coves
         r->fastq = std::strcmp(dot, ".fq") == 0 || std::strcmp(dot, ".fastq") == 0;
     r->n_strategy = n_strategy;
     r->seed = seed;
+    r->wrapped = r->fastq && r->size && fastq_looks_wrapped(r);
     // threads: COVEST_READER_THREADS, or what the machine offers, 16 at most
     unsigned hw = std::thread::hardware_concurrency();
     int nt = hw ? (int)std::min(hw, 16u) : 4;
@@ -377,6 +504,57 @@ int covest_reads_next(covest_reads *r, int64_t max_bases, const uint8_t **bases,
     // the span: about max_bases bases' worth of file (headers, line ends and -- FASTQ -- qualities on top), up to
     // the next record boundary; one record at least
     const uint8_t *begin = r->map + r->pos, *end = r->map + r->size;
+    if (r->wrapped) { // FASTQ by the general grammar: one piece, whole records until max_bases are there
+        if (r->pieces.empty()) {
+            try {
+                r->pieces.resize(1);
+            } catch (const std::bad_alloc &) {
+                return covest::set_error(COVEST_E_NOMEM, "covest_reads_next: out of host memory");
+            }
+        }
+        Piece &pc = r->pieces[0];
+        pc.bases.n = 0;
+        pc.lens.clear();
+        pc.bad = pc.malformed = nullptr;
+        pc.oom = false;
+        const uint8_t *stop = parse_fastq_wrapped(r, begin, end, pc, max_bases);
+        if (!stop) {
+            if (pc.oom)
+                return covest::set_error(COVEST_E_NOMEM, "covest_reads_next: out of host memory");
+            if (r->strict_malformed) // neither grammar takes the record the 4-line parser stopped at: name THAT line
+                return covest::set_error(COVEST_E_INVALID, "covest_reads_next: malformed FASTQ record at byte " +
+                                                              std::to_string((long long)(r->strict_malformed - r->map)) +
+                                                              " (@id, sequence, +, quality -- or wrapped: sequence lines, "
+                                                              "+, as many quality characters)");
+            if (pc.malformed)
+                return covest::set_error(COVEST_E_INVALID, "covest_reads_next: malformed FASTQ record at byte " +
+                                                              std::to_string((long long)(pc.malformed - r->map)) +
+                                                              " (@id, sequence lines, +, as many quality characters)");
+            return covest::set_error(COVEST_E_INVALID, std::string("covest_reads_next: base '") + (char)*pc.bad +
+                                                          "' outside acgtn (single_hash raises KeyError)");
+        }
+        if (!out.reserve(std::max<size_t>(pc.bases.n, 1), r->want_pinned))
+            return covest::set_error(COVEST_E_NOMEM, "covest_reads_next: out of host memory");
+        try {
+            out.offsets.resize(pc.lens.size() + 1);
+        } catch (const std::bad_alloc &) {
+            return covest::set_error(COVEST_E_NOMEM, "covest_reads_next: out of host memory");
+        }
+        if (pc.bases.n)
+            std::memcpy(out.bases, pc.bases.p, pc.bases.n);
+        int64_t at = 0;
+        for (size_t k = 0; k < pc.lens.size(); ++k) {
+            at += pc.lens[k];
+            out.offsets[k + 1] = at;
+        }
+        r->pos = (size_t)(stop - r->map);
+        if (r->strict_malformed && stop > r->strict_malformed)
+            r->strict_malformed = nullptr; // (the general grammar took what the 4-line parser could not)
+        *bases = out.bases;
+        *offsets = out.offsets.data();
+        *n_reads = (int64_t)pc.lens.size();
+        return COVEST_OK;
+    }
     const double per_base = r->fastq ? 2.1 : 1.08;
     const size_t want = (size_t)std::min<double>((double)(end - begin), (double)max_bases * per_base + 64.0);
     const uint8_t *stop = next_record(r, begin + std::max<size_t>(want, 1));
@@ -420,10 +598,12 @@ int covest_reads_next(covest_reads *r, int64_t max_bases, const uint8_t **bases,
         const Piece &pc = pieces[(size_t)i];
         if (pc.oom)
             return covest::set_error(COVEST_E_NOMEM, "covest_reads_next: out of host memory");
-        if (pc.malformed)
-            return covest::set_error(COVEST_E_INVALID, "covest_reads_next: malformed FASTQ record at byte " +
-                                                          std::to_string((long long)(pc.malformed - r->map)) +
-                                                          " (4-line records: @id, sequence, +, quality)");
+        if (pc.malformed) { // not a 4-line record: a file that wraps its lines from here on?  The general grammar decides
+            r->wrapped = true;
+            r->strict_malformed = pc.malformed;
+            r->cur ^= 1; // (this call's batch buffer again)
+            return covest_reads_next(r, max_bases, bases, offsets, n_reads);
+        }
         if (pc.bad) // (pieces are in file order: the first one reported is the first in the file)
             return covest::set_error(COVEST_E_INVALID, std::string("covest_reads_next: base '") + (char)*pc.bad +
                                                           "' outside acgtn (single_hash raises KeyError)");
