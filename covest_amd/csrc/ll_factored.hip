@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 
     // ================= phase A: G'[key][o] of key tile t into `dst` =================
     // in-kernel stamps (diagnostic builds only): cycles per wave in build / contract / log / barrier
-    long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0, dg_zero = 0;
+    long long dg_a = 0, dg_b = 0, dg_b0 = 0, dg_c = 0, dg_w = 0, dg_t0 = 0, dg_zero = 0, dg_enter = 0, dg_first = 0;
 #ifdef COVEST_DIAG
     const bool diag = plan.diag != nullptr;
 #else
@@ -337,6 +337,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // n_live: streams above it are zero in every lane of this wave (streams.h) -- most of them, for most tiles
         const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
                                          tv.run_start[t] != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
+        if (diag) { // (diagnostic builds: entering the tile apart from walking it)
+            const long long now__ = (long long)clock64();
+            dg_enter += now__ - dg_t0;
+            dg_t0 = now__;
+        }
         double *colp = dst + (lane_in_row ? tid : 0);
         if (nb == kTileBins) { // the common case: straight-line code
             if (n_live > 4) {
@@ -509,6 +514,16 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 #pragma unroll
             for (int k = 0; k < MU; ++k)
                 a0[k] = cur[a_off0[k]]; // (an idle slot reads a valid address and uses nothing)
+            if (diag) { // (diagnostic builds: until the first fragments and the weights are there)
+                double sink = 0.0;
+#pragma unroll
+                for (int k = 0; k < MU; ++k)
+                    sink += a0[k] + wfirst[k];
+                asm volatile("" ::"v"(sink));
+                const long long now__ = (long long)clock64();
+                dg_first += now__ - dg_t0;
+                dg_t0 = now__;
+            }
 #pragma unroll
             for (int k = 0; k < MU; ++k) {
                 if (PLAIN && ((off_slots >> k) & 1u)) { // wave-uniform: a dead unit (its len[k] is 0 by now)
@@ -723,6 +738,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         d[3] = dg_w;
         d[4] = dg_b0;
         d[5] = dg_zero; // key tiles whose G columns of this (builder) wave were all zero
+        d[6] = dg_enter; // of phase A: StreamSet::enter_tile
+        d[7] = dg_first; // of phase B: waiting for the first A fragments (LDS) and the tile's weights (HBM / L2)
     }
 #undef STAMP
     if (list_mode >= 2)

@@ -1,13 +1,14 @@
-"""One estimate, start to finish, on the GPU path: what covest/covest.py:99-195 `main` does between parsing
-its arguments and printing -- `.hist` file -> process_histogram -> model -> first guess -> CoverageEstimator
--> result record -- as a function (no argparse surface; SURVEY.md 8(f) row F4 closes the loop with it)."""
+"""TEST HELPER (not part of the package: the reference's `main`, covest/covest.py:99-195, is out of scope -- SURVEY.md 2
+#4, "host Python stays as is" -- and a maintainer keeps calling it).  One estimate, start to finish, on
+the GPU path -- `.hist` file -> process_histogram -> model -> first guess -> CoverageEstimator -> result record -- so that
+tests/test_gpu_hist_steps.py::test_whole_default_flow can compare a whole run with the reference's recorded one."""
 from pathlib import Path
 
-from . import __version__, constants
-from .estimator import CoverageEstimator
-from .hist_steps import load_histogram, process_histogram, save_histogram
-from .models import select_model
-from .report import print_output
+from covest_amd import __version__, constants
+from covest_amd.estimator import CoverageEstimator
+from covest_amd.hist_steps import load_histogram, process_histogram, save_histogram
+from covest_amd.models import select_model
+from covest_amd.report import print_output
 
 
 def estimate(input_histogram, kmer_size=constants.DEFAULT_K, read_length=constants.DEFAULT_READ_LENGTH,

@@ -9,8 +9,8 @@ mkdir -p "$out"
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp && cd "$repo"
 for w in c3 c2; do
-  timeout -k 10 200 python3 bench.py --workload $w > "$out/bench_$w.json" 2> "$out/bench_$w.err" || echo "bench $w failed"
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$w" -o "$w" -- python3 bench.py --workload $w --steps 10 --warmup 2 --cpu-budget 0 > "$out/bench_${w}_under_rocprof.json" 2> "$out/trace_$w.err" || echo "trace $w failed"
+  timeout -k 10 200 python3 bench.py --workload $w --no-variants > "$out/bench_$w.json" 2> "$out/bench_$w.err" || echo "bench $w failed"
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$w" -o "$w" -- python3 bench.py --workload $w --steps 10 --warmup 2 --cpu-budget 0 --no-variants > "$out/bench_${w}_under_rocprof.json" 2> "$out/trace_$w.err" || echo "trace $w failed"
   find "$out/trace_$w" -name "*kernel_stats.csv" -exec cp {} "$out/${w}_kernel_stats.csv" \;
   bash tools/pmc_profile.sh "$out/pmc_$w" --workload $w --steps 5 --warmup 1 > "$out/pmc_$w.log" 2>&1
   python3 tools/pmc_summary.py "$out/pmc_$w" ll_ > "$out/${w}_pmc_summary.json"
@@ -20,8 +20,8 @@ done
 timeout -k 10 100 python3 bench.py --workload c1 > "$out/bench_c1.json" 2> "$out/bench_c1.err"
 timeout -k 10 200 python3 bench.py --workload og --steps 5 > "$out/bench_og.json" 2> "$out/bench_og.err"
 timeout -k 10 200 python3 bench.py --scaling strong --steps 5 --warmup 1 --cpu-budget 0 > "$out/bench_c3_strong_1gpu.json" 2> "$out/bench_strong.err"
-# the driver's N > 1 command line, rehearsed with two ranks on the one card over gloo: the weak step AND variants.strong
-timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --backend gloo --share-gpu --steps 5 --warmup 1 --cpu-budget 0 2> "$out/bench_2rank.err" | tail -1 > "$out/bench_c3_2rank_gloo_rehearsal.json"
+# the driver's N > 1 command line, rehearsed with four ranks on the one card over gloo (the pool's process guard allows six processes a GPU: five ranks and the launcher): the weak step AND variants.strong
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 4 --backend gloo --share-gpu --steps 5 --warmup 1 --cpu-budget 0 2> "$out/bench_4rank.err" | tail -1 > "$out/bench_c3_4rank_gloo_rehearsal.json"
 # phase stamps and instruction counts by phase: the DIAGNOSTIC build only (the shipped library has no such switches)
 if [ -f tools/bin/libcovest_amd_diag.so ]; then
   COVEST_AMD_LIB=$PWD/tools/bin/libcovest_amd_diag.so COVEST_FACTORED_DIAG=1 timeout -k 10 100 python3 tools/factored_diag.py > "$out/c3_factored_phase_stamps.txt" 2>&1

@@ -23,8 +23,7 @@ buf = np.zeros(n, dtype=np.int64)
 L.covest_grid_diag(g._handle, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n)
 d = buf.reshape(-1, 8, 8)[:, :, :4].astype(np.float64)  # [wg][wave][build, contract, log, barrier]
 extra = buf.reshape(-1, 8, 8)
-print("workgroups", d.shape[0], "units logged per wave %.1f, of which through the cold branch %.1f" % (
-    extra[:, :, 6].mean(), extra[:, :, 5].mean()))
+print("workgroups", d.shape[0])
 print("key tiles (of %d) whose 64 G columns of a builder wave were all zero: " % 31 +
       "  ".join("wave %d: %.1f" % (w, extra[:, w, 5].mean()) for w in range(5)))
 tot = d.sum(axis=2)
@@ -32,5 +31,6 @@ print("mean cycles per wave (s_memtime ticks): total %.0f" % tot.mean())
 for w in range(8):
     a, b, c, bar = d[:, w, :].mean(axis=0)
     b0 = extra[:, w, 4].mean()  # shared steps + first MFMA step
-    print("wave %d: build %8.0f  shared+first %8.0f  contract %8.0f  log %8.0f  barrier %8.0f   total %8.0f" % (
-        w, a, b0, b, c, bar, a + b0 + b + c + bar))
+    ent, fst = extra[:, w, 6].mean(), extra[:, w, 7].mean()
+    print("wave %d: enter %7.0f  walk %7.0f  wait-first %7.0f  shared+first %7.0f  contract %7.0f  log %7.0f  barrier %7.0f   total %8.0f" % (
+        w, ent, a, fst, b0, b, c, bar, ent + a + fst + b0 + b + c + bar))

@@ -15,7 +15,7 @@ groups=(
 )
 i=0
 for g in "${groups[@]}"; do
-  timeout -k 10 240 rocprofv3 --pmc $g --output-format csv -d "$out" -o "pass$i" -- python3 bench.py "$@" --cpu-budget 0 > "$out/pass$i.json" 2> "$out/pass$i.err" || echo "pass $i failed"
+  timeout -k 10 240 rocprofv3 --pmc $g --output-format csv -d "$out" -o "pass$i" -- python3 bench.py "$@" --cpu-budget 0 --no-variants > "$out/pass$i.json" 2> "$out/pass$i.err" || echo "pass $i failed"
   i=$((i+1))
 done
 ls "$out"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: the end point of THIS library's default flow (covest_amd.pipeline.estimate: guess, L-BFGS-B refinement) on
+"""GPU box: the end point of THIS library's default flow (tests/flow_helper.py estimate: guess, L-BFGS-B refinement) on
 the reference's own test histogram, for both models -> gpurun_out/own_optimum.json.  NOT reference values: where
 L-BFGS-B stops on the flat ridge hangs on the last bits of the likelihood values, so the reference's end
 point is not reproducible; this file pins the library's OWN end point as a regression value
@@ -11,12 +11,13 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
 
 
 def main():
-    from covest_amd.pipeline import estimate
+    from flow_helper import estimate
     path = os.path.join(REPO, "tests", "golden", "sim_c10_e0.05.hist")
-    out = {"what": "covest_amd.pipeline.estimate on sim_c10_e0.05.hist: this library's own end point (regression value, "
+    out = {"what": "tests/flow_helper.py estimate on sim_c10_e0.05.hist: this library's own end point (regression value, "
                    "not the reference's)", "models": {}}
     for model in ("basic", "repeats"):
         runs = [estimate(path, model=model) for _ in range(2)]
