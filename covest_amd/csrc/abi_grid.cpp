@@ -36,12 +36,8 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
 
     // threshold_o over the (q1, q2, q) sub-grid (host, libm)
     std::vector<int32_t> table((size_t)nq);
-    for (int64_t a = 0; a < n1 && nq; ++a)
-        for (int64_t b = 0; b < n2; ++b)
-            for (int64_t c = 0; c < n3; ++c) {
-                const double par[5] = {0, 0, axes[2][a], axes[3][b], axes[4][c]};
-                table[(size_t)((a * n2 + b) * n3 + c)] = threshold_for_point(m, par);
-            }
+    if (nq)
+        threshold_table(m, axes[2], n1, axes[3], n2, axes[4], n3, table.data());
 
     // arena layout: [axes | queue counter (8 B) | t_table] uploaded together, then the outputs
     auto up8 = [](size_t v) { return (v + 7) / 8 * 8; };
@@ -118,8 +114,9 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
 
 static void grid_release(covest_grid *g)
 {
+    (void)hipDeviceSynchronize(); // (the buffers go back to the process's cache, host.h: nothing may still work on them)
     if (g->result_host) {
-        (void)hipHostFree(g->result_host);
+        pinned_block_give(g->result_host);
         g->result_host = nullptr;
     }
     g->arena.release();
@@ -279,8 +276,12 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
         }
     }
 #endif
-    if (!g->result_host) // (page-locked, mapped: argmin_stage2 stores the winner there itself)
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->result_host), sizeof(ArgminResult), hipHostMallocMapped));
+    if (!g->result_host) { // (page-locked, mapped: argmin_stage2 stores the winner there itself)
+        static_assert(sizeof(ArgminResult) <= 64, "pinned block");
+        g->result_host = static_cast<ArgminResult *>(pinned_block_take());
+        if (!g->result_host)
+            return fail(COVEST_E_NOMEM, "covest_grid_eval: no page-locked memory for the result");
+    }
     HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->flat_begin, g->partial_val.as<double>(),
                           g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), g->result_host, g->sub_ctl.as<unsigned>(), st));
     g->last_stream = st;

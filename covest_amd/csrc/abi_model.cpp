@@ -121,6 +121,7 @@ void covest_model_destroy(covest_model *m)
     if (!m)
         return;
     DeviceGuard dev_guard(m->device);
+    (void)hipDeviceSynchronize(); // (its small buffers go back to the process's cache: nothing may still work on them)
     delete m; // (its buffers go with it: host.h DevBuf / HostBuf)
 }
 

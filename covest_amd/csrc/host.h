@@ -41,6 +41,17 @@ int fail_hip(hipError_t e, const char *what);
             return fail_hip(e__, #expr);             \
     } while (0)
 
+// Small device buffers that a handle lets go are KEPT for the next handle of the process (round 4): hipMalloc costs
+// 20-50 us and hipFree waits for the device, and a search that creates a model handle and a grid handle pays four of each
+// -- a quarter of a millisecond of a 1.1 ms time-to-argmin.  Per device, buffers of up to 8 MB, 64 MB at most; a buffer
+// is given only by an owner whose work on it is done (the destroy entry points wait for the device first), and taken by
+// best fit.  host_common.cpp.
+bool dev_cache_take(size_t bytes, void **ptr, size_t *cap);
+bool dev_cache_give(void *ptr, size_t cap);
+// ... and the 64 page-locked, device-mapped bytes a grid handle's arg-min writes its winner to
+void *pinned_block_take();
+void pinned_block_give(void *p);
+
 // A device allocation that grows on demand and is released with its owner.
 struct DevBuf {
     void *ptr = nullptr;
@@ -64,9 +75,10 @@ struct DevBuf {
         if (bytes <= cap)
             return hipSuccess;
         if (ptr)
-            (void)hipFree(ptr);
-        ptr = nullptr;
-        cap = 0;
+            (void)hipDeviceSynchronize(); // (growing: whatever still works on the old buffer finishes first -- hipFree waited too)
+        release();
+        if (dev_cache_take(bytes, &ptr, &cap))
+            return hipSuccess;
         hipError_t e = hipMalloc(&ptr, bytes);
         if (e == hipSuccess)
             cap = bytes;
@@ -74,7 +86,7 @@ struct DevBuf {
     }
     void release()
     {
-        if (ptr)
+        if (ptr && !dev_cache_give(ptr, cap))
             (void)hipFree(ptr);
         ptr = nullptr;
         cap = 0;
@@ -267,6 +279,8 @@ namespace covest {
 
 // ---- host_common.cpp
 int threshold_o_host(double q1, double q2, double q, double thr, bool has_thr, int hist_max);
+void threshold_table(const covest_model *m, const double *a1, int64_t n1, const double *a2, int64_t n2, const double *a3,
+                     int64_t n3, int32_t *out); // threshold_o over the product of three (q1, q2, q) axes, last fastest
 double clamp_one(const DevModel &dm, int d, double v);
 int threshold_for_point(const covest_model *m, const double *par);
 void lgamma_ensure(int64_t j_max);

@@ -30,6 +30,106 @@ int fail_hip(hipError_t e, const char *what)
                : COVEST_E_HIP;
 }
 
+namespace {
+struct DevCache {
+    std::mutex mu;
+    struct Entry {
+        int device;
+        void *ptr;
+        size_t cap;
+    };
+    std::vector<Entry> free_list;
+    size_t bytes = 0;
+    std::vector<std::pair<int, void *>> pinned; // (device, block)
+};
+DevCache &dev_cache()
+{
+    static DevCache *c = new DevCache; // (never freed: the runtime may be gone when statics are destroyed)
+    return *c;
+}
+constexpr size_t kDevCacheEntryMax = (size_t)8 << 20, kDevCacheTotalMax = (size_t)64 << 20;
+} // namespace
+
+bool dev_cache_take(size_t bytes, void **ptr, size_t *cap)
+{
+    if (bytes == 0 || bytes > kDevCacheEntryMax)
+        return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return false;
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> hold(c.mu);
+    size_t best = c.free_list.size();
+    for (size_t i = 0; i < c.free_list.size(); ++i) {
+        const DevCache::Entry &e = c.free_list[i];
+        // best fit, and no buffer more than four times what is asked for (a 4 MB buffer for 200 bytes would starve the
+        // next large request)
+        if (e.device == dev && e.cap >= bytes && e.cap <= std::max<size_t>(4 * bytes, 4096) &&
+            (best == c.free_list.size() || e.cap < c.free_list[best].cap))
+            best = i;
+    }
+    if (best == c.free_list.size())
+        return false;
+    *ptr = c.free_list[best].ptr;
+    *cap = c.free_list[best].cap;
+    c.bytes -= c.free_list[best].cap;
+    c.free_list.erase(c.free_list.begin() + (std::ptrdiff_t)best);
+    return true;
+}
+
+bool dev_cache_give(void *ptr, size_t cap)
+{
+    if (!ptr || cap == 0 || cap > kDevCacheEntryMax)
+        return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return false;
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> hold(c.mu);
+    if (c.bytes + cap > kDevCacheTotalMax || c.free_list.size() >= 256)
+        return false;
+    c.free_list.push_back({dev, ptr, cap});
+    c.bytes += cap;
+    return true;
+}
+
+void *pinned_block_take()
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        DevCache &c = dev_cache();
+        std::lock_guard<std::mutex> hold(c.mu);
+        for (size_t i = 0; i < c.pinned.size(); ++i)
+            if (c.pinned[i].first == dev) {
+                void *p = c.pinned[i].second;
+                c.pinned.erase(c.pinned.begin() + (std::ptrdiff_t)i);
+                return p;
+            }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void pinned_block_give(void *p)
+{
+    if (!p)
+        return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    DevCache &c = dev_cache();
+    std::lock_guard<std::mutex> hold(c.mu);
+    if (c.pinned.size() < 64) {
+        c.pinned.push_back({dev, p});
+        return;
+    }
+    (void)hipHostFree(p);
+}
+
 SharedStage &shared_stage()
 {
     static SharedStage *s = new SharedStage; // (never freed: the runtime may be gone when statics are destroyed)
@@ -42,12 +142,9 @@ SharedStage &shared_stage()
 // 0 <= 1-q <= 1, so the first crossing is found by bisection and then confirmed
 // against its left neighbours with the very same pow calls the linear scan of
 // the reference would make; outside that domain the scan itself is used.
-double weight_ge3(double head, double one_minus_q, int o)
-{
-    return head * std::pow(one_minus_q, (double)(o - 3));
-}
-
-int threshold_o_host(double q1, double q2, double q, double thr, bool has_thr, int hist_max)
+// (pw(o) = pow(1 - q, o - 3): libm's, called directly or looked up in a table of the very same calls)
+template <class PowFn>
+static int threshold_o_impl(double q1, double q2, double q, double thr, bool has_thr, int hist_max, PowFn pw)
 {
     if (!has_thr)
         return hist_max;
@@ -60,27 +157,67 @@ int threshold_o_host(double q1, double q2, double q, double thr, bool has_thr, i
     const double head = (1 - q1) * (1 - q2) * q;
     const double base = 1 - q;
     const int last = hist_max - 1; // o ranges over 3..last
+    auto weight = [&](int o) { return head * pw(o); };
     if (!(base >= 0.0 && base <= 1.0) || !(head == head)) {
         for (int o = 3; o <= last; ++o)
-            if (weight_ge3(head, base, o) <= thr)
+            if (weight(o) <= thr)
                 return o;
         return hist_max;
     }
-    if (weight_ge3(head, base, 3) <= thr)
+    if (weight(3) <= thr)
         return 3;
-    if (!(weight_ge3(head, base, last) <= thr))
+    if (!(weight(last) <= thr))
         return hist_max;
     int lo = 3, hi = last; // f(lo) > thr, f(hi) <= thr
     while (hi - lo > 1) {
         const int mid = lo + (hi - lo) / 2;
-        if (weight_ge3(head, base, mid) <= thr)
+        if (weight(mid) <= thr)
             hi = mid;
         else
             lo = mid;
     }
-    while (hi > 3 && weight_ge3(head, base, hi - 1) <= thr)
+    while (hi > 3 && weight(hi - 1) <= thr)
         --hi;
     return hi;
+}
+
+int threshold_o_host(double q1, double q2, double q, double thr, bool has_thr, int hist_max)
+{
+    const double base = 1 - q;
+    return threshold_o_impl(q1, q2, q, thr, has_thr, hist_max, [&](int o) { return std::pow(base, (double)(o - 3)); });
+}
+
+// threshold_o over the (q1, q2, q) product of three axes (clamped to the model's bounds), last axis fastest: the same
+// decisions as threshold_o_host point by point, but the powers of one q are computed ONCE for all its (q1, q2) -- an
+// optimize_grid iteration asks for 216 thresholds of 6 different q, 1 300 calls of pow otherwise (round 4).
+void threshold_table(const covest_model *m, const double *a1, int64_t n1, const double *a2, int64_t n2, const double *a3,
+                     int64_t n3, int32_t *out)
+{
+    // pw[o] = pow(1 - q, o - 3) for the q in hand; NaN: not asked for yet (the entries a q touched are set back, not the
+    // whole table: 10 000 keys and 16 values of q would be a megabyte of fills)
+    std::vector<double> pw((size_t)std::max(m->hist_max, 4) + 1, std::numeric_limits<double>::quiet_NaN());
+    std::vector<int> touched;
+    for (int64_t c = 0; c < n3; ++c) {
+        const double q = clamp_one(m->dm, 4, a3[c]);
+        const double base = 1 - q;
+        for (int o : touched)
+            pw[(size_t)o] = std::numeric_limits<double>::quiet_NaN();
+        touched.clear();
+        auto pow_of = [&](int o) {
+            double &v = pw[(size_t)o];
+            if (v != v) {
+                v = std::pow(base, (double)(o - 3));
+                touched.push_back(o); // (a power that IS NaN -- q is -- is computed again each time: still the same value)
+            }
+            return v;
+        };
+        for (int64_t a = 0; a < n1; ++a) {
+            const double q1 = clamp_one(m->dm, 2, a1[a]);
+            for (int64_t b = 0; b < n2; ++b)
+                out[(a * n2 + b) * n3 + c] = threshold_o_impl(q1, clamp_one(m->dm, 3, a2[b]), q, m->threshold, m->has_threshold,
+                                                              m->hist_max, pow_of);
+        }
+    }
 }
 
 double clamp_one(const DevModel &dm, int d, double v)

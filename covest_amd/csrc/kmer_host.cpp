@@ -101,6 +101,7 @@ void covest_kmer_destroy(covest_kmer *c)
             (void)hipEventDestroy(e);
             e = nullptr;
         }
+    (void)hipDeviceSynchronize();
     delete c; // (its buffers go with it: host.h DevBuf)
 }
 
@@ -126,6 +127,8 @@ int covest_kmer_clear(covest_kmer *c, void *stream)
     // whether its last call succeeded or not (a call that failed after its reserve left `bulk` false and the records
     // allocated: the table path the caller falls back to needs that memory).  covest_kmer_count_reads_device has
     // returned, and hipFree waits for the device: nothing of it is in flight
+    if (c->bulk_recs.ptr || c->bulk_ovf.ptr)
+        (void)hipDeviceSynchronize();
     c->bulk_recs.release();
     c->bulk_ovf.release();
     c->bulk = false;

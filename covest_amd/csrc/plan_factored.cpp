@@ -365,6 +365,8 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
 {
     covest_model *m = g->model;
     g->has_plan = false;
+    if (!g->long_parts.empty())
+        (void)hipDeviceSynchronize(); // (their buffers go back to the process's cache, host.h)
     for (covest_grid::Part &part : g->long_parts)
         part.buf.release();
     g->long_parts.clear();
