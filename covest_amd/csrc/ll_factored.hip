@@ -233,6 +233,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // the unit's remaining shared steps, MFMA steps and logs are skipped.  The units that die are the short ones
     // (small threshold_o against large keys): 13 % of C3's logs.  Wave-uniform, bit k = slot k and its pieces.
     unsigned off_slots = 0;
+    bool newly_dead = false; // a column of this wave's met its first zero in the item just logged
     CompSum spacc[MU];
     // wave w's block of MU slots in the unit tables
     auto wave_block = [&](int w) -> int {
@@ -268,6 +269,15 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         spacc[k].lo = 0.0;
     }
 
+    // what kind of slot k is, as bit k of a mask (wave-uniform; tested once per tile and slot): the first slot of a unit
+    // (it takes the logs), a piece behind one (its accumulator is added to the slot before), a unit with shared steps
+    unsigned m_first = 0, m_cont = 0, m_sh = 0;
+#pragma unroll
+    for (int k = 0; k < MU; ++k) {
+        m_first |= (qslot[k] >= 0 && !cont[k]) ? 1u << k : 0u;
+        m_cont |= cont[k] ? 1u << k : 0u;
+        m_sh |= nsh[k] > 0 ? 1u << k : 0u;
+    }
     // b_o of every slot's first (wfirst) and second (wrun, then advanced by (1-q)^4 per step) MFMA step:
     // an L2-resident host table.  The loads for tile t+1 are issued between tile t's MFMAs and its
     // logs, so their latency (2-3 us per tile when exposed) hides behind the logs and the barrier.
@@ -320,12 +330,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 xx[s] = 0.0;
             }
         }
+        double *row = colp; // (walked row by row: one vector add a store, no scalar multiply by the row's number)
 #pragma unroll
         for (int b = 0; b < kTileBins; b += 2) {
             double g1, g2;
             st.template step2n<N>(xx, g1, g2);
-            colp[b * LD] = g1;
-            colp[(b + 1) * LD] = g2;
+            row[0] = g1;
+            row[LD] = g2;
+            row += 2 * LD;
         }
         st.template leave_tile_n<N>(renorm);
     };
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     acc[k] = zero4;
                     continue;
                 }
-                if (!PLAIN || nsh[k] == 0 || COVEST_SKIP_PHASE(plan, 8)) { // wave-uniform
+                if (!PLAIN || !((m_sh >> k) & 1u) || COVEST_SKIP_PHASE(plan, 8)) { // wave-uniform
                     acc[k] = len[k] > 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], wfirst[k], zero4, 0, 0, 0) : zero4;
                     continue;
                 }
@@ -572,6 +584,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 #pragma unroll
                 for (int k = 0; k < MU; ++k)
                     a_off[k] = a_off0[k] + 4 * nsh[k];
+                // (measured and not kept, round 4: one address register a slot with the buffer's base folded in and two
+                // steps a trip, the second fragment an immediate offset away -- the compiler moves the induction to the
+                // scalar unit, six s_add a trip: 0.867-0.871 against 0.855-0.858 ms)
                 int i = 1;
                 for (; i < len[5]; ++i)
                     contract_step<6, MU>(i, cur, a_off, cut, r4, wrun, acc);
@@ -590,7 +605,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             // keeps the compiler from turning it into four adds and eight selects for every slot, taken or not)
 #pragma unroll
             for (int k = MU - 1; k >= 1; --k)
-                if (cont[k]) { // wave-uniform
+                if ((m_cont >> k) & 1u) { // wave-uniform
                     asm volatile("" ::: "memory");
                     acc[k - 1] += acc[k];
                 }
@@ -624,7 +639,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     continue;
                 }
                 if (TAIL && item_is_sum) { // rows are sums over count-less tiles (scaled ones): they only enter sp_j
-                    if (qslot[k] >= 0 && !cont[k] && !(PLAIN && ((off_slots >> k) & 1u))) {
+                    if (((m_first >> k) & 1u) && !(PLAIN && ((off_slots >> k) & 1u))) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             spacc[k].add(acc[k][r]);
@@ -633,7 +648,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
                 if (PLAIN && ((off_slots >> k) & 1u))
                     continue; // a dead unit: nothing it could add changes its -inf
-                if (qslot[k] >= 0 && !cont[k] && !COVEST_SKIP_PHASE(plan, 4)) { // wave-uniform: first slot of a unit
+                if (((m_first >> k) & 1u) && !COVEST_SKIP_PHASE(plan, 4)) { // wave-uniform: first slot of a unit
                     // Everything out of the ordinary -- p_j <= 0, or deep in the subnormal range (below p_clamp,
                     // direct_point.h), at a key with h_j != 0 -- is caught by ONE compare per row against the clamp in
                     // the row's own units (0 for a row without a count: filler keys, a tile's padding, zero counts
@@ -683,6 +698,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                         // met the zero, and the other three need not come through here for it
                         const uint64_t zc = (zero | (zero >> 16) | (zero >> 32) | (zero >> 48)) & 0xFFFFull;
                         dead[k] |= zc * 0x0001000100010001ull;
+                        newly_dead = newly_dead || zc != 0; // (wave-uniform: look for dead units after this item's logs)
                         // p_j DEEP IN THE SUBNORMAL RANGE: the unit (this half tile) is recorded for every weight vector
                         // (column) concerned -- first and last unit met; one writer per entry, the lane of row group 0.
                         // The strict evaluation of its counted rows follows in ll_fix_list_kernel (argmin.hip)
@@ -712,11 +728,12 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             // spills none and measures the same, 0.856 against 0.856-0.862 ms: the builders' phase A and the barrier hide
             // the loads just as well)
             load_weights();
-            if (PLAIN) { // retire the units that died in this item: the first slot and the pieces behind it
+            if (PLAIN && newly_dead) { // retire the units that died in this item: the first slot and the pieces behind it
+                newly_dead = false;
 #pragma unroll
                 for (int k = 0; k < MU; ++k) {
-                    const bool first_dead = !cont[k] && dead[k] == ~0ull && qslot[k] >= 0;
-                    const bool piece_dead = k > 0 && cont[k] && ((off_slots >> (k - 1)) & 1u);
+                    const bool first_dead = ((m_first >> k) & 1u) && dead[k] == ~0ull;
+                    const bool piece_dead = k > 0 && ((m_cont >> k) & 1u) && ((off_slots >> (k - 1)) & 1u);
                     if (first_dead || piece_dead) { // wave-uniform
                         off_slots |= 1u << k;
                         len[k] = 0; // (the step loops below stay correct with a zero among the sorted lengths: every
@@ -787,15 +804,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const int qt = plan.unit_tile[at];
         if (qt < 0 || plan.unit_half[at] != 0 || plan.unit_cont[at])
             continue;
-        int pe = -1; // the unit with the same tile and half 1 (always in the same workgroup)
-        for (int w2 = 0; w2 < NW && pe < 0; ++w2)
-            for (int k2 = 0; k2 < MU; ++k2) {
-                const int at2 = wave_block(w2) * MU + k2;
-                if (plan.unit_tile[at2] == qt && plan.unit_half[at2] == 1 && !plan.unit_cont[at2]) {
-                    pe = (w2 * MU + k2) * 16 + c;
-                    break;
-                }
-            }
+        // the unit with the same tile and half 1 (always in the same workgroup): named by the host (tiles.h unit_pair;
+        // until round 4 every thread searched the 48 slots for it, three dependent loads a slot)
+        const int pslot = plan.unit_pair[at];
+        const int pe = pslot >= 0 ? pslot * 16 + c : -1;
         // + the constant of the rows' scales (see the kernel's header): sum_j h_j ln((k0-1)!/(k0+b)!) over this
         // workgroup's items
         const double ll = (part_ll[e] + (pe >= 0 ? part_ll[pe] : 0.0)) + lconst;

@@ -261,9 +261,23 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
             }
         }
     }
+    // the half-1 partner of every half-0 unit (the same workgroup holds both): looked up by the kernel's last step
+    std::vector<int32_t> unit_pair(n_unit, -1);
+    for (int blk = 0; blk < n_qblocks; ++blk) {
+        const size_t b0 = (size_t)blk * nw * mu, b1 = b0 + (size_t)nw * mu;
+        for (size_t at = b0; at < b1; ++at) {
+            if (unit_tile[at] < 0 || unit_half[at] != 0 || unit_cont[at])
+                continue;
+            for (size_t at2 = b0; at2 < b1; ++at2)
+                if (unit_tile[at2] == unit_tile[at] && unit_half[at2] == 1 && !unit_cont[at2]) {
+                    unit_pair[at] = (int32_t)(at2 - b0);
+                    break;
+                }
+        }
+    }
     // one buffer: doubles first (r4 | piece_w), then int32 (q_T | q_orig | unit tables)
     const size_t n_dbl = n_slots + piece_w.size() + unit_rho.size();
-    const size_t n_int = 2 * n_slots + 7 * n_unit;
+    const size_t n_int = 2 * n_slots + 8 * n_unit;
     HIP_TRY(buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
     double *dbase = buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
@@ -288,6 +302,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         std::copy(unit_len.begin(), unit_len.end(), sp + 4 * n_unit);
         std::copy(unit_cont.begin(), unit_cont.end(), sp + 5 * n_unit);
         std::copy(unit_nsh.begin(), unit_nsh.end(), sp + 6 * n_unit);
+        std::copy(unit_pair.begin(), unit_pair.end(), sp + 7 * n_unit);
         HIP_TRY(hipMemcpy(buf.ptr, sd, stage_bytes, hipMemcpyHostToDevice));
     }
     pl = FactoredPlan{};
@@ -320,6 +335,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     pl.unit_len = ub + 4 * n_unit;
     pl.unit_cont = ub + 5 * n_unit;
     pl.unit_nsh = ub + 6 * n_unit;
+    pl.unit_pair = ub + 7 * n_unit;
     pl.piece_w = dbase + n_slots;
     pl.unit_rho = dbase + n_slots + piece_w.size();
     pl.q_first8 = nullptr;
@@ -523,7 +539,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     const size_t n_slots = (size_t)n * 16, n_blocks = 1 + 2 * (size_t)n, n_unit = n_blocks * MU;
     std::vector<double> axes(2 * (size_t)n), r4(n_slots, 0.0), piece_w(n_unit * 64 * 2, 0.0);
     std::vector<int32_t> q_t(n_slots, 0), q_orig(n_slots, -1), unit_tile(n_unit, -1), unit_half(n_unit, 0),
-        unit_s0(n_unit, 0), unit_o0(n_unit, 1), unit_len(n_unit, 0), unit_cont(n_unit, 0);
+        unit_s0(n_unit, 0), unit_o0(n_unit, 1), unit_len(n_unit, 0), unit_cont(n_unit, 0), unit_pair(n_unit, -1);
     for (int64_t p = 0; p < n; ++p) {
         const double *par = params + p * 5;
         axes[(size_t)p] = par[0];
@@ -549,6 +565,8 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
                 unit_o0[at] = 1 + 4 * k * piece_len;
                 unit_len[at] = piece_len;
                 unit_cont[at] = k > 0;
+                if (h == 0 && k == 0) // its half-1 partner: the first slot of the workgroup's last wave (tiles.h unit_pair)
+                    unit_pair[at] = (NW - 1) * MU;
                 for (int which = 0; which < 2; ++which)
                     for (int kq = 0; kq < 4; ++kq) { // column 0 only: lanes 16 kq
                         const int o_local = 1 + 4 * (unit_s0[at] + which) + kq;
@@ -563,7 +581,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     std::vector<std::pair<const void *, size_t>> iparts = {
         {q_t.data(), q_t.size()},             {q_orig.data(), q_orig.size()},       {unit_tile.data(), unit_tile.size()},
         {unit_half.data(), unit_half.size()}, {unit_s0.data(), unit_s0.size()},     {unit_len.data(), unit_len.size()},
-        {unit_cont.data(), unit_cont.size()}, {unit_o0.data(), unit_o0.size()}};
+        {unit_cont.data(), unit_cont.size()}, {unit_o0.data(), unit_o0.size()}, {unit_pair.data(), unit_pair.size()}};
     size_t n_dbl = 0, n_int = 0;
     for (auto &pr : dparts)
         n_dbl += pr.second;
@@ -619,6 +637,7 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     pl.unit_len = iptr[5];
     pl.unit_cont = iptr[6];
     pl.unit_o0 = iptr[7];
+    pl.unit_pair = iptr[8];
     pl.unit_nsh = nullptr; // (list modes are not the PLAIN kernel: never read)
     pl.unit_rho = nullptr;
     pl.qtile_nsteps = nullptr;

@@ -147,6 +147,8 @@ struct FactoredPlan {
                                    //   unit's end are masked by the T cut-off)
     const int32_t *unit_cont;      // 1 = this slot continues the unit of the slot before it
     const int32_t *unit_nsh;       // SHARED steps of the slot's unit (0: none), see below
+    const int32_t *unit_pair;      // first slot of a half-0 unit: wave * kMaxUnits + slot (inside the workgroup) of the first
+                                   //   slot of the same q-tile's half-1 unit (-1: none); the kernel's last step adds the two
     const double *unit_rho;        // [slots][4] units with unit_nsh > 0: {(1-q)^16, unused, (1-q)^4, (1-q)^(-4 nsh)} of the unit's q-tile
     const double *piece_w;         // [slots][64 lanes][2] b_o at the piece's first step (masked by the column's
                                    //   cut-off) and at its second (o = 1 + 4 step + lane/16, column lane%16), libm
