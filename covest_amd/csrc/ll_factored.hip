@@ -157,7 +157,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // only exist with a tail; without one item i is tile i)
     const int seg_items = (n_items + n_seg - 1) / n_seg;
     const int t_begin = seg * seg_items, t_end = min(n_items, t_begin + seg_items);
-    const int64_t ce = plan.ce_begin + unit;
+    // (a dense grid's (c, e) pairs are taken from the END of the block: a pair costs the more the larger its rates are --
+    // 452 k to 467 k ticks along c on C3 -- and the workgroups launched last decide how long the chip's last round runs;
+    // round 4, from the per-workgroup stamps: 1.6 % of the launch was that tail, 0.4 % with the long ones first)
+    const int64_t ce = (PLAIN || list_mode == 0) ? plan.ce_end - 1 - unit : plan.ce_begin + unit;
     // (list mode: workgroup i takes point i of a point list -- its own (c, e) AND its own single weight
     // vector, see tiles.h FactoredPlan::list_mode)
     const bool list = list_mode == 1 || list_mode == 2; // (3 is a dense grid's chunk: addressed like mode 0)
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     __syncthreads();
     StreamSet<8> st;
     if (wave_builds) { // (wave-uniform) the waves that build nothing skip the mixture weights' exps, divisions and logs
-        st.init(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab, nullptr, 8 * my_pass,
+        st.init(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab, log_tab, 8 * my_pass,
                 n_total);
     } else {
         st.gone = 0u;
@@ -538,10 +541,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
 #pragma unroll
             for (int k = 0; k < MU; ++k) {
-                if (PLAIN && ((off_slots >> k) & 1u)) { // wave-uniform: a dead unit (its len[k] is 0 by now)
-                    acc[k] = zero4;
-                    continue;
-                }
+                // (a dead unit, off_slots: its len[k] is 0 by now and its bit of m_sh cleared -- it takes the branch below
+                // and starts from zero)
                 if (!PLAIN || !((m_sh >> k) & 1u) || COVEST_SKIP_PHASE(plan, 8)) { // wave-uniform
                     acc[k] = len[k] > 0 ? __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k], wfirst[k], zero4, 0, 0, 0) : zero4;
                     continue;
@@ -639,15 +640,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     continue;
                 }
                 if (TAIL && item_is_sum) { // rows are sums over count-less tiles (scaled ones): they only enter sp_j
-                    if (((m_first >> k) & 1u) && !(PLAIN && ((off_slots >> k) & 1u))) {
+                    if ((m_first >> k) & 1u) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             spacc[k].add(acc[k][r]);
                     }
                     continue;
                 }
-                if (PLAIN && ((off_slots >> k) & 1u))
-                    continue; // a dead unit: nothing it could add changes its -inf
+                // (a dead unit's bit of m_first is cleared: nothing it could add changes its -inf)
                 if (((m_first >> k) & 1u) && !COVEST_SKIP_PHASE(plan, 4)) { // wave-uniform: first slot of a unit
                     // Everything out of the ordinary -- p_j <= 0, or deep in the subnormal range (below p_clamp,
                     // direct_point.h), at a key with h_j != 0 -- is caught by ONE compare per row against the clamp in
@@ -736,8 +736,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     const bool piece_dead = k > 0 && ((m_cont >> k) & 1u) && ((off_slots >> (k - 1)) & 1u);
                     if (first_dead || piece_dead) { // wave-uniform
                         off_slots |= 1u << k;
-                        len[k] = 0; // (the step loops below stay correct with a zero among the sorted lengths: every
-                                    // live slot k still gets max(len[k..5]) = len[k] steps)
+                        m_first &= ~(1u << k); // no logs, no shared steps any more ...
+                        m_sh &= ~(1u << k);
+                        len[k] = 0; // ... and no MFMA steps (the step loops stay correct with a zero among the sorted
+                                    // lengths: every live slot k still gets max(len[k..5]) = len[k] steps)
                     }
                 }
             }

@@ -121,9 +121,17 @@ struct StreamSet {
     __device__ __forceinline__ int enter_tile_n(double km1, double klast, double lgam_prev,
                                                 double lgam_last, bool run_start)
     {
-        int n_live = 0;
+        // Round 4: the questions of all streams are asked FIRST (compares into scalar masks, no branch), then ONE branch
+        // for the rare case that some stream must be anchored, then the masks of what is live / gone.  (Until then every
+        // stream took three compare-then-branch round trips through the scalar unit, one after the other: a tenth of a
+        // builder wave's time in K-factored.)  Same decisions, same arithmetic, stream by stream.
+        uint64_t m_window[N], m_need[N];
+        double a0s[N];
+        uint64_t any_need = 0;
 #pragma unroll
         for (int s = 0; s < N; ++s) {
+            m_window[s] = m_need[s] = 0;
+            a0s[s] = 0.0;
             if ((gone >> s) & 1u)
                 continue; // wave-uniform: nothing to test, v[s] is 0 in every lane and stays 0
             const double lx = an.lx(s), c = an.c(s);
@@ -134,24 +142,42 @@ struct StreamSet {
             // anchor was a SUBNORMAL double, a handful of significant bits carried along by every later multiply;
             // below -745 it was 0 and the stream re-entered correctly.  Found by the C3 fixture with a tail:
             // sp_j off by 2e-10 where those streams have their mass.)
-            const bool in_window = fmax(a0, a1) > kWindowLn;
-            const bool need = run_start ? in_window : (v[s] == 0.0 && in_window);
+            m_window[s] = __ballot(fmax(a0, a1) > kWindowLn);
+            m_need[s] = run_start ? m_window[s] : (__ballot(v[s] == 0.0) & m_window[s]);
             if (run_start)
                 v[s] = 0.0; // what is left of the run before means nothing here
-            if (__any(need)) {
+            a0s[s] = a0;
+            any_need |= m_need[s];
+        }
+        if (any_need != 0) { // (wave-uniform; the first tiles of a run, and now and then a stream that enters the window)
+            const uint64_t me = 1ull << (threadIdx.x & 63);
+#pragma unroll
+            for (int s = 0; s < N; ++s) {
+                if (m_need[s] == 0)
+                    continue;
                 // 2^SC is applied exactly (v_ldexp_f64) wherever exp(a0) itself is a normal
                 // double: folding ln 2^SC = 374.3 into the argument would cost its ulp
                 // (5.7e-14) in every term, which tail*log(1 - sp_j) amplifies by 1/(1 - sp_j).
+                const double a0 = a0s[s];
                 const bool deep = a0 < -700.0;
                 const double e0 = exp(deep ? a0 + kScaleLn : a0);
                 const double anchored = deep ? e0 : ldexp(e0, kScaleBits);
-                v[s] = need ? anchored : v[s];
+                v[s] = (m_need[s] & me) ? anchored : v[s];
             }
-            if (__any(v[s] != 0.0))
+        }
+        int n_live = 0;
+#pragma unroll
+        for (int s = 0; s < N; ++s) {
+            if ((gone >> s) & 1u)
+                continue;
+            const uint64_t m_on = __ballot(v[s] != 0.0);
+            // off, outside the window and past the mode (the log-term is concave in the key, its top near x): in every
+            // lane, for every later key
+            const uint64_t m_stay = m_window[s] | __ballot(!(km1 >= x[s]));
+            if (m_on != 0)
                 n_live = s + 1; // wave-uniform
-            else if (!__any(in_window || !(km1 >= x[s])))
-                gone |= 1u << s; // off, outside the window and past the mode (the log-term is concave in the key,
-                                 // its top near x): in every lane, for every later key
+            else if (m_stay == 0)
+                gone |= 1u << s;
         }
         return n_live;
     }
