@@ -22,7 +22,7 @@ SOURCES = [("host_common.cpp", (), "host_common"), ("tiles_host.cpp", (), "tiles
            ("thin_host.cpp", (), "thin_host"), ("reads_io.cpp", (), "reads_io"), ("ll_direct.hip", (), "ll_direct"),
            ("ll_basic.hip", (), "ll_basic"), ("ll_factored.hip", (), "ll_factored"), ("argmin.hip", (), "argmin"),
            ("kmer_count.hip", (), "kmer_count"), ("kmer_wide.hip", (), "kmer_wide"), ("kmer_bulk.hip", (), "kmer_bulk"), ("thin_hist.hip", (), "thin_hist")]
-SOURCES += [("ll_factored.hip", ("-DCOVEST_FACTORED_VARIANT=%d" % v,), "ll_factored_v%d" % v) for v in range(8)]
+SOURCES += [("ll_factored.hip", ("-DCOVEST_FACTORED_VARIANT=%d" % v,), "ll_factored_v%d" % v) for v in range(10)]
 SOURCES += [("ll_basic.hip", ("-DCOVEST_BASIC_VARIANT=%d" % v,), "ll_basic_v%d" % v) for v in range(8)]
 MAX_PARALLEL = 8
 ARCH = "gfx950"

@@ -105,7 +105,11 @@ __device__ __forceinline__ void contract_step(int i, const double *cur, const in
 // right before their use: an exposed scalar-load latency every two keys); the 2^-SC disappears into the exponent
 // arithmetic of the log (fastmath.h fast_log_bits_n).  Only where p_j itself is needed -- sp_j with a tail, the
 // chunks' shares of p_j in list modes 2 and 3 -- a row is multiplied by its scale, read from LDS.
-template <int NT, int HU, bool TAIL, bool PLAIN>
+// LDC: the row stride of G as a COMPILE-TIME constant (0: plan.ld) -- kLdWide = 290, the stride of every plain grid whose
+// largest threshold_o - 1 lies in 257 .. 288 (C3: 284): the 32 stores of a tile's walk and the fragments' offsets become
+// immediates (round 4).
+constexpr int kLdWide = 290;
+template <int NT, int HU, bool TAIL, bool PLAIN, int LDC = 0>
 __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                          const double *__restrict__ tile_dbl,
                                                          const int32_t *__restrict__ tile_int,
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     static_assert(MU == 6, "contract loops are written for 6 slots");
     constexpr bool NEED_SCAL = TAIL || !PLAIN; // p_j itself is needed somewhere: sp_j, or the chunks' shares
     constexpr int LOG_DEG = PLAIN ? 4 : 5;     // (point lists keep the 2e-16 log: refinements difference their values)
-    const int LD = plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
+    const int LD = LDC ? LDC : plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
     __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
     load_log_table(log_tab);
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(kWave) void ll_finish_dense(const DevModel m, const
 // One instantiation per translation unit (COVEST_FACTORED_VARIANT, see the end of this file): the HIP runtime
 // loads a translation unit's code object when one of its kernels is first launched, and a process that evaluates a
 // plain dense grid should not pay for the seven other variants (75-98 KB of code each).
-template <int NT, bool TAIL, bool PLAIN>
+template <int NT, bool TAIL, bool PLAIN, int LDC = 0>
 hipError_t launch_ll_factored_variant(const DevModel &m, const TileView &tv, const FactoredPlan &plan,
                                       double *out_ll, const SubList &sub_list, hipStream_t stream)
 {
@@ -1003,7 +1007,7 @@ hipError_t launch_ll_factored_variant(const DevModel &m, const TileView &tv, con
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         dev = 0;
     if (lds > configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ll_factored_kernel<NT, HU, TAIL, PLAIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ll_factored_kernel<NT, HU, TAIL, PLAIN, LDC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
@@ -1017,18 +1021,24 @@ hipError_t launch_ll_factored_variant(const DevModel &m, const TileView &tv, con
         part.ce_end = std::min(plan.ce_end, first + per_launch);
         const dim3 grid((unsigned)((part.ce_end - part.ce_begin) * (plan.list_mode ? plan.n_seg : 1)),
                         (unsigned)plan.n_qblocks);
-        hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL, PLAIN>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.n_items,
+        hipLaunchKernelGGL((ll_factored_kernel<NT, HU, TAIL, PLAIN, LDC>), grid, dim3(NT), lds, stream, m, tv.n_tiles, tv.n_items,
                            tv.dbl_base, tv.int_base, part, out_ll, sub_list);
     }
     return hipGetLastError();
 }
 
 #ifdef COVEST_FACTORED_VARIANT
-// this translation unit holds ONE variant: bit 2 = 512 threads (else 256), bit 1 = TAIL, bit 0 = PLAIN
+// this translation unit holds ONE variant: bit 2 = 512 threads (else 256), bit 1 = TAIL, bit 0 = PLAIN; 8 and 9: 512
+// threads, PLAIN, the row stride kLdWide at compile time, bit 0 = TAIL
+#if COVEST_FACTORED_VARIANT >= 8
+template hipError_t launch_ll_factored_variant<512, (COVEST_FACTORED_VARIANT & 1) != 0, true, kLdWide>(
+    const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+#else
 template hipError_t launch_ll_factored_variant<(COVEST_FACTORED_VARIANT & 4) ? 512 : 256, (COVEST_FACTORED_VARIANT & 2) != 0,
                                                (COVEST_FACTORED_VARIANT & 1) != 0>(const DevModel &, const TileView &,
                                                                                    const FactoredPlan &, double *,
                                                                                    const SubList &, hipStream_t);
+#endif
 #else
 // the common translation unit: the finishing kernels and the dispatcher; the variants are linked in
 extern template hipError_t launch_ll_factored_variant<256, false, false>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
@@ -1039,6 +1049,8 @@ extern template hipError_t launch_ll_factored_variant<512, false, false>(const D
 extern template hipError_t launch_ll_factored_variant<512, false, true>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
 extern template hipError_t launch_ll_factored_variant<512, true, false>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
 extern template hipError_t launch_ll_factored_variant<512, true, true>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+extern template hipError_t launch_ll_factored_variant<512, false, true, kLdWide>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
+extern template hipError_t launch_ll_factored_variant<512, true, true, kLdWide>(const DevModel &, const TileView &, const FactoredPlan &, double *, const SubList &, hipStream_t);
 
 namespace {
 
@@ -1047,6 +1059,9 @@ hipError_t launch_nt(const DevModel &m, const TileView &tv, const FactoredPlan &
                      const SubList &sub_list, hipStream_t stream)
 {
     const bool plain = plan.list_mode == 0 && plan.n_pass == 1;
+    if (NT == 512 && plain && plan.ld == kLdWide) // the widest double-buffered shape: its row stride at compile time
+        return m.tail != 0.0 ? launch_ll_factored_variant<512, true, true, kLdWide>(m, tv, plan, out_ll, sub_list, stream)
+                             : launch_ll_factored_variant<512, false, true, kLdWide>(m, tv, plan, out_ll, sub_list, stream);
     if (m.tail != 0.0)
         return plain ? launch_ll_factored_variant<NT, true, true>(m, tv, plan, out_ll, sub_list, stream)
                      : launch_ll_factored_variant<NT, true, false>(m, tv, plan, out_ll, sub_list, stream);
