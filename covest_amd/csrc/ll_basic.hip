@@ -55,9 +55,7 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     const bool finite = isfinite(par[0]) && isfinite(par[1]);
 
     double lam[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-        lam[s] = error_class_rate(m, par[0], par[1], s);
+    error_class_rates<S>(m, par[0], par[1], lam); // (by multiplication: point_fetch.h)
     extern __shared__ double anchors[]; // [2S][lane of the workgroup]: conflict-free columns
     StreamSet<S, LdsAnchors<S>> st;
     st.an.mine = anchors + threadIdx.x;

@@ -64,6 +64,39 @@ __device__ __forceinline__ double error_class_rate(const DevModel &m, double c, 
     return v;
 }
 
+// ALL S error classes' rates of one point at once, for a kernel whose every lane is a point of its own (K-basic):
+// (1 - e)^(k - s) and e^s by multiplication -- (1 - e)^(k - S + 1) by squaring, then one multiply a class -- instead of
+// two calls of pow a class.  Round 4: the device library's pow is 210 instructions, and sixteen of them were HALF of
+// K-basic's instruction count on C2.  The products differ from pow's by a few 1e-16 relative (the reference's own pow and
+// the device's differ by as much); the log-likelihood moves by less than 1e-12 of itself.  Classes beyond k (padding of
+// the class count to a multiple of 8: comb = 0, they weigh nothing) get the exponent 0.
+template <int S>
+__device__ __forceinline__ void error_class_rates(const DevModel &m, double c, double err, double (&lam)[S])
+{
+    const double ck = c * (double)(m.r - m.k + 1) / (double)m.r;
+    const double q = 1.0 - err;
+    const int n_low = m.k - (S - 1) > 0 ? m.k - (S - 1) : 0; // the smallest exponent of q among the classes (wave-uniform)
+    double pw = 1.0, sq = q;
+    for (int n = n_low; n > 0; n >>= 1) { // q^n_low by squaring
+        if (n & 1)
+            pw *= sq;
+        sq *= sq;
+    }
+    double qp[S]; // q^(k - s)
+#pragma unroll
+    for (int s = S - 1; s >= 0; --s) {
+        qp[s] = pw;        // q^max(k - s, 0)
+        if (m.k - s >= 0)  // (wave-uniform) the class before has one more factor
+            pw *= q;
+    }
+    double pe = 1.0; // e^s (0^0 = 1: the error-free class at e = 0)
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        lam[s] = ((ck * m.pow3neg[s]) * qp[s]) * pe; // the reference's order of evaluation, covest/models.py:76-79
+        pe *= err;
+    }
+}
+
 // RepeatsModel.get_b_o, covest/models.py:193-208 (o >= 1).
 __device__ __forceinline__ double copy_number_weight(double q1, double q2, double q, int o)
 {
