@@ -446,7 +446,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         return gsum * (1.0 / kBasicScale);
     };
     // One item into `dst`: a plain tile, or (TAIL) the per-tile sums of up to 32 count-less tiles as its rows.
-    auto build_item = [&](int it, double *dst) __attribute__((always_inline)) {
+    auto build_item = [&](int it, bool seg_start, double *dst) __attribute__((always_inline)) {
         const int first = TAIL ? __builtin_amdgcn_readfirstlane(tv.item_first[it]) : it;
         if (TAIL && tv.item_sum[it] != 0) {
             if (COVEST_SKIP_PHASE(plan, 1))
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             const int n = __builtin_amdgcn_readfirstlane(tv.item_ntiles[it]);
             double *colp = dst + (lane_in_row ? tid : 0);
             for (int r = 0; r < n; ++r) {
-                const double gsum = build_tile_sum(first + r, it == t_begin && r == 0);
+                const double gsum = build_tile_sum(first + r, seg_start && r == 0);
                 if (lane_in_row)
                     colp[r * LD] = gsum;
             }
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 if (lane_in_row)
                     colp[r * LD] = 0.0;
         } else {
-            build_tile(first, it == t_begin, dst);
+            build_tile(first, seg_start, dst);
         }
     };
 
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 
     // With two buffers the builders fill item t+1 while every wave contracts item t: one barrier per item, and the
     // host's unit assignment charges the builders for phase A.  ONE loop for both set-ups (and ONE copy of phase A in
-    // the code: three used to be inlined): interval t builds item `tb` and contracts item t.
+    // the code: three used to be inlined): interval p builds the item of position p + 1 and contracts that of position p.
     // (Measured and not kept, round 3: no barrier between the items but two counters per buffer in LDS -- builder waves
     // that have filled it, waves that are done with it -- so that a wave may run an item ahead: 0.846-0.849 against
     // 0.831-0.832 ms; the polling costs more than the hardware barrier's lock step, whose waits are 10 % of the kernel.)
@@ -495,24 +495,41 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 nxt_s = tv.item_scal[at];
         }
     };
-    fetch_rows(t_begin);
-    for (int t = t_begin - (dbuf ? 1 : 0); t < t_end; ++t) {
-        const int tb = dbuf ? t + 1 : t;
-        if (tb < t_end) {
+    // THE LAST KEY TILE FIRST (a plain grid without a tail; round 4).  A weight vector whose sum is -inf -- 44 % of C3's
+    // points -- has met a p_j = 0 at a counted key, and the key where that happens is, with hardly an exception, the
+    // LARGEST one: p_j is a mixture of Poissons whose means stop at (threshold_o - 1) c, so it only underflows beyond
+    // them.  Taken in ascending order a doomed unit is walked, contracted and logged until its columns die near the end;
+    // with the last tile taken first it dies in the first interval and the dead-unit skip (above) leaves out all the
+    // rest.  The order of a point's sums changes by that one term; its value is -inf or finite either way, and the rows
+    // handed back are recorded as a range (min, max).  Position p of the walk is tile tile_at(p); the buffers, rowc and
+    // rows alternate with the POSITION.  The streams are anchored afresh at the first position (the last tile: nothing
+    // is on yet) and at the second (tile 0 is a run start anyway; what they know of the last tile -- `gone` -- is
+    // forgotten there).
+    const bool last_first = PLAIN && !TAIL && t_end - t_begin >= 2;
+    auto tile_at = [&](int p) -> int { return last_first ? (p == t_begin ? t_end - 1 : p - 1) : p; };
+    fetch_rows(tile_at(t_begin));
+    for (int p = t_begin - (dbuf ? 1 : 0); p < t_end; ++p) {
+        const int pb = dbuf ? p + 1 : p;
+        if (pb < t_end) {
             if (tid < kTileBins) { // read after the barrier that makes the item readable
-                rowc[tb & 1][tid] = make_double2(nxt_h, p_clamp * nxt_c);
+                rowc[pb & 1][tid] = make_double2(nxt_h, p_clamp * nxt_c);
                 if (NEED_SCAL)
-                    rows[tb & 1][tid] = nxt_s;
+                    rows[pb & 1][tid] = nxt_s;
             }
-            fetch_rows(tb + 1);
-            if (wave_builds)
-                build_item(tb, Gs + (dbuf ? (tb & 1) * kTileBins * LD : 0));
+            fetch_rows(pb + 1 < t_end ? tile_at(pb + 1) : t_end);
+            if (wave_builds) {
+                if (last_first && pb == t_begin + 1)
+                    st.gone = 0u;
+                build_item(tile_at(pb), pb == t_begin || (last_first && pb == t_begin + 1),
+                           Gs + (dbuf ? (pb & 1) * kTileBins * LD : 0));
+            }
         }
         STAMP(dg_a)
         if (!dbuf)
             __syncthreads();
-        if (t >= t_begin) {
-            const double *cur = Gs + (dbuf ? (t & 1) * kTileBins * LD : 0);
+        if (p >= t_begin) {
+            const int t = tile_at(p); // the tile this interval contracts and logs
+            const double *cur = Gs + (dbuf ? (p & 1) * kTileBins * LD : 0);
             // ================= phase B: P' = G' x b on the matrix pipe =================
             d4 acc[MU];
             const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
@@ -558,23 +575,43 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 const int n4 = nsh[k] >> 2, rem = nsh[k] & 3;
                 // the top `rem` steps (m = n4) are the heads of chains 0 .. rem - 1
                 const double *top = g1 + 4 * (1 + 4 * n4);
-                double h0 = rem > 0 ? top[0] : 0.0, h1 = rem > 1 ? top[4] : 0.0, h2 = rem > 2 ? top[8] : 0.0, h3 = 0.0;
+                // the heads WITHOUT branches: a head that does not exist is read from the zeroed slack behind the buffers
+                // (one select on the address), so that the three loads, the slot's constants above and the first trip's
+                // eight are in flight together -- one LDS round trip at the top of a slot instead of three or four
+                const double *zp = Gs + (size_t)plan.n_buf * kTileBins * LD;
+                double h0 = *(rem > 0 ? top : zp), h1 = *(rem > 1 ? top + 4 : zp), h2 = *(rem > 2 ? top + 8 : zp), h3 = 0.0;
                 {
-                    const double *q = top - 16; // steps 1 + 4 (n4 - 1) .. 4 n4
+                    // The trips' reads are written out as ds_read_b64: left alone the compiler pairs them into
+                    // ds_read2_b64, which the LDS serves at half the rate and with banks counted mod 32 -- rows 8 apart
+                    // collide there (the row stride is 4 dwords mod 64: conflict-free for ds_read_b64 only).  The
+                    // compiler does not count reads it cannot see: the wait is part of the statement.
+                    unsigned qa = (unsigned)(uintptr_t)(top - 32); // LDS byte address of the trip's lowest step
                     int gq = n4;
-                    for (; gq >= 2; gq -= 2, q -= 32) { // eight loads in flight per trip
-                        const double b0 = q[0], b1 = q[4], b2 = q[8], b3 = q[12];
-                        const double c0 = q[-16], c1 = q[-12], c2 = q[-8], c3 = q[-4];
+                    for (; gq >= 2; gq -= 2, qa -= 256) { // eight loads in flight per trip
+                        double b0, b1, b2, b3, c0, c1, c2, c3;
+                        asm volatile("ds_read_b64 %0, %8 offset:128\n\tds_read_b64 %1, %8 offset:160\n\t"
+                                     "ds_read_b64 %2, %8 offset:192\n\tds_read_b64 %3, %8 offset:224\n\t"
+                                     "ds_read_b64 %4, %8\n\tds_read_b64 %5, %8 offset:32\n\t"
+                                     "ds_read_b64 %6, %8 offset:64\n\tds_read_b64 %7, %8 offset:96\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+                                     : "v"(qa));
                         h0 = fma(fma(h0, rr16, b0), rr16, c0);
                         h1 = fma(fma(h1, rr16, b1), rr16, c1);
                         h2 = fma(fma(h2, rr16, b2), rr16, c2);
                         h3 = fma(fma(h3, rr16, b3), rr16, c3);
                     }
                     if (gq > 0) {
-                        h0 = fma(h0, rr16, q[0]);
-                        h1 = fma(h1, rr16, q[4]);
-                        h2 = fma(h2, rr16, q[8]);
-                        h3 = fma(h3, rr16, q[12]);
+                        double b0, b1, b2, b3;
+                        asm volatile("ds_read_b64 %0, %4 offset:128\n\tds_read_b64 %1, %4 offset:160\n\t"
+                                     "ds_read_b64 %2, %4 offset:192\n\tds_read_b64 %3, %4 offset:224\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+                                     : "v"(qa));
+                        h0 = fma(h0, rr16, b0);
+                        h1 = fma(h1, rr16, b1);
+                        h2 = fma(h2, rr16, b2);
+                        h3 = fma(h3, rr16, b3);
                     }
                 }
                 const double hs = fma(fma(fma(h3, rr4, h2), rr4, h1), rr4, h0);
@@ -625,7 +662,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             plan.partial[(ce * tv.n_items + t) * kTileBins + 16 * uhalf[k] + kq + 4 * r] = // (x 2^128: kShareScale)
-                                acc[k][r] * (rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0] * kShareScale);
+                                acc[k][r] * (rows[NEED_SCAL ? (p & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0] * kShareScale);
                     }
                     continue;
                 }
@@ -637,7 +674,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                                       16 * uhalf[k] + kq;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const double share = acc[k][r] * (rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0] * kShareScale);
+                            const double share = acc[k][r] * (rows[NEED_SCAL ? (p & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq + 4 * r : 0] * kShareScale);
                             row[4 * r] = plan.o_base == 0 ? share : row[4 * r] + share;
                         }
                     }
@@ -658,7 +695,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     // the row's own units (0 for a row without a count: filler keys, a tile's padding, zero counts
                     // with a tail -- never "low"), made BEFORE the logs, and sorted out in a branch the wave takes
                     // for one unit in twenty.  Rows without a count add 0 * log below.
-                    const double2 *rc = &rowc[t & 1][16 * uhalf[k] + kq]; // {h, clamp} of this lane's rows kq, kq + 4, ...
+                    const double2 *rc = &rowc[p & 1][16 * uhalf[k] + kq]; // {h, clamp} of this lane's rows kq, kq + 4, ...
                     double h4[4], c4[4], x4[4], lg4[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -667,7 +704,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                         c4[r] = hc.y;
                     }
                     if (TAIL) { // sp_j needs p_j itself (filler and padding keys: scale 0), before the clamp
-                        const double *sr = &rows[NEED_SCAL ? (t & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq : 0];
+                        const double *sr = &rows[NEED_SCAL ? (p & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq : 0];
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             spacc[k].add(acc[k][r] * sr[NEED_SCAL ? 4 * r : 0]);

@@ -111,7 +111,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     // while the contraction sees one item -- charge them for the tiles an item holds on average)
     if (m->has_tiles && m->tv.n_items > 0)
         build_cost = (int)std::lround((double)kBuildCost * (double)m->tv.n_tiles / (double)m->tv.n_items);
-#ifdef COVEST_DIAG
+#if defined(COVEST_DIAG) || defined(COVEST_TUNE)
     if (const char *v = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD"))
         unit_overhead = std::atoi(v);
     if (const char *v = std::getenv("COVEST_FACTORED_BUILD_COST"))
@@ -414,7 +414,7 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
         share = share && std::atoi(share_env) != 0;
 #endif
     int min_shared = kMinSharedSteps;
-#ifdef COVEST_DIAG
+#if defined(COVEST_DIAG) || defined(COVEST_TUNE)
     if (const char *v = std::getenv("COVEST_FACTORED_MIN_SHARED"))
         min_shared = std::atoi(v);
 #endif
