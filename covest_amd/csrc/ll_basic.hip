@@ -56,6 +56,34 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
 
     double lam[S];
     error_class_rates<S>(m, par[0], par[1], lam); // (by multiplication: point_fetch.h)
+    // DOOMED WAVES LEAVE HERE (round 4).  A point whose sum is -inf -- 44 % of C2 -- has p_j = 0 at a counted key, and
+    // the key where that is decided first is the LAST counted one.  p_j = 0 in the reference iff every class's term is
+    // flushed by the extension's cast to double (c_src/covest_poissonmodule.c:32: below 2^-1075 = e^-745.13).  The
+    // classes' rates fall with s for e < 3/4 (covest/models.py:76-79: x_{s+1} / x_s = e / (3 (1 - e))), and for
+    // x <= j - 1 the truncated pmf x^j / (j! (e^x - 1)) grows with x, so every class's term at the last counted key j is
+    // at most the error-free class's, which is at most 1.59 times the plain Poisson term (x >= 1), times what the
+    // 200-chunk normaliser can add (point_fetch.h log_trunc_norm: at most 1 / (1 - e^-1e-8) = 1e8).  So
+    //     j ln x_0 - x_0 - ln j!  <  -745.13 - ln 1.59 - ln 1e8 - 1.5  =  -765.5
+    // is SUFFICIENT for -inf (safe_log, covest/utils.py; a tail term is finite or 0); points between that and the exact
+    // decision take the ordinary route below.  A wave whose lanes are all doomed (or NaN) writes its values and ends
+    // before the mixture weights, the anchors and the tiles that are walked with all streams: neighbouring points of a
+    // grid are doomed together.
+    {
+        const double jl = tv.last_key[0], x0 = lam[0];
+        bool sure = false;
+        if (jl > 0.0) // (wave-uniform: the histogram has a counted key)
+            sure = finite && par[1] < 0.75 && x0 >= 1.0 && x0 <= jl - 1.0 &&
+                   fma(jl, fast_log(x0, log_tab), -(x0 + tv.last_key[1])) < -765.5;
+        bool leave = !__any(finite && !sure);
+#ifdef COVEST_DIAG
+        leave = leave && sub_list.diag_class == 0; // (tools/dump_c2_classes.py wants every point's route)
+#endif
+        if (leave) { // wave-uniform
+            if (live)
+                out_ll[pt] = finite ? -INFINITY : NAN;
+            return;
+        }
+    }
     extern __shared__ double anchors[]; // [2S][lane of the workgroup]: conflict-free columns
     StreamSet<S, LdsAnchors<S>> st;
     st.an.mine = anchors + threadIdx.x;
