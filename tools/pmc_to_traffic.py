@@ -9,7 +9,7 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 want = {"c3": ("ll_factored", "ll_factored_kernel<512,3,false,true>"), "c2": ("ll_basic", "ll_basic_kernel<false>")}
 out = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 and executed fp64 flops per launch from separate "
                 "rocprofv3 --pmc passes (tools/pmc_profile.sh, profiles/%s_c{3,2}_pmc_summary.json; tools/pmc_to_traffic.py); "
@@ -18,7 +18,9 @@ out = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 and exe
                 "scratch of spilled registers" % tag}
 for w, (short, full) in want.items():
     with open(os.path.join(REPO, "profiles", "%s_%s_pmc_summary.json" % (tag, w))) as f:
-        d = json.load(f)[full]
+        summary = json.load(f)
+    # (the headline shape of K-factored is compiled with its row stride as a fifth template argument since round 4)
+    d = summary.get(full) or next(v for k, v in summary.items() if k.startswith(full[:-1] + ","))
     flops = 64.0 * (2.0 * d["SQ_INSTS_VALU_FMA_F64"] + d["SQ_INSTS_VALU_MUL_F64"] + d["SQ_INSTS_VALU_ADD_F64"]) \
         + 2048.0 * d.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / 4.0
     out[w] = {short: int(round((2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0)),
