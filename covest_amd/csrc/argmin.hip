@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "direct_point.h"
+#include "fastmath.h"
 #include "kernels.h"
 #include "wave.h"
 
@@ -113,6 +114,15 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int wave = wave_in_block % NW; // among the waves of its point
     const unsigned count = __builtin_amdgcn_readfirstlane(*list.count);
+    if (count == 0)
+        return; // (workgroup-uniform) the common case: a launch and one load
+    // (round 4) the preparation of a lot -- ln x, the normaliser's two logs, the copy number's weight -- was most of this
+    // kernel: the device library's log (72 issue slots) three times and its pow (210) once per component.  The logs go
+    // through the fast_log table (absolute error 2e-16, what the recurrence kernels' anchors are made with), the weight
+    // by squaring.
+    __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
+    load_log_table(log_tab);
+    __syncthreads();
     const int S = m.n_err;
     const int OT = kWave / S; // copy numbers prepared per lot of 64 components
     const int s = lane % S;
@@ -174,11 +184,11 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
                     if (tot == 0.0)
                         tot = 1.0;
                     double a_os = n_os / tot;
-                    const double b_o = (P == 5) ? copy_number_weight(par[2], par[3], par[4], o) : 1.0;
+                    const double b_o = (P == 5) ? copy_number_weight_by_squaring(par[2], par[3], par[4], o) : 1.0;
                     double lx = 0.0, nd = -INFINITY;
                     if (live && x > 0.0) {
-                        lx = log(x);
-                        nd = -log_trunc_norm(x, lx);
+                        lx = fast_log(x, log_tab);
+                        nd = -log_trunc_norm(x, lx, log_tab);
                     }
                     if (!live)
                         a_os = 0.0;
@@ -286,6 +296,7 @@ __global__ __launch_bounds__(256) void argmin_small(const double *__restrict__ l
         publish(c, flat_begin, result, host_mirror);
 }
 
+
 } // namespace
 
 hipError_t launch_ll_fix_list(const DevModel &m, const TileView &tv, const PointSource &src, double *ll,
@@ -311,6 +322,9 @@ hipError_t launch_argmin(const double *ll, int64_t n, int64_t flat_begin, double
     }
     // (a small grid needs no more workgroups than it has waves of points)
     const int blocks = (int)std::min<int64_t>(kArgminBlocks, std::max<int64_t>(1, (n + 255) / 256));
+    // (measured and not kept, round 4: both stages in ONE launch -- every workgroup stores its candidate, adds to a
+    // counter behind a fence, the workgroup whose add came last reduces the candidates -- is 20-27 us SLOWER a step than
+    // the second launch it saves: 1 024 agent-scope fences cost more than a 4 us launch)
     hipLaunchKernelGGL(argmin_stage1, dim3(blocks), dim3(256), 0, stream, ll, n, partial_val, partial_idx);
     hipLaunchKernelGGL(argmin_stage2, dim3(1), dim3(256), 0, stream, partial_val, partial_idx, blocks, flat_begin, result,
                        host_mirror, queue_count);
