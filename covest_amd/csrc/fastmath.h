@@ -35,6 +35,16 @@ __device__ __forceinline__ double fma_vvs(double a, double b, double c)
     return d;
 }
 
+// d = a * b + c as the three-address instruction with every operand in vector registers: where d is a LOOP-CARRIED value
+// and c a freshly loaded one the compiler takes v_fmac_f64 into c's register and copies the result back (a v_mov_b64, one
+// full-rate slot, per Horner step of K-factored's shared steps).
+__device__ __forceinline__ double fma_vvv(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // log(x) for finite x > 0 (subnormals included).  NaN propagates.  x == 0 gives a finite
 // value (callers handle p_j <= 0 themselves).
 __device__ __forceinline__ double fast_log(double x, const double *tab_lds)

@@ -301,13 +301,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     load_weights();
     // A NaN among (q1, q2, q) makes every b_o from the third on a NaN (covest/models.py:193-208; its threshold_o is
     // max(hist)), and the reference's likelihood with it.  The logs below work on the bits and would turn it into
-    // a finite number: the columns concerned are found here, once, from the weights themselves.
-    uint64_t nan_cols[MU];
-#pragma unroll
-    for (int k = 0; k < MU; ++k) {
-        const uint64_t nm = __ballot(wfirst[k] != wfirst[k] || wrun[k] != wrun[k]);
-        nan_cols[k] = ((nm | (nm >> 16) | (nm >> 32) | (nm >> 48)) & 0xFFFFull) * 0x0001000100010001ull;
-    }
+    // a finite number: the columns concerned are found from the weights themselves -- AFTER the walk (round 4: found
+    // here and kept, the six masks held twelve scalar registers through the whole kernel, which spills them).
 
     // ================= phase A: G'[key][o] of key tile t into `dst` =================
     // in-kernel stamps (diagnostic builds only): cycles per wave in build / contract / log / barrier
@@ -596,10 +591,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                                      "s_waitcnt lgkmcnt(0)"
                                      : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
                                      : "v"(qa));
-                        h0 = fma(fma(h0, rr16, b0), rr16, c0);
-                        h1 = fma(fma(h1, rr16, b1), rr16, c1);
-                        h2 = fma(fma(h2, rr16, b2), rr16, c2);
-                        h3 = fma(fma(h3, rr16, b3), rr16, c3);
+                        h0 = fma_vvv(fma(h0, rr16, b0), rr16, c0); // (three-address: no copy back into the chain's register)
+                        h1 = fma_vvv(fma(h1, rr16, b1), rr16, c1);
+                        h2 = fma_vvv(fma(h2, rr16, b2), rr16, c2);
+                        h3 = fma_vvv(fma(h3, rr16, b3), rr16, c3);
                     }
                     if (gq > 0) {
                         double b0, b1, b2, b3;
@@ -608,10 +603,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                                      "s_waitcnt lgkmcnt(0)"
                                      : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
                                      : "v"(qa));
-                        h0 = fma(h0, rr16, b0);
-                        h1 = fma(h1, rr16, b1);
-                        h2 = fma(h2, rr16, b2);
-                        h3 = fma(h3, rr16, b3);
+                        h0 = fma_vvv(h0, rr16, b0);
+                        h1 = fma_vvv(h1, rr16, b1);
+                        h2 = fma_vvv(h2, rr16, b2);
+                        h3 = fma_vvv(h3, rr16, b3);
                     }
                 }
                 const double hs = fma(fma(fma(h3, rr4, h2), rr4, h1), rr4, h0);
@@ -810,10 +805,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     double *part_ll = Gs;                               // [NW][MU][16]
     double *part_hi = Gs + (size_t)NW * MU * 16; // compensated sp_j parts
     double *part_lo = part_hi + (size_t)NW * MU * 16;
+    load_weights(); // (the slots' first weights once more: a NaN column is a NaN in them)
 #pragma unroll
     for (int k = 0; k < MU; ++k) {
         double ll = llacc[k];
-        if ((nan_cols[k] >> lane) & 1)
+        const uint64_t nm = __ballot(wfirst[k] != wfirst[k] || wrun[k] != wrun[k]);
+        const uint64_t nan_cols_k = ((nm | (nm >> 16) | (nm >> 32) | (nm >> 48)) & 0xFFFFull) * 0x0001000100010001ull;
+        if ((nan_cols_k >> lane) & 1)
             ll = NAN; // a NaN weight vector: math.log(nan), covest/models.py:105
         if ((dead[k] >> lane) & 1)
             ll = isnan(ll) ? ll : -INFINITY; // h * -inf summed with finite terms
