@@ -235,6 +235,102 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
     }
 }
 
+// The same hand-back for the BASIC model, several points a wave (round 4).  A basic-model point has ONE copy number: its
+// S mixture components are prepared by S lanes, and ll_fix_list_kernel<2, 1> above left the other 64 - S idle through
+// the whole preparation (exp_neg_rn, a division, three logs) and then used a dozen of its 64 lanes for the point's
+// dozen rows -- 1 900 instructions a point, 28 us of C2's 238 us step.  Here a wave takes G = 64 / S queued points at
+// once: lane (g, s) prepares component s of point g, then stands for row s of a pass of S rows of point g, the
+// components reaching it through the lanes' crossbar (the group's own, in ascending s).  The arithmetic of a row is the
+// one above to the letter -- the terms a_s exp(key ln x_s - D_s - ln key!) added in ascending s (a component that is out
+// of reach adds an exact 0: the kernel above skips it, which is the same), b_o = 1, the contributions of a point's rows
+// in ascending order.
+__global__ __launch_bounds__(256) void ll_fix_basic_packed_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
+                                                                  const double *__restrict__ tile_dbl,
+                                                                  const int32_t *__restrict__ tile_int, const PointSource src,
+                                                                  double *__restrict__ ll, const SubList list)
+{
+    const unsigned count = __builtin_amdgcn_readfirstlane(*list.count);
+    if (count == 0)
+        return; // (workgroup-uniform) the common case: a launch and one load
+    __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
+    load_log_table(log_tab);
+    __syncthreads();
+    const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int S = m.n_err;            // 8, 16, 24 or 32 (padded: comb = 0 beyond the model's classes)
+    const int G = kWave / S;          // points a wave takes at once
+    const int g = lane / S, s = lane - g * S;
+    const bool in_group = g < G;
+    const int first_lane = (in_group ? g : 0) * S; // the group's lane 0 (idle lanes shadow group 0 and store nothing)
+    const double comb_s = m.comb[s];
+    const int64_t n_rows_table = (int64_t)tv.n_tiles * kTileBins;
+    const unsigned wave_global = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const unsigned n_waves = gridDim.x * (blockDim.x / kWave);
+    for (unsigned base = wave_global * (unsigned)G; base < count; base += n_waves * (unsigned)G) { // wave-uniform
+        const unsigned at = base + (unsigned)(in_group ? g : 0);
+        const bool have = in_group && at < count;
+        const int64_t pt = list.index[have ? at : base];
+        const unsigned long long word = have ? list.word[at] : 0ull;
+        double par[kMaxParams];
+        int T;
+        fetch_point<2>(src, pt, par, T);
+        clamp_point<2>(m, par);
+        const bool units16 = sub_units16(word);
+        const int64_t row_first = units16 ? (int64_t)sub_first(word) * 16 : (int64_t)sub_first(word);
+        const int64_t row_last = units16 ? (int64_t)sub_last(word) * 16 + 15 : (int64_t)sub_last(word);
+        // ---- component s of point g: covest/models.py:85-90, as K-direct prepares it (direct_point.h) ----
+        const double x = error_class_rate(m, par[0], par[1], s); // o = 1
+        const bool live = have && T > 1;
+        const double n_os = comb_s * (1.0 - exp_neg_rn(x));
+        double tot = 0.0;
+        for (int t = 0; t < S; ++t) // naive sum in s order
+            tot += __shfl(n_os, first_lane + t, kWave);
+        if (tot == 0.0)
+            tot = 1.0;
+        double a_s = n_os / tot;
+        double lx = 0.0, nd = -INFINITY;
+        if (live && x > 0.0) {
+            lx = fast_log(x, log_tab);
+            nd = -log_trunc_norm(x, lx, log_tab);
+        }
+        if (!live)
+            a_s = 0.0;
+        double value = have ? ll[pt] : 0.0;
+        // ---- the point's rows, S at a time ----
+        const int64_t my_rows = have ? row_last - row_first + 1 : 0;
+        int64_t most = my_rows;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            most = max(most, __shfl_xor(most, off, kWave)); // wave-uniform trip count
+        for (int64_t r0 = 0; r0 < most; r0 += S) {
+            const int64_t row = row_first + r0 + s;
+            const int bin = (have && row <= row_last && row < n_rows_table) ? tv.row_bin[row] : -1;
+            const double h = bin >= 0 ? m.bins.cnt[bin] : 0.0;
+            const bool counted = bin >= 0 && h != 0.0;
+            const double key = counted ? m.bins.key[bin] : 0.0;
+            const double nlg = counted ? -m.bins.lgam[bin] : 0.0;
+            double pj = 0.0;
+            for (int t = 0; t < S; ++t) { // error classes, ascending
+                const double a_t = __shfl(a_s, first_lane + t, kWave);
+                const double lx_t = __shfl(lx, first_lane + t, kWave);
+                const double nd_t = __shfl(nd, first_lane + t, kWave);
+                const double term = a_t * exp(fma(key, lx_t, nd_t + nlg));
+                pj += (a_t != 0.0) ? term : 0.0; // (a component without weight is left out above: it adds nothing here)
+            }
+            const bool fix = counted && pj < list.p_clamp;
+            const double contrib = fix ? h * ((pj <= 0.0 ? -INFINITY : log(pj)) - list.log_p_clamp) : 0.0;
+            for (int t = 0; t < S; ++t) { // ascending rows of the group's point
+                const double c_t = __shfl(contrib, first_lane + t, kWave);
+                const bool f_t = __shfl((int)fix, first_lane + t, kWave) != 0;
+                if (f_t)
+                    value += c_t;
+            }
+        }
+        if (have && s == 0)
+            ll[pt] = value;
+    }
+}
+
 // The winner where it is wanted: in HBM (the ranks' exchange reads it there) and, when the caller gave one, in a
 // page-locked HOST mirror -- the kernel's own store, visible once the stream is synchronised: no copy launch and no
 // staging for 16 bytes.
@@ -304,7 +400,10 @@ hipError_t launch_ll_fix_list(const DevModel &m, const TileView &tv, const Point
 {
     // enough workgroups to spread a few thousand queued points over the chip; an empty queue is the common case
     const dim3 grid(2048), block(256);
-    if (m.kind == 0)
+    if (m.kind == 0 && m.n_err <= 32)
+        hipLaunchKernelGGL(ll_fix_basic_packed_kernel, dim3(512), block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+                           tv.int_base, src, ll, list);
+    else if (m.kind == 0)
         hipLaunchKernelGGL((ll_fix_list_kernel<2, 1>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
                            tv.int_base, src, ll, list);
     else
