@@ -834,6 +834,99 @@ def test_subnormal_pj_goes_to_the_strict_kernel(hip_lib, oracle):
     print("subnormal p_j: %d basic points, >= %d repeats points re-evaluated by the strict kernel" % (sum(sub), n_sub))
 
 
+def test_round4_shortcuts_on_awkward_shapes(hip_lib, oracle):
+    """The work the round-4 kernels leave OUT must never change a value.  K-factored takes the LAST key tile first (a
+    unit whose weight vectors all end at -inf dies in the first interval, ll_factored.hip `last_first`); K-basic lets a
+    wave whose points are all -inf by a sufficient bound at the last counted key leave before its prologue
+    (ll_basic.hip); the strict kernel of the basic model takes 64 / S points a wave (argmin.hip).  Histograms chosen
+    for what those shortcuts could trip over -- one partial tile, a full and a partial one, a gap between two runs with
+    the last tile a run of its own, a lone far key that dooms most of the grid, a subnormal key with 8, 16 and 24 error
+    classes -- each on a grid that holds finite points, -inf points and the border between them: the recurrence kernel
+    against K-direct (term by term, itself pinned to the reference by the fixtures) at 1e-11 with IEEE specials in the
+    same places and the same arg-min, and against the oracle at 1e-9 on a sample."""
+    from covest_amd import BasicModel, DenseGrid, RepeatsModel
+
+    def falling(keys, top):
+        return {int(j): max(1, int(top * math.exp(-0.07 * i))) for i, j in enumerate(keys)}
+
+    hists = {
+        "one partial tile": falling(range(1, 21), 5000),
+        "a full and a partial tile": falling(range(1, 46), 20000),
+        "two runs": {**falling(range(1, 41), 9000), **{j: 3 + (j % 4) for j in range(300, 331)}},
+        "a far key": {**falling(range(1, 101), 50000), 2000: 3},
+    }
+    rng = np.random.default_rng(5)
+    for name, hist in hists.items():
+        top = max(hist)
+        # ---- repeats model: K-factored against K-direct on the whole grid
+        rm = RepeatsModel(21, 100, hist, 0, max_error=8)
+        orm = oracle.OracleModel("repeats", 21, 100, hist, 0, max_error=8)
+        axes = [np.exp(np.linspace(np.log(0.4), np.log(max(4.0, 0.9 * top)), 14)), [0.004, 0.03, 0.2],
+                np.linspace(0.35, 0.95, 4), [0.5], [0.05, 0.3, 0.6, 0.95]]
+        grid = DenseGrid(rm, axes)
+        grid.evaluate(kernel="factored")
+        assert grid.work()[2] == "ll_factored"
+        fast, best = grid.loglikelihoods(), grid.argmin()
+        grid.evaluate(kernel="direct")
+        ref = grid.loglikelihoods()
+        assert np.array_equal(np.isneginf(fast), np.isneginf(ref)) and np.array_equal(np.isnan(fast), np.isnan(ref)), name
+        fin = np.isfinite(ref)
+        assert fin.any(), name
+        if name in ("two runs", "a far key"):
+            assert (~fin).any(), name  # the grid does hold doomed points
+        err = np.abs(fast[fin] - ref[fin]) / np.abs(ref[fin])
+        assert float(err.max()) <= 1e-11, (name, float(err.max()), int(np.flatnonzero(fin)[int(err.argmax())]))
+        assert grid.argmin()[1] == best[1], name
+        some = rng.choice(grid.total, size=24, replace=False)
+        pts = np.array([grid.point(int(i)) for i in some])
+        _check(fast[some], orm.compute_loglikelihood_many(pts, n_threads=16), "round-4 shapes, repeats, " + name)
+        grid.close()
+        rm.close()
+        # ---- basic model, 8 / 16 / 24 error classes: K-basic (+ the packed strict kernel) against K-direct
+        for max_error in (8, 16, 24):
+            m = BasicModel(21, 100, hist, 0, max_error=max_error)
+            cs = np.exp(np.linspace(np.log(0.3), np.log(3.0 * top), 640))
+            g = DenseGrid(m, [cs, [0.002, 0.05, 0.3, 0.5]])
+            g.evaluate(kernel="recur")
+            assert g.work()[2] == "ll_basic"
+            fast, best = g.loglikelihoods(), g.argmin()
+            g.evaluate(kernel="direct")
+            ref = g.loglikelihoods()
+            assert np.array_equal(np.isneginf(fast), np.isneginf(ref)) and np.array_equal(np.isnan(fast), np.isnan(ref)), (name, max_error)
+            fin = np.isfinite(ref)
+            assert fin.any() and ((~fin).any() or name == "one partial tile"), (name, max_error)
+            err = np.abs(fast[fin] - ref[fin]) / np.abs(ref[fin])
+            assert float(err.max()) <= 1e-11, (name, max_error, float(err.max()))
+            assert g.argmin()[1] == best[1], (name, max_error)
+            if max_error == 8:
+                om = oracle.OracleModel("basic", 21, 100, hist, 0, max_error=8)
+                some = rng.choice(g.total, size=48, replace=False)
+                pts = np.array([g.point(int(i)) for i in some])
+                _check(fast[some], om.compute_loglikelihood_many(pts, n_threads=16), "round-4 shapes, basic, " + name)
+            g.close()
+            m.close()
+    # the strict kernel of the basic model with several points a wave: a key with a SUBNORMAL p_j (as in
+    # test_subnormal_pj_goes_to_the_strict_kernel) under 8, 16 and 24 error classes, list and grid
+    hist = {1: 1000, 2: 500, 150: 6000, 151: 40, 153: 7}
+    cs = np.linspace(0.50, 0.85, 141)
+    for max_error in (8, 16, 24):
+        m = BasicModel(21, 100, hist, 0, max_error=max_error)
+        g = DenseGrid(m, [cs, [0.01, 0.02]])
+        g.evaluate(kernel="recur")
+        fast = g.loglikelihoods()
+        g.evaluate(kernel="direct")
+        ref = g.loglikelihoods()
+        assert np.array_equal(np.isneginf(fast), np.isneginf(ref))
+        fin = np.isfinite(ref)
+        assert 20 <= int(fin.sum()) < g.total
+        err = np.abs(fast[fin] - ref[fin]) / np.abs(ref[fin])
+        assert float(err.max()) <= 1e-11, (max_error, float(err.max()))
+        pts = np.array([g.point(i) for i in range(g.total)])
+        _check(m.loglikelihood_points(pts, kernel="recur"), ref, "packed strict kernel, list, max_error %d" % max_error, tol=1e-11)
+        g.close()
+        m.close()
+
+
 def test_estimator_fix_and_err_scale_on_gpu(hip_lib, oracle):
     """CoverageEstimator.likelihood_f (covest/covest.py:26-31) with `fix` and `err_scale != 1` -- the "4-D grid =
     q2 fixed" case of SURVEY discrepancy 1 -- on the GPU: the scalar objective, its batched form negll_grid, and
