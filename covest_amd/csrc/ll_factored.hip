@@ -567,7 +567,13 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 const double2 rt = *reinterpret_cast<const double2 *>(&rho_tab[4 * (wave * MU + k) + 2]);
                 const double rr4 = rt.x, rho_n = rt.y;
                 const double *g1 = cur + a_off0[k]; // step 0 of the unit (o = 1 .. 4); step i at g1[4 i]
-                const int n4 = nsh[k] >> 2, rem = nsh[k] & 3;
+                // (the empty asm: what derives from the slot's step count -- the trip count, the three "is there a head"
+                // masks -- is made afresh per tile, five scalar instructions, instead of being held across the walk: the
+                // compiler hoisted all of it out of the tile loop, 40 scalar registers that it then spilled to vector
+                // lanes and fetched back with v_readlane, a VECTOR instruction, every tile)
+                int nsh_k = nsh[k];
+                asm volatile("" : "+s"(nsh_k));
+                const int n4 = nsh_k >> 2, rem = nsh_k & 3;
                 // the top `rem` steps (m = n4) are the heads of chains 0 .. rem - 1
                 const double *top = g1 + 4 * (1 + 4 * n4);
                 // the heads WITHOUT branches: a head that does not exist is read from the zeroed slack behind the buffers
@@ -620,7 +626,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                                // instead of 6 registers held through the other phases)
 #pragma unroll
                 for (int k = 0; k < MU; ++k)
-                    a_off[k] = a_off0[k] + 4 * nsh[k];
+                {
+                    int nsh_k = nsh[k];
+                    asm volatile("" : "+s"(nsh_k));
+                    a_off[k] = a_off0[k] + 4 * nsh_k;
+                }
                 // (measured and not kept, round 4: one address register a slot with the buffer's base folded in and two
                 // steps a trip, the second fragment an immediate offset away -- the compiler moves the induction to the
                 // scalar unit, six s_add a trip: 0.867-0.871 against 0.855-0.858 ms)
