@@ -208,6 +208,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
     __syncthreads();
     StreamSet<8> st;
+    // (measured and not kept, round 4: the prologue by ALL the waves -- the 8 max_o (copy number, class) pairs dealt to
+    // the 512 lanes, n_os / ln x / the normaliser of each made once into the G area, the copy number's lane adding,
+    // dividing and taking ln a_os: 30 KB less code and, by the in-kernel stamps, a third off the 23 k ticks the three
+    // waves that build nothing wait at the first barrier -- 0.704 against 0.702 ms: no gain)
     if (wave_builds) { // (wave-uniform) the waves that build nothing skip the mixture weights' exps, divisions and logs
         st.init(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab, log_tab, 8 * my_pass,
                 n_total);
@@ -792,10 +796,20 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             STAMP(dg_c)
         }
         __syncthreads(); // the tile just contracted may be overwritten, the one just built may be read
+#ifdef COVEST_DIAG
+        if (diag && (plan.skip_phases & 0x10000)) { // (COVEST_FACTORED_DIAG=2) the wait at the barrier by eighths of the walk
+            const long long now__ = (long long)clock64();
+            if (lane == 0) {
+                const int grp = (plan.skip_phases & 0x20000) ? min(7, p - t_begin + 1) // (=3: the first seven intervals one by one)
+                                                              : min(7, (p - t_begin + 1) * 8 / (t_end - t_begin + 1));
+                plan.diag[((int64_t)(blockIdx.x * gridDim.y + blockIdx.y) * NW + wave) * 8 + grp] += now__ - dg_t0;
+            }
+        }
+#endif
         STAMP(dg_w)
     }
 
-    if (diag && lane == 0) {
+    if (diag && lane == 0 && !(plan.skip_phases & 0x10000)) {
         long long *d = plan.diag + ((int64_t)(blockIdx.x * gridDim.y + blockIdx.y) * NW + wave) * 8;
         d[0] = dg_a;
         d[1] = dg_b;

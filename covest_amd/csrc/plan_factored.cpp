@@ -364,6 +364,10 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
             const size_t bytes = (size_t)(pl.ce_end - pl.ce_begin) * n_qblocks * nw * 8 * sizeof(long long);
             if (hipMalloc(&dp, bytes) == hipSuccess && hipMemset(dp, 0, bytes) == hipSuccess) {
                 pl.diag = static_cast<long long *>(dp);
+                if (std::atoi(std::getenv("COVEST_FACTORED_DIAG")) >= 2)
+                    pl.skip_phases |= 0x10000; // the barrier waits by eighths of the walk instead of the phase sums
+                if (std::atoi(std::getenv("COVEST_FACTORED_DIAG")) == 3)
+                    pl.skip_phases |= 0x20000; // ... of the first seven intervals one by one, the rest in the eighth
                 std::fprintf(stderr, "COVEST_FACTORED_DIAG %p %zu\n", dp, bytes);
             }
         }
