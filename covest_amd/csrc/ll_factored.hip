@@ -210,8 +210,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     StreamSet<8> st;
     // (measured and not kept, round 4: the prologue by ALL the waves -- the 8 max_o (copy number, class) pairs dealt to
     // the 512 lanes, n_os / ln x / the normaliser of each made once into the G area, the copy number's lane adding,
-    // dividing and taking ln a_os: 30 KB less code and, by the in-kernel stamps, a third off the 23 k ticks the three
-    // waves that build nothing wait at the first barrier -- 0.704 against 0.702 ms: no gain)
+    // dividing and taking ln a_os: 30 KB less code, the same bits -- 0.705 against 0.702 ms: no gain, although the three
+    // waves that build nothing wait 23 k ticks at the first barrier by the stamps of the diagnostic build)
     if (wave_builds) { // (wave-uniform) the waves that build nothing skip the mixture weights' exps, divisions and logs
         st.init(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab, log_tab, 8 * my_pass,
                 n_total);
