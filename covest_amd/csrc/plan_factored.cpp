@@ -104,7 +104,8 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     // cost model of the assignment, in MFMA steps: a unit costs its steps (in every pass) plus its share of the
     // logs; a builder wave starts with the cost of phase A (tuned on C3 with the in-kernel stamps)
     // (the assignment fixes the order of a point's sums: the shipped library takes the constants of tiles.h, only a
-    // diagnostic build -- tiles.h -- lets the environment override them for tuning sweeps)
+    // diagnostic build -- tiles.h -- or a TUNING build of this file alone, -DCOVEST_TUNE linked against the shipped
+    // kernels (tools/build_tune.sh, profiles/r04_c3_factored_lpt_sweep_*.txt), lets the environment override them)
     int unit_overhead = kUnitOverhead, build_cost = kBuildCost, shared_div = kSharedStepsPerMfma;
     int last_builder_extra = kLastBuilderExtra;
     // (with a tail an item may stand for up to 32 count-less tiles, tiles.h: the builders walk every one of them
