@@ -791,9 +791,30 @@ def main():
 
     # W untimed warm-up steps as asked, preceded by a fixed spin-up that is not counted either: the device
     # needs a few milliseconds of work before its clocks settle (at --warmup 1 the first timed steps ran 13 %
-    # slower than steady state)
+    # slower than steady state).  The timed steps follow the warm-up DIRECTLY.
     for _ in range(int(os.environ.get("COVEST_BENCH_SPINUP", "25")) + args.warmup):
         step()
+    grid.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gmin, gidx = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, launches = grid.kernel_ms()
+    grid.profile(False)
+    terms, flops, kernel_name = grid.work()
+    # (measured AFTER the timed region since round 4: between the warm-up and the timed steps its ten searches, with
+    # their host-side gaps, let the device's clocks sag, and the 20 timed steps then ran 3-5 % under the sustained rate
+    # -- profiles/r04_clock_ramp.txt: 0.718 ms a step for the first 20 steps from idle, 0.685 from 14 ms on)
     # warm time-to-argmin (library and context warm; model + grid handles re-created): host axes + histogram ->
     # global (min, index) on the host.  Twice: the histogram handed over as the reference's dict {j: count}
     # (covest/models.py:26 -- walking a 10 000-key dict costs 0.3 ms of host time) and as (keys, counts) arrays,
@@ -828,24 +849,6 @@ def main():
     time_to_argmin_split = runs_arr[2][1]
     time_to_argmin_warm_dict = runs_dict[2][0]
 
-    grid.profile(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gmin, gidx = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms, launches = grid.kernel_ms()
-    grid.profile(False)
-    terms, flops, kernel_name = grid.work()
     # N > 1: every rank's likelihood-kernel time (imbalance of the partition) and the price of the exchange alone
     per_rank_kernel_ms, exchange_us = None, None
     if world > 1:
