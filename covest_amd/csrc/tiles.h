@@ -117,7 +117,7 @@ constexpr int kHalfUnits = 3;      // (kept for the 256-thread capacity rule: 4 
 constexpr int kBuildCost = 18;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3; 36 before round 3 took the scales and the scalar-load stalls out of phase A)
 constexpr int kListSegments = 8;   // key segments of a point-list evaluation (list mode): latency of ONE point
 constexpr int kMinPieceSteps = 6;  // pieces are not made shorter than this
-constexpr int kSharedStepsPerMfma = 5; // cost of the shared steps in the assignment: this many weigh one MFMA step
+constexpr int kSharedStepsPerMfma = 4; // cost of the shared steps in the assignment: this many weigh one MFMA step (5 until the fine sweep at the end of round 4: -0.7 %)
 constexpr int kMinSharedSteps = 3; // fewer shared steps than this are left to the MFMA steps
 constexpr int kLastBuilderExtra = 4; // extra charge of the builder of the top copy numbers when it shares a SIMD with another builder
 constexpr int kUnitOverhead = 2;   // per-unit cost besides its MFMA steps (logs, setup), same unit
