@@ -490,7 +490,8 @@ def tail_variant(cls, axes, args, device, stream):
         grid.evaluate(kernel=args.kernel, stream=stream)
         return grid.argmin()
 
-    for _ in range(5 + args.warmup):
+    # (the same spin-up as the headline step's: the searches measured just before let the clocks sag)
+    for _ in range(int(os.environ.get("COVEST_BENCH_SPINUP", "25")) + args.warmup):
         step()
     import torch
     grid.profile(True)
