@@ -126,12 +126,12 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     };
 
     // One key tile with the streams 0 .. N-1 (N = S: all of them; N = 1: see below).
-    auto do_tile = [&](auto n_tag, int t) __attribute__((always_inline)) {
+    auto do_tile = [&](auto n_tag, int t, bool force_start) __attribute__((always_inline)) {
         constexpr int N = decltype(n_tag)::value;
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
         st.template enter_tile_n<N>(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                                    tv.run_start[t] != 0);
+                                    tv.run_start[t] != 0 || force_start); // (behind skipped tiles: anchored afresh)
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         const double *cnt = tv.cnt + (int64_t)t * kTileBins;
         double xx[S]; // squared rates, recomputed per tile (N multiplies) rather than held in 2 S registers
@@ -204,7 +204,7 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
         }
         if (st.only_first_left())
             break;
-        do_tile(std::integral_constant<int, S>{}, t);
+        do_tile(std::integral_constant<int, S>{}, t, false);
     }
     // CLOSED FORM for the rest (round 3).  With one stream left and no tail, p_j = a_0 TP(x_0, j) for every later key
     // -- the other classes' terms are below e^-760, exact zeros in the reference's doubles too -- so
@@ -248,9 +248,33 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
             }
         }
     }
-    if (walk_rest)
+    // A wave that must walk (round 4: walks only WHERE it must).  log p_j is concave in j, so over the keys of ONE tile
+    // its minimum lies at an end of the tile too: a tile at whose ends every lane is well above the clamp holds no row for
+    // the strict evaluation and no zero, and its share of the sum is the closed form again -- three multiply-adds
+    // against the tile's own sums (differences of the suffix sums).  Only the tiles some lane comes near the clamp in
+    // are walked key by key -- for C2 the last two or three of the forty the walk used to take, which was a sixth of
+    // the kernel's instructions; the stream is anchored afresh behind skipped tiles, as at the start of a run.
+    if (walk_rest && !TAIL) {
+        const double lx0 = st.an.lx(0), c0 = st.an.c(0);
+        bool skipped = false;
+        for (; t < tv.n_tiles; ++t) {
+            const double k0 = tv.first_key[t];
+            const double lp_lo = fma(k0 - 1.0, lx0, c0 - tv.lgam_prev[t]); // (at the key before the tile: a superset)
+            const double lp_hi = fma(k0 + (double)(tv.n_bins[t] - 1), lx0, c0 - tv.lgam_last[t]);
+            const bool near = !(fmin(lp_lo, lp_hi) > sub_list.log_p_clamp + 0.5); // (a stream that is off, a NaN: near)
+            if (__any(finite && near)) { // wave-uniform
+                do_tile(std::integral_constant<int, 1>{}, t, skipped);
+                skipped = false;
+            } else {
+                acc_ll += fma(c0, tv.suf_h[t] - tv.suf_h[t + 1],
+                              fma(lx0, tv.suf_jh[t] - tv.suf_jh[t + 1], -(tv.suf_lgh[t] - tv.suf_lgh[t + 1])));
+                skipped = true;
+            }
+        }
+    } else if (walk_rest) {
         for (; t < tv.n_tiles; ++t)
-            do_tile(std::integral_constant<int, 1>{}, t);
+            do_tile(std::integral_constant<int, 1>{}, t, false);
+    }
 
     double tail_term = 0.0;
     if (TAIL) {
