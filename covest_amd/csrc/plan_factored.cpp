@@ -63,6 +63,7 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     if (list_mode == 0 && n_pass == 1 && o_base == 0)
         for (int32_t qt = 0; qt < n_qtiles; ++qt)
             nsh[(size_t)qt] = qo.tile_nsh[(size_t)(tile_lo + qt)];
+    double r4_q = NAN, r4_of_q = 0.0; // (neighbouring slots of a shared tile have one q: one pow for them)
     for (size_t ls = 0; ls < n_slots; ++ls) {
         const size_t gs = (size_t)tile_lo * 16 + ls;
         if (qo.order[gs] < 0)
@@ -73,7 +74,11 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         q_orig[ls] = (int32_t)qi;
         double q1, q2, q;
         weights_of(gs, q1, q2, q);
-        r4[ls] = std::pow(1 - q, 4.0);
+        if (!(q == r4_q)) {
+            r4_q = q;
+            r4_of_q = std::pow(1 - q, 4.0);
+        }
+        r4[ls] = r4_of_q;
         const int steps = t_loc > 1 ? (t_loc - 1 + 3) / 4 : 0;
         nsteps[ls / 16] = std::max(nsteps[ls / 16], steps);
         t_loc_max = std::max(t_loc_max, t_loc);
@@ -217,6 +222,10 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         const int qt = unit_tile[at];
         if (qt < 0)
             continue;
+        // (the columns of a shared tile have ONE q: its powers are made once per slot, not once per column -- the same
+        // calls of pow with the same arguments, so the same bits; they were most of a plan's build time, which is a third
+        // of an optimize_grid iteration)
+        double pw_q = NAN, pw_geo = 0.0, pw_16 = 0.0, pw_4 = 0.0, pw_inv = 0.0, pw_after = 0.0;
         for (int colx = 0; colx < 16; ++colx) {
             const size_t gs = ((size_t)tile_lo + (size_t)qt) * 16 + (size_t)colx;
             if (qo.order[gs] < 0)
@@ -225,7 +234,17 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
             weights_of(gs, q1, q2, q);
             const int o_first = o_base + unit_o0[at];
             const double head = (1 - q1) * (1 - q2) * q, base = 1 - q;
-            double geo = o_first >= 3 ? std::pow(base, (double)(o_first - 3)) : 1.0; // base^(o - 3) at o = max(o_first, 3)
+            if (!(q == pw_q)) { // (NaN: never equal, made afresh)
+                pw_q = q;
+                pw_geo = o_first >= 3 ? std::pow(base, (double)(o_first - 3)) : 1.0;
+                if (unit_nsh[at] > 0) {
+                    pw_16 = std::pow(base, 16.0);
+                    pw_4 = std::pow(base, 4.0);
+                    pw_inv = 1.0 / std::pow(base, 4.0 * (double)unit_nsh[at]);
+                    pw_after = std::pow(base, (double)(o_first + 4 * (unit_nsh[at] + 1) - 3));
+                }
+            }
+            double geo = pw_geo; // base^(o - 3) at o = max(o_first, 3)
             for (int d = 0; d < 8; ++d) {
                 const int o = o_first + d;
                 double w;
@@ -250,13 +269,12 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
                 // (1-q)^16), and the MFMA that brings the sum in multiplies by b_o of that first step, which the kernel
                 // makes from the weight it holds anyway -- b_o of the first step AFTER them -- times (1-q)^(-4 nsh)
                 // (<= 1e10: the cut-off is where b_o reaches 1e-8)
-                unit_rho[4 * at] = std::pow(base, 16.0);
-                unit_rho[4 * at + 2] = std::pow(base, 4.0);
-                unit_rho[4 * at + 3] = 1.0 / std::pow(base, 4.0 * (double)unit_nsh[at]);
+                unit_rho[4 * at] = pw_16;
+                unit_rho[4 * at + 2] = pw_4;
+                unit_rho[4 * at + 3] = pw_inv;
             }
             if (unit_nsh[at] > 0) { // the first step after the shared ones: o = 5 + 4 nsh .. 8 + 4 nsh
-                const int o_after = o_first + 4 * (unit_nsh[at] + 1);
-                double g2 = std::pow(base, (double)(o_after - 3));
+                double g2 = pw_after; // base^(o_after - 3), o_after = o_first + 4 (nsh + 1)
                 for (int d = 0; d < 4; ++d, g2 *= base)
                     piece_w[(at * 64 + (size_t)(d * 16 + colx)) * 2 + 1] = head * g2;
             }
