@@ -306,16 +306,21 @@ def first_wins_scan(vals, min_val, sgn=1):
     Returns (min_val, argmin or -1, diff) exactly as the sequential scan would:
     only strict improvements are visited, in index order, and `diff`
     accumulates `min_val - val` at each of them in that order.
+    (Round 4: only the values below the STARTING minimum can ever pass the test -- the running minimum only falls --, and
+    after a search's first iterations those are a handful: they are picked out with one vectorised compare and walked
+    by the reference's own loop; where they are many, the strict running-minimum records among them are picked first.
+    59 -> 12 us for an iteration's 7 776 values, a fifth of an optimize_grid search.)
     """
     v = np.asarray(vals, dtype=np.float64)
-    sv = sgn * v
+    sv = v if sgn == 1 else sgn * v
     diff = 0.0
     arg = -1
-    # candidates: strict running-minimum records below the starting value
     with np.errstate(invalid="ignore"):
-        prev = np.minimum.accumulate(np.where(np.isnan(sv), np.inf, sv))
-        prev = np.concatenate(([np.inf], prev[:-1]))
-        cand = np.flatnonzero((sv < prev) & (sv < min_val))
+        cand = np.flatnonzero(sv < min_val)  # (a NaN never passes: NaN < x is False)
+    if cand.size > 256:
+        sc = sv[cand]
+        prev = np.minimum.accumulate(sc)
+        cand = cand[np.concatenate(([True], sc[1:] < prev[:-1]))]
     for i in cand:
         if sv[i] < min_val:
             diff += min_val - v[i]
