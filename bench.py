@@ -65,8 +65,23 @@ def load_hist(name):
     return hist
 
 
+def workload_tail(name):
+    """The tail (covest/histogram.py:105-134: the mass trim_hist cuts off) a workload's model is built with: 0 for the
+    SURVEY 8(d) configurations, the reference's own for the trimmed histograms (tests/golden/c{3,2}_trim.json)."""
+    fixture = {"c3t": "c3_trim.json", "c2t": "c2_trim.json"}.get(name)
+    if fixture is None:
+        return 0
+    with open(os.path.join(REPO, "tests", "golden", fixture)) as f:
+        return json.load(f)["tail"]
+
+
 def workload(name, n_ranks, scaling="weak"):
-    """(model kind, histogram name, axes) -- SURVEY.md 8(d)."""
+    """(model kind, histogram name, axes) -- SURVEY.md 8(d).  c3t / c2t: the same grids on the histograms the
+    reference's process_histogram would hand the model -- trimmed by get_trim / trim_hist, with their tail
+    (workload_tail): the shape every real CovEst run has."""
+    if name in ("c3t", "c2t"):
+        kind, _, axes = workload(name[:2], n_ranks, scaling)
+        return kind, {"c3t": "H10k_rep_trim", "c2t": "H10k_basic_trim"}[name], axes
     if scaling == "strong":
         if name != "c3":
             raise SystemExit("--scaling strong is defined for the c3 workload")
@@ -84,6 +99,32 @@ def workload(name, n_ranks, scaling="weak"):
         return "basic", "H256", [np.array([50 + i * 100 / (50 * n_ranks - 1) for i in range(50 * n_ranks)]),
                                  np.array([0.001 + i * 0.099 / 49 for i in range(50)])]
     raise SystemExit("unknown workload %r" % name)
+
+
+def source_sha16():
+    """sha256[:16] over the library's sources (covest_amd/csrc, include/): what ties profiles/pmc_traffic.json --
+    counters of ANOTHER run -- to the library a bench line was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(REPO, "covest_amd", "csrc"), os.path.join(REPO, "include")):
+        for name in sorted(os.listdir(d)):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def argmin_record(workload_name, gmin, gidx):
+    """The step's arg-min; for the trimmed-histogram workloads beside the one the REFERENCE finds among the
+    candidates of tests/golden/c{3,2}_trim.json (make_golden.py sections c3trim, c2trim)."""
+    rec = {"min_negll": gmin, "flat_index": gidx}
+    fixture = {"c3t": "c3_trim.json", "c2t": "c2_trim.json"}.get(workload_name)
+    if fixture:
+        with open(os.path.join(REPO, "tests", "golden", fixture)) as f:
+            ref = json.load(f)["candidates"]
+        rec["reference"] = {"min_negll": ref["reference_min_negll"], "flat_index": ref["reference_argmin_flat"]}
+        rec["identical_index"] = gidx == ref["reference_argmin_flat"]
+        rec["rel_err"] = abs(gmin - ref["reference_min_negll"]) / abs(ref["reference_min_negll"])
+    return rec
 
 
 def host_threads(cap=16):
@@ -108,7 +149,7 @@ def host_threads(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(kind, hist, axes, budget_s, seed=20240521):
+def cpu_baseline(kind, hist, axes, budget_s, seed=20240521, tail=0):
     """The oracle (faithful restatement of the reference's O(j) long-double pmf
     product) timed on this host's cores on a bounded, seeded sample of the same
     grid.  Its cost per point is exactly proportional to (T-1) [x S x sum of
@@ -117,7 +158,7 @@ def cpu_baseline(kind, hist, axes, budget_s, seed=20240521):
     from oracle import covest_oracle as orc
     import itertools
     threads = host_threads()
-    om = orc.OracleModel(kind, 21, 100, hist, 0, max_error=8)
+    om = orc.OracleModel(kind, 21, 100, hist, tail, max_error=8)
     shape = [len(a) for a in axes]
     total = int(np.prod(shape))
     rng = np.random.default_rng(seed)
@@ -471,57 +512,6 @@ def bench_refine(args):
     print(json.dumps(out), flush=True)
 
 
-def tail_variant(cls, axes, args, device, stream):
-    """The same grid on the histogram the reference's own pipeline would hand the model: H10k_rep TRIMMED by
-    get_trim / trim_hist (covest/histogram.py:105-134; tests/golden/H10k_rep_trim.hist, made by the reference in
-    make_golden.py section c3trim): the 380 keys below the trim point, tail = the trimmed mass (11 192), so that
-    1 - sp_j ~ 1e-4 at the optimum and the tail term tail * log(1 - sp_j) (covest/models.py:103-104) is well
-    conditioned.  With a tail EVERY key enters sp_j.  Same step, same timing rules as the headline number; the
-    arg-min is the one the reference finds (tests/golden/c3_trim.json, checked by tests/test_gpu_parity.py)."""
-    from covest_amd import DenseGrid
-    hist = load_hist("H10k_rep_trim")
-    with open(os.path.join(REPO, "tests", "golden", "c3_trim.json")) as f:
-        fix = json.load(f)
-    tail = fix["tail"]
-    model = cls(21, 100, hist, tail, max_error=8, device=device)
-    grid = DenseGrid(model, axes)
-
-    def step():
-        grid.evaluate(kernel=args.kernel, stream=stream)
-        return grid.argmin()
-
-    # (the same spin-up as the headline step's: the searches measured just before let the clocks sag)
-    for _ in range(int(os.environ.get("COVEST_BENCH_SPINUP", "25")) + args.warmup):
-        step()
-    import torch
-    grid.profile(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gmin, gidx = step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = grid.kernel_ms()
-    terms, flops, kernel_name = grid.work()
-    avg_kernel_s = 1e-3 * kernel_ms / max(launches, 1)
-    total = len(grid)
-    ref = fix["candidates"]
-    out = {"what": "same grid, H10k_rep trimmed as the reference trims it (%d keys, all evaluated) with its tail = %d"
-                   % (model.bins_evaluated, tail),
-           "value": total * args.steps / elapsed, "unit": "evals/s", "ms_per_step": 1e3 * elapsed / args.steps,
-           "argmin": {"min_negll": gmin, "flat_index": gidx,
-                      "reference": {"min_negll": ref["reference_min_negll"], "flat_index": ref["reference_argmin_flat"]},
-                      "identical_index": gidx == ref["reference_argmin_flat"],
-                      "rel_err": abs(gmin - ref["reference_min_negll"]) / abs(ref["reference_min_negll"])},
-           "roofline": {"bound": "mfma", "achieved": flops / avg_kernel_s / 1e12, "peak": FP64_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": flops / avg_kernel_s / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
-                        "kernel": kernel_name, "kernel_ms_avg": 1e3 * avg_kernel_s, "launches": launches,
-                        "algorithmic_flops_per_launch": flops, "pmf_terms_per_launch": terms}}
-    grid.close()
-    model.close()
-    return out
-
-
 def strong_variant(cls, hist, args, world, rank, local_rank, xdev, on_device, stream):
     """N > 1: the strong-scaling answer in the SAME invocation as the weak one (the driver issues one command per N).
     ONE fixed grid -- c128 x e128 x q1 16 x q 16 = 4.2 M points, `workload("c3", 1, "strong")` -- cut into N
@@ -604,15 +594,18 @@ def strong_variant(cls, hist, args, world, rank, local_rank, xdev, on_device, st
 
 def other_configs(args):
     """The default (driver-timed) run carries every single-GPU configuration of BASELINE.json, not only C3: config 2
-    (basic model, 10^6 points), config 5 (k-mer histogram; 10 Gbp when >= 200 GB of HBM are free, else 1 Gbp) and the
-    reference's consumer of batched evaluations (optimize_grid), each run as a CHILD process of this one -- its own
+    (basic model, 10^6 points), config 5 (k-mer histogram; 10 Gbp when >= 200 GB of HBM are free, else 1 Gbp), the
+    reference's consumer of batched evaluations (optimize_grid) and configs 3 and 2 on the histograms the reference's own
+    pipeline would hand the model (trimmed, with a tail: `tail`, `c2_tail`), each run as a CHILD process of this one -- its own
     model handles and HBM, its own JSON line -- and reported in compact form under variants.{c2,c5,og}.  The children
     run one after the other after this process's own timed region; their CPU baselines are capped at 4 s each."""
     import subprocess
     import torch
     free_b, _ = torch.cuda.mem_get_info()
     gbp = 10.0 if free_b >= 200e9 else 1.0
-    runs = [("c2", ["--workload", "c2", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-budget", "4"]),
+    runs = [("tail", ["--workload", "c3t", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-budget", "0"]),
+            ("c2", ["--workload", "c2", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-budget", "4"]),
+            ("c2_tail", ["--workload", "c2t", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-budget", "0"]),
             ("c5", ["--workload", "c5", "--kmer-gbp", str(gbp), "--steps", "3", "--warmup", "1", "--cpu-budget", "1"]),
             ("og", ["--workload", "og", "--steps", "3"])]
     out = {}
@@ -636,8 +629,9 @@ def other_configs(args):
                           "unit": roof.get("unit")},
              "cpu_baseline": {k: r["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")} if "cpu_baseline" in r else None,
              "wall_s": time.perf_counter() - t0}
-        if "executed" in roof:
-            c["roofline"]["executed_frac"] = roof["executed"]["frac"]
+        for k in ("frac_is", "executed_from", "algorithmic", "traffic"):
+            if k in roof:
+                c["roofline"][k] = roof[k]
         if "atomics" in roof:
             c["roofline"]["atomics_frac"] = roof["atomics"]["frac"]
             c["passes_ms"] = roof.get("passes_ms")
@@ -704,7 +698,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5", "f2", "f3", "og"])
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c3t", "c2t", "c5", "f2", "f3", "og"])
     ap.add_argument("--kmer-gbp", type=float, default=10.0,
                     help="c5: gigabases of synthetic reads (BASELINE.json config 5: 10; ~65 GB of HBM)")
     ap.add_argument("--kmer-path", default="partitioned", choices=["partitioned", "table"],
@@ -755,6 +749,7 @@ def main():
     xdev = device if args.backend == "nccl" else None  # where the 16-byte exchange lives
 
     kind, hist_name, axes = workload(args.workload, world, args.scaling)
+    tail = workload_tail(args.workload)
     hist = load_hist(hist_name)
     cls = BasicModel if kind == "basic" else RepeatsModel
     on_device = world > 1 and args.backend == "nccl"  # the exchange consumes the arg-min kernel's output in HBM
@@ -766,7 +761,7 @@ def main():
     torch.zeros(8, device=device).cpu()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    model = cls(21, 100, hist, 0, max_error=8, device=local_rank)
+    model = cls(21, 100, hist, tail, max_error=8, device=local_rank)
     shape = [len(a) for a in axes]
     total = int(np.prod(shape))
     # contiguous flat-index blocks, one per rank, balanced by sum(T - 1) for the repeats model (covest_amd.grid):
@@ -793,7 +788,8 @@ def main():
     # W untimed warm-up steps as asked, preceded by a fixed spin-up that is not counted either: the device
     # needs a few milliseconds of work before its clocks settle (at --warmup 1 the first timed steps ran 13 %
     # slower than steady state).  The timed steps follow the warm-up DIRECTLY.
-    for _ in range(int(os.environ.get("COVEST_BENCH_SPINUP", "25")) + args.warmup):
+    spinup_steps = int(os.environ.get("COVEST_BENCH_SPINUP", "25"))
+    for _ in range(spinup_steps + args.warmup):
         step()
     grid.profile(True)
     if world > 1:
@@ -826,7 +822,7 @@ def main():
     def warm_search(h):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        model2 = cls(21, 100, h, 0, max_error=8, device=local_rank)
+        model2 = cls(21, 100, h, tail, max_error=8, device=local_rank)
         t1 = time.perf_counter()
         model2.handle
         t2 = time.perf_counter()
@@ -865,10 +861,9 @@ def main():
         torch.cuda.synchronize()
         exchange_us = 1e6 * (time.perf_counter() - t1) / 20
     variants = None
-    if rank == 0 and world == 1 and args.workload == "c3" and args.scaling == "weak" and not args.compact:
-        variants = {"tail": tail_variant(cls, axes, args, local_rank, stream)}
-        if not args.no_variants:
-            variants.update(other_configs(args))
+    if rank == 0 and world == 1 and args.workload == "c3" and args.scaling == "weak" and not args.compact \
+            and not args.no_variants:
+        variants = other_configs(args)
     if world > 1 and args.workload == "c3" and args.scaling == "weak":  # (every rank takes part)
         variants = {"strong": strong_variant(cls, hist, args, world, rank, local_rank, xdev, on_device, stream)}
 
@@ -880,34 +875,40 @@ def main():
         n_local = block[1] - block[0]
         # algorithmic HBM bytes of one launch: axes in, 8 B/point LL out, histogram once
         alg_bytes = 8.0 * sum(shape) + 8.0 * n_local + 24.0 * model.bins_evaluated
-        traffic, executed = None, None
+        traffic, executed, profile_sha = None, None, None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    rec = json.load(f).get(args.workload, {})
+                    doc = json.load(f)
+                rec = doc.get(args.workload, {})
                 traffic = rec.get(kernel_name)
                 executed = rec.get(kernel_name + "_executed_flops")
+                profile_sha = doc.get("_source_sha16")
             except (OSError, ValueError):
                 traffic = None
         out = {
             "metric": "grid-point log-likelihood evals/s, repeat model, 10k-bin hist"
                       if args.workload == "c3" else "grid-point log-likelihood evals/s (%s)" % args.workload,
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "warmup": args.warmup, "spinup_steps": spinup_steps, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": {"c3": "C3: RepeatsModel k=21 r=100 S=8, H10k_rep.hist (10000 keys, %d evaluated: tail=0), "
                                    "grid c%dxe%dxq1 16xq2 1xq 16" % (model.bins_evaluated, shape[0], shape[1]),
                              "c2": "C2: BasicModel k=21 r=100 S=8, H10k_basic.hist (10000 keys, %d evaluated: tail=0), "
                                    "grid c%dxe1000" % (model.bins_evaluated, shape[0]),
+                             "c3t": "C3 grid on H10k_rep as the reference trims it (covest/histogram.py:105-134): %d keys, all "
+                                    "evaluated, tail = %d; grid c%dxe%dxq1 16xq2 1xq 16" % (model.bins_evaluated, tail, shape[0], shape[1]),
+                             "c2t": "C2 grid on H10k_basic as the reference trims it: %d keys, all evaluated, tail = %d; "
+                                    "grid c%dxe1000" % (model.bins_evaluated, tail, shape[0]),
                              "c1": "C1: BasicModel k=21 r=100 S=8, H256.hist, grid c%dxe50" % shape[0]}[args.workload],
                 "grid_points": total, "points_per_gpu": n_local, "kernel": kernel_name,
                 "partition": "contiguous flat-index block per GPU balanced by sum(T-1), one RCCL all-gather of 16-byte "
                              "(min, index) pairs per step (taken from the arg-min kernel's output in HBM, scanned on the "
                              "device, 16 bytes copied back)",
             },
-            "argmin": {"min_negll": gmin, "flat_index": gidx},
+            "argmin": argmin_record(args.workload, gmin, gidx),
             "time_to_argmin_ms": {"first_call_incl_module_load": 1e3 * time_to_argmin_first,
                                   "warm": 1e3 * time_to_argmin_warm, "warm_split": time_to_argmin_split,
                                   "warm_histogram_as_dict": 1e3 * time_to_argmin_warm_dict,
@@ -917,7 +918,9 @@ def main():
                 "bound": "mfma", "pipe": "fp64 VALU + fp64 MFMA: ONE shared fp64 datapath (tools/microbench_mix.hip); "
                                          "78.6 TFLOP/s is both the fp64 vector and the dense fp64 MFMA peak of MI355X",
                 "achieved": achieved_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
+                "frac": achieved_tflops / FP64_PEAK_TFLOPS,
+                "frac_is": "algorithmic flops (covest_grid_work) / this run's kernel time / peak: no PMC profile of this workload",
+                "traffic": traffic,
                 "traffic_from": None if traffic is None else "profiles/pmc_traffic.json: PMC passes of the same kernel "
                                 "and workload under rocprofv3 (tools/pmc_profile.sh), 2 x FETCH_SIZE + WRITE_SIZE per "
                                 "launch; NOT counted in this run",
@@ -928,23 +931,27 @@ def main():
                         "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
-        if executed:
-            # the fp64 flops the kernel EXECUTED (PMC: 64 x (2 FMA + MUL + ADD) + 2048 per MFMA, profiles/pmc_traffic.json,
-            # from a profiled run of this workload) over THIS run's kernel time -- beside `frac`, which is on algorithmic
-            # flops: K-basic's closed form leaves most of SURVEY's pmf terms unevaluated, so only this one says how busy
-            # the fp64 pipe is
-            out["roofline"]["executed"] = {"flops_per_launch": executed, "achieved": executed / avg_kernel_s / 1e12,
-                                           "unit": "TFLOP/s", "frac": executed / avg_kernel_s / 1e12 / FP64_PEAK_TFLOPS}
-            if kernel_name == "ll_basic":
-                # K-basic no longer evaluates most of SURVEY's pmf terms (closed form, doomed waves leave early): on
-                # that unit `achieved` passes the peak, which says nothing.  `frac` is the executed one here; the
-                # figure on SURVEY's unit stays beside it, labelled.
-                out["roofline"]["survey_unit"] = {"achieved": achieved_tflops, "frac": achieved_tflops / FP64_PEAK_TFLOPS,
-                                                  "note": "4 flop per pmf term of every class and key + 25 per log: work "
-                                                          "the kernel skips by its closed form; not a utilisation"}
-                out["roofline"]["achieved"] = out["roofline"]["executed"]["achieved"]
-                out["roofline"]["frac"] = out["roofline"]["executed"]["frac"]
-                out["roofline"]["frac_is"] = "executed fp64 flops (PMC profile of this workload) / this run's kernel time / peak"
+        if executed and world == 1 and args.scaling == "weak":
+            # `frac` is on the fp64 flops the kernel EXECUTES (PMC: 64 x (2 FMA + MUL + ADD) + 2048 per MFMA, from a
+            # profiled run of this workload: profiles/pmc_traffic.json) over THIS run's kernel time.  Both kernels skip
+            # work their "algorithmic" counts still hold -- K-basic's closed form leaves most of SURVEY's pmf terms
+            # unevaluated, K-factored drops the units whose sums are -inf -- so a count of what would have to be done
+            # without those shortcuts says nothing about how busy the fp64 pipe is; those counts stay beside it, labelled.
+            # The profile is tied to the sources it was taken on (_source_sha16): on other sources it is marked stale.
+            here = source_sha16()
+            out["roofline"]["algorithmic"] = {
+                "flops_per_launch": flops, "achieved": achieved_tflops, "frac": achieved_tflops / FP64_PEAK_TFLOPS,
+                "note": ("SURVEY 8(d)'s unit (4 flop per pmf term of every class and key + 25 per log): work the kernel "
+                         "skips by its closed form; not a utilisation") if kernel_name == "ll_basic" else
+                        "the factored formulation's own count (covest_grid_work), INCLUDING the units the kernel skips "
+                        "once their sums are -inf; not a utilisation"}
+            out["roofline"]["executed_flops_per_launch"] = executed
+            out["roofline"]["achieved"] = executed / avg_kernel_s / 1e12
+            out["roofline"]["frac"] = executed / avg_kernel_s / 1e12 / FP64_PEAK_TFLOPS
+            out["roofline"]["frac_is"] = "executed fp64 flops (PMC profile of this workload) / this run's kernel time / peak"
+            out["roofline"]["executed_from"] = {"file": "profiles/pmc_traffic.json", "source_sha16": profile_sha,
+                                                "this_library_source_sha16": here,
+                                                "stale": profile_sha is not None and profile_sha != here}
         if kernel_name == "ll_factored" and world == 1 and model.tail == 0:
             # The same kernel time on ROUND 1's flop count of K-factored (one multiply-add per (key, column, o < T)
             # in the contraction; since round 2 the steps below a q-tile's smallest cut-off are summed once per key --
@@ -971,7 +978,7 @@ def main():
                     "efficiency column measures); variants.strong is the north-star question -- one fixed 4.2 M-point "
                     "grid divided among the N GPUs -- answered in the same run")
         if world == 1 and args.cpu_budget > 0:
-            out["cpu_baseline"] = cpu_baseline(kind, hist, axes, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(kind, hist, axes, args.cpu_budget, tail=tail)
         print(json.dumps(out), flush=True)
 
     grid.close()

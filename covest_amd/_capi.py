@@ -24,7 +24,8 @@ EXPORTS = (
     "covest_model_create", "covest_model_destroy", "covest_model_param_count",
     "covest_model_bins_evaluated", "covest_threshold_o", "covest_eval_points",
     "covest_probabilities", "covest_reference_overflow", "covest_grid_create", "covest_grid_reset", "covest_grid_destroy", "covest_grid_size",
-    "covest_grid_eval", "covest_grid_argmin", "covest_grid_argmin_pair_device", "covest_grid_ll_device",
+    "covest_grid_eval", "covest_grid_eval_scan", "covest_grid_scan", "covest_grid_argmin", "covest_grid_argmin_pair_device",
+    "covest_grid_ll_device",
     "covest_grid_ll_host",
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
     "covest_kmer_create", "covest_kmer_destroy", "covest_kmer_reserve", "covest_kmer_add",
@@ -116,6 +117,10 @@ def lib():
     L.covest_grid_size.argtypes = [vp]
     L.covest_grid_eval.restype = ctypes.c_int
     L.covest_grid_eval.argtypes = [vp, i32, vp]
+    L.covest_grid_eval_scan.restype = ctypes.c_int
+    L.covest_grid_eval_scan.argtypes = [vp, i32, vp, ctypes.c_double]
+    L.covest_grid_scan.restype = ctypes.c_int
+    L.covest_grid_scan.argtypes = [vp, i32, ctypes.POINTER(i64), dp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.covest_grid_argmin.restype = ctypes.c_int
     L.covest_grid_argmin.argtypes = [vp, dp, ctypes.POINTER(i64)]
     L.covest_grid_argmin_pair_device.restype = vp

@@ -3,6 +3,48 @@
 
 using namespace covest;
 
+namespace covest {
+
+// Where a grid handle stages an upload, and how the copy is issued (host.h covest_grid::stage).
+int grid_stage_begin(covest_grid *g, size_t bytes, StageSlot &slot)
+{
+    if (!g->async_uploads) { // covest_grid_create: the process's staging buffer, a blocking copy
+        SharedStage &ss = shared_stage();
+        slot.shared_hold = std::unique_lock<std::mutex>(ss.mu);
+        HIP_TRY(ss.buf.reserve(bytes));
+        slot.ptr = ss.buf.as<char>();
+        return COVEST_OK;
+    }
+    const size_t at = (g->stage_off + 63) / 64 * 64;
+    if (at + bytes > g->stage.cap) {
+        // (growing frees the old block: the copies queued from it finish first.  What they staged is then on the device,
+        // so the new block starts empty)
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        HIP_TRY(g->stage.reserve(std::max<size_t>(2 * (at + bytes), 1 << 18)));
+        g->stage_off = 0;
+        slot.ptr = g->stage.as<char>();
+        g->stage_off = bytes;
+        return COVEST_OK;
+    }
+    slot.ptr = g->stage.as<char>() + at;
+    g->stage_off = at + bytes;
+    return COVEST_OK;
+}
+
+int grid_stage_commit(covest_grid *g, StageSlot &slot, void *dst, size_t bytes)
+{
+    if (!g->async_uploads) {
+        HIP_TRY(hipMemcpy(dst, slot.ptr, bytes, hipMemcpyHostToDevice));
+        slot.shared_hold = std::unique_lock<std::mutex>();
+        return COVEST_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(dst, slot.ptr, bytes, hipMemcpyHostToDevice, nullptr));
+    g->upload_pending = true;
+    return COVEST_OK;
+}
+
+} // namespace covest
+
 // optimize_grid re-configures a handle every iteration (21 times 0.2 ms of allocations and copies otherwise).
 static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *axes, const int64_t *axis_len,
                           int64_t flat_begin, int64_t flat_end, const char *who)
@@ -29,7 +71,9 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
     g->flat_begin = flat_begin;
     g->flat_end = flat_end;
     g->evaluated = false;
+    g->scan_valid = false;
     g->ev_used = 0;
+    g->stage_off = 0; // (a reset waited for the stream of the last evaluation: what the last reset staged has been copied)
     const int64_t n = flat_end - flat_begin;
     const int64_t n1 = n_axes == 5 ? axis_len[2] : 1, n2 = n_axes == 5 ? axis_len[3] : 1, n3 = n_axes == 5 ? axis_len[4] : 1;
     const int64_t nq = n_axes == 5 ? n1 * n2 * n3 : 0;
@@ -49,10 +93,11 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
     HIP_TRY(g->arena.reserve(bytes));
     char *base = g->arena.as<char>();
     {
-        SharedStage &ss = shared_stage();
-        std::lock_guard<std::mutex> hold(ss.mu);
-        HIP_TRY(ss.buf.reserve(o_ll));
-        char *stage = ss.buf.as<char>();
+        StageSlot slot;
+        const int src = grid_stage_begin(g, o_ll, slot);
+        if (src != COVEST_OK)
+            return src;
+        char *stage = slot.ptr;
         std::memset(stage, 0, o_ll);
         double *sa = reinterpret_cast<double *>(stage);
         for (int d = 0; d < n_axes; ++d) {
@@ -64,7 +109,9 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
             g->len[d] = 1;
         if (nq)
             std::memcpy(stage + o_table, table.data(), (size_t)nq * sizeof(int32_t));
-        HIP_TRY(hipMemcpy(base, stage, o_ll, hipMemcpyHostToDevice));
+        const int crc = grid_stage_commit(g, slot, base, o_ll);
+        if (crc != COVEST_OK)
+            return crc;
     }
     g->axes.ptr = base + o_axes;
     g->sub_ctl.ptr = base + o_ctl;
@@ -108,6 +155,11 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
         if (prc != COVEST_OK)
             return prc;
     }
+    if (g->upload_pending) { // an evaluation on another stream than the copies' waits for this
+        if (!g->upload_ev)
+            HIP_TRY(hipEventCreateWithFlags(&g->upload_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(g->upload_ev, nullptr));
+    }
     g->configured = true;
     return COVEST_OK;
 }
@@ -115,6 +167,11 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
 static void grid_release(covest_grid *g)
 {
     (void)hipDeviceSynchronize(); // (the buffers go back to the process's cache, host.h: nothing may still work on them)
+    if (g->upload_ev) {
+        (void)hipEventDestroy(g->upload_ev);
+        g->upload_ev = nullptr;
+    }
+    g->stage.release();
     if (g->result_host) {
         pinned_block_give(g->result_host);
         g->result_host = nullptr;
@@ -173,6 +230,10 @@ int covest_grid_reset(covest_grid *g, int32_t n_axes, const double *const *axes,
         return dev_guard.status();
     if (g->last_stream || g->evaluated)
         HIP_TRY(hipStreamSynchronize(g->last_stream)); // nothing of the last evaluation may still be in flight
+    if (g->upload_pending && !g->evaluated)
+        HIP_TRY(hipStreamSynchronize(nullptr)); // (a reset that was never evaluated: its copies read the staging memory)
+    g->upload_pending = false;
+    g->async_uploads = true; // (from the first reset on: a handle that is re-configured is re-configured often)
     return grid_configure(g, n_axes, axes, axis_len, flat_begin, flat_end, "covest_grid_reset");
 }
 
@@ -216,7 +277,7 @@ int covest_grid_kernel_ms(covest_grid *g, double *total_ms, int64_t *launches)
 
 int64_t covest_grid_size(const covest_grid *g) { return g ? g->flat_end - g->flat_begin : COVEST_E_INVALID; }
 
-int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
+static int grid_eval(covest_grid *g, int32_t kernel, void *stream, bool scan, double scan_start)
 {
     if (!g)
         return fail(COVEST_E_INVALID, "covest_grid_eval: null grid");
@@ -233,6 +294,8 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
         return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n = g->flat_end - g->flat_begin;
+    if (g->upload_pending && st != nullptr && g->upload_ev)
+        HIP_TRY(hipStreamWaitEvent(st, g->upload_ev, 0)); // (covest_grid_reset's copies run on the null stream)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g->profiling) {
         if (g->ev_used == g->ev_begin.size()) {
@@ -277,15 +340,54 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream)
     }
 #endif
     if (!g->result_host) { // (page-locked, mapped: argmin_stage2 stores the winner there itself)
-        static_assert(sizeof(ArgminResult) <= 64, "pinned block");
+        static_assert(sizeof(ArgminResult) <= 64 && 64 + sizeof(ScanRecords) <= kPinnedBlockBytes, "pinned block");
         g->result_host = static_cast<ArgminResult *>(pinned_block_take());
         if (!g->result_host)
             return fail(COVEST_E_NOMEM, "covest_grid_eval: no page-locked memory for the result");
     }
-    HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->flat_begin, g->partial_val.as<double>(),
-                          g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), g->result_host, g->sub_ctl.as<unsigned>(), st));
+    g->scan_valid = scan && n >= 1 && n <= kArgminSmall;
+    if (g->scan_valid)
+        HIP_TRY(launch_argmin_scan(g->ll.as<double>(), n, g->flat_begin, scan_start, g->result.as<ArgminResult>(), g->result_host,
+                                   g->scan_host(), g->sub_ctl.as<unsigned>(), st));
+    else
+        HIP_TRY(launch_argmin(g->ll.as<double>(), n, g->flat_begin, g->partial_val.as<double>(),
+                              g->partial_idx.as<int64_t>(), g->result.as<ArgminResult>(), g->result_host, g->sub_ctl.as<unsigned>(), st));
     g->last_stream = st;
     g->evaluated = true;
+    return COVEST_OK;
+}
+
+int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream) { return grid_eval(g, kernel, stream, false, 0.0); }
+
+int covest_grid_eval_scan(covest_grid *g, int32_t kernel, void *stream, double start_min)
+{
+    return grid_eval(g, kernel, stream, true, start_min);
+}
+
+int covest_grid_scan(covest_grid *g, int32_t cap, int64_t *index, double *negll, int32_t *n_records, int32_t *truncated)
+{
+    if (!g || !n_records || !truncated || cap < 0 || (cap > 0 && (!index || !negll)))
+        return fail(COVEST_E_INVALID, "covest_grid_scan: bad argument");
+    if (!g->evaluated)
+        return fail(COVEST_E_INVALID, "covest_grid_scan: covest_grid_eval_scan has not run");
+    DeviceGuard dev_guard(g->model->device);
+    int rc = dev_guard.status();
+    if (rc != COVEST_OK)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(g->last_stream));
+    *n_records = 0;
+    *truncated = 1; // (a grid beyond one workgroup's reach, or a plain covest_grid_eval: no list -- read the values back)
+    if (!g->scan_valid)
+        return COVEST_OK;
+    const ScanRecords *sr = g->scan_host(); // (the kernel's own stores to page-locked memory)
+    const int32_t have = sr->n;
+    *truncated = (sr->truncated || have > cap) ? 1 : 0;
+    const int32_t take = std::min(have, cap);
+    for (int32_t i = 0; i < take; ++i) {
+        index[i] = sr->rec[i].index;
+        negll[i] = sr->rec[i].negll;
+    }
+    *n_records = take;
     return COVEST_OK;
 }
 

@@ -47,6 +47,7 @@ int covest_model_create(const covest_model_desc *d, covest_model **out)
     for (int s = 0; s < kMaxErr; ++s) {
         dm.comb[s] = s < d->n_err ? d->comb[s] : 0.0;
         dm.pow3neg[s] = std::pow(3.0, (double)-s); // 3 ** -s, covest/models.py:77
+        dm.ln_comb[s] = dm.comb[s] > 0.0 ? std::log(dm.comb[s]) : -INFINITY;
     }
     for (int i = 0; i < kMaxParams; ++i) {
         dm.lo[i] = i < m->n_par ? d->lo[i] : std::numeric_limits<double>::quiet_NaN();

@@ -393,7 +393,114 @@ __global__ __launch_bounds__(256) void argmin_small(const double *__restrict__ l
 }
 
 
+// The selection scan of covest/grid.py:65-70 ON THE DEVICE, for the caller that runs it every iteration
+// (optimize_grid): started from `start` -- the minimum the search holds when the iteration begins -- the loop
+//     if val < min_val: diff += min_val - val; min_val = val; min_args = args
+// changes its state exactly at the STRICT RUNNING-MINIMUM RECORDS below `start`, in index order: a handful of points
+// once a search is under way.  The kernel lists them -- {flat index, -LL} -- straight into page-locked host memory, and
+// the host replays the loop over that list alone (covest_amd/grid.py replay_records): same comparisons, same sums, same
+// order.  Until round 5 every iteration copied the whole LL array back (62 KB for 7 776 points) to run the loop there.
+// One workgroup (grids up to kArgminSmall points); the values are staged in LDS, every thread owns a contiguous run of
+// them: its minimum, an exclusive prefix minimum across the threads, then its own records behind a prefix sum.  A NaN
+// never passes `<`.  More than kScanCap records: `truncated`, and the caller reads the array back as before.
+__global__ __launch_bounds__(256) void argmin_scan_small(const double *__restrict__ ll, int64_t n, int64_t flat_begin, double start,
+                                                         ArgminResult *__restrict__ result, ArgminResult *__restrict__ host_mirror,
+                                                         ScanRecords *__restrict__ scan, unsigned *__restrict__ queue_count)
+{
+    extern __shared__ double vals[]; // [n] -LL
+    __shared__ double pre_v[256];
+    __shared__ int pre_n[256];
+    const int tid = threadIdx.x;
+    if (tid == 0 && queue_count)
+        *queue_count = 0;
+    Cand c;
+    c.v = INFINITY;
+    c.i = INT64_MAX;
+    for (int64_t i = tid; i < n; i += 256) { // coalesced; ascending i within a thread: strict < keeps the first
+        const double v = -ll[i];
+        vals[i] = v;
+        if (v < c.v) {
+            c.v = v;
+            c.i = i;
+        }
+    }
+    c = block_best(c); // (ends with a barrier: vals is complete)
+    if (tid == 0)
+        publish(c, flat_begin, result, host_mirror);
+    const int chunk = (int)((n + 255) / 256);
+    const int lo = min((int)n, tid * chunk), hi = min((int)n, lo + chunk);
+    double m = INFINITY;
+    for (int i = lo; i < hi; ++i)
+        m = vals[i] < m ? vals[i] : m;
+    pre_v[tid] = m;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { // inclusive prefix minimum (Hillis-Steele)
+        const double o = tid >= off ? pre_v[tid - off] : INFINITY;
+        __syncthreads();
+        pre_v[tid] = o < pre_v[tid] ? o : pre_v[tid];
+        __syncthreads();
+    }
+    // the running minimum this thread's run starts from: `start`, or the smallest value before the run
+    double run0 = start;
+    if (tid > 0 && pre_v[tid - 1] < run0)
+        run0 = pre_v[tid - 1];
+    double run = run0;
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i)
+        if (vals[i] < run) {
+            run = vals[i];
+            ++cnt;
+        }
+    pre_n[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { // inclusive prefix sum
+        const int o = tid >= off ? pre_n[tid - off] : 0;
+        __syncthreads();
+        pre_n[tid] += o;
+        __syncthreads();
+    }
+    int at = pre_n[tid] - cnt;
+    run = run0;
+    for (int i = lo; i < hi; ++i)
+        if (vals[i] < run) {
+            run = vals[i];
+            if (at < kScanCap) {
+                scan->rec[at].index = flat_begin + i;
+                scan->rec[at].negll = run;
+            }
+            ++at;
+        }
+    if (tid == 255) {
+        scan->start = start;
+        scan->truncated = pre_n[255] > kScanCap ? 1 : 0;
+        __threadfence_system(); // (the records before the count that says they are there)
+        scan->n = min(pre_n[255], kScanCap);
+    }
+}
+
 } // namespace
+
+hipError_t launch_argmin_scan(const double *ll, int64_t n, int64_t flat_begin, double start, ArgminResult *result,
+                              ArgminResult *host_mirror, ScanRecords *scan, unsigned *queue_count, hipStream_t stream)
+{
+    if (n > kArgminSmall || n < 1)
+        return hipErrorInvalidValue;
+    const size_t lds = (size_t)n * sizeof(double);
+    static bool raised[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        dev = 0;
+    if (!raised[dev]) { // (128 KB of dynamic LDS for the largest grid: above the default ceiling)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&argmin_scan_small),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kArgminSmall * sizeof(double)));
+        if (e != hipSuccess)
+            return e;
+        raised[dev] = true;
+    }
+    hipLaunchKernelGGL(argmin_scan_small, dim3(1), dim3(256), lds, stream, ll, n, flat_begin, start, result, host_mirror, scan,
+                       queue_count);
+    return hipGetLastError();
+}
 
 hipError_t launch_ll_fix_list(const DevModel &m, const TileView &tv, const PointSource &src, double *ll,
                               const SubList &list, hipStream_t stream)

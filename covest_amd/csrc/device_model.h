@@ -26,6 +26,7 @@ struct DevModel {
     int32_t k, r, n_err;
     double comb[kMaxErr];    // self.comb[s]                       covest/models.py:25
     double pow3neg[kMaxErr]; // 3 ** -s, libm pow on the host      covest/models.py:77
+    double ln_comb[kMaxErr]; // ln comb[s] (host libm; -inf for the padding classes): streams.h StreamSet::init
     double lo[kMaxParams];   // self.bounds, NaN = None            covest/models.py:23,179
     double hi[kMaxParams];
     double tail;

@@ -45,6 +45,46 @@ __device__ __forceinline__ double fma_vvv(double a, double b, double c)
     return d;
 }
 
+// exp(x) 2^sc: the device library's algorithm (ocml expD: x = n ln 2 + t by Cody-Waite, a degree-11 polynomial in t,
+// |t| <= 0.347, ldexp) with its OWN coefficients, written so that none of them lives in a vector register.  Inlined from
+// the library the eleven coefficients are loop invariants that the compiler parks in 22 VGPRs for the whole key walk of
+// a recurrence kernel (and copies into the v_fmac destination before every use, a full-rate v_mov_b64 each): a sixth
+// of K-basic's register file -- round 5, found in the ISA of ll_basic_kernel<true>, which spilled 266 registers.  Here
+// every coefficient is a scalar operand of a three-address v_fma_f64 (the scalar unit re-creates it with two s_mov).
+// The power of two is applied by the final v_ldexp_f64 -- exactly, one rounding in all, where the result is a normal
+// double -- so a caller that wants exp(x) 2^540 (streams.h) no longer adds ln 2^540 to the argument or scales twice.
+// x = -inf gives 0, NaN propagates, results beyond the doubles' range are +inf / 0 as v_ldexp_f64 rounds them.
+__device__ __forceinline__ double exp_scaled(double x, int sc)
+{
+#ifdef COVEST_AB_EXP_LIB
+    return ldexp(exp(x), sc);
+#endif
+    const double dn = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double t = fma(-dn, 0x1.62e42fefa39efp-1, x);
+    t = fma(-dn, 0x1.abc9e3b39803fp-56, t);
+    // (the first Horner step as two instructions with one scalar operand each -- gfx950's VOP3 reads ONE scalar pair --
+    // behind asm: left to the compiler the pair is contracted into a v_fmac whose addend is hoisted into a VGPR pair)
+    double p;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(p) : "v"(t), "s"(0x1.ade156a5dcb37p-26));
+    asm("v_add_f64 %0, %1, %2" : "=v"(p) : "v"(p), "s"(0x1.28af3fca7ab0cp-22));
+    p = fma_vvs(t, p, 0x1.71dee623fde64p-19);
+    p = fma_vvs(t, p, 0x1.a01997c89e6b0p-16);
+    p = fma_vvs(t, p, 0x1.a01a014761f6ep-13);
+    p = fma_vvs(t, p, 0x1.6c16c1852b7b0p-10);
+    p = fma_vvs(t, p, 0x1.1111111122322p-7);
+    p = fma_vvs(t, p, 0x1.55555555502a1p-5);
+    p = fma_vvs(t, p, 0x1.5555555555511p-3);
+    p = fma_vvs(t, p, 0x1.000000000000bp-1);
+    p = fma(t, p, 1.0);
+    p = fma(t, p, 1.0);
+    // (|x| beyond 1100: the result is 0 or +inf whatever the polynomial says; keeps n + sc inside the ints)
+    const int n = (int)fmin(fmax(dn, -4096.0), 4096.0);
+    const double z = ldexp(p, n + sc);
+    return x == -INFINITY ? 0.0 : z;
+}
+
+__device__ __forceinline__ double exp_fast(double x) { return exp_scaled(x, 0); }
+
 // log(x) for finite x > 0 (subnormals included).  NaN propagates.  x == 0 gives a finite
 // value (callers handle p_j <= 0 themselves).
 __device__ __forceinline__ double fast_log(double x, const double *tab_lds)

@@ -48,7 +48,9 @@ int fail_hip(hipError_t e, const char *what);
 // best fit.  host_common.cpp.
 bool dev_cache_take(size_t bytes, void **ptr, size_t *cap);
 bool dev_cache_give(void *ptr, size_t cap);
-// ... and the 64 page-locked, device-mapped bytes a grid handle's arg-min writes its winner to
+// ... and the page-locked, device-mapped block (kPinnedBlockBytes) a grid handle's arg-min writes to: the winner in the
+// first 64 bytes, the records of the selection scan (kernels.h ScanRecords) behind them
+constexpr size_t kPinnedBlockBytes = 2048;
 void *pinned_block_take();
 void pinned_block_give(void *p);
 
@@ -241,7 +243,18 @@ struct covest_grid {
     const char *last_kernel = "none";
     int last_kernel_id = 0;
     hipStream_t last_stream = nullptr;
-    ArgminResult *result_host = nullptr; // page-locked mirror of `result`
+    ArgminResult *result_host = nullptr; // page-locked mirror of `result` (+ the scan's records: scan_host())
+    ScanRecords *scan_host() const { return reinterpret_cast<ScanRecords *>(reinterpret_cast<char *>(result_host) + 64); }
+    bool scan_valid = false; // the last evaluation left the records of the selection scan (covest_grid_eval_scan)
+    // covest_grid_reset stages what it uploads in page-locked memory OF THE HANDLE and copies asynchronously (the null
+    // stream; an evaluation on another stream waits for upload_ev): the kernels queue up behind the copies and an
+    // optimize_grid iteration waits for the device once, when it reads its result.  The staging memory of one reset
+    // stays untouched until the next (stage_off only grows; a buffer that must grow waits for the copies first).
+    HostBuf stage;
+    size_t stage_off = 0;
+    bool async_uploads = false;
+    bool upload_pending = false;
+    hipEvent_t upload_ev = nullptr;
     bool evaluated = false;
     bool configured = false; // false while (and after) a covest_grid_reset failed half way: the views may dangle
     // optional hipEvent bracketing of the likelihood kernel
@@ -301,6 +314,14 @@ int upload_bins(DevBuf &buf, BinView &view, const std::vector<double> &key, cons
                 const std::vector<double> &cnt);
 int build_tiles(covest_model *m, std::vector<HostBin> bins);
 double clamp_for(const covest_model *m, int t_max); // p_clamp of direct_point.h for a launch whose largest threshold_o is t_max
+
+// ---- abi_grid.cpp: staging of a grid handle's uploads (see covest_grid::stage)
+struct StageSlot {
+    char *ptr = nullptr;
+    std::unique_lock<std::mutex> shared_hold; // held while the process-wide staging buffer is in use (blocking path)
+};
+int grid_stage_begin(covest_grid *g, size_t bytes, StageSlot &slot);
+int grid_stage_commit(covest_grid *g, StageSlot &slot, void *dst, size_t bytes);
 
 // ---- plan_factored.cpp
 double copy_number_weight_host(double q1, double q2, double q, int o);

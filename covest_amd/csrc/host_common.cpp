@@ -108,7 +108,7 @@ void *pinned_block_take()
             }
     }
     void *p = nullptr;
-    if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) {
+    if (hipHostMalloc(&p, kPinnedBlockBytes, hipHostMallocMapped) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }

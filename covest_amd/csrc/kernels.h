@@ -63,6 +63,21 @@ constexpr int64_t kArgminSmall = 16384; // grids up to this size: one workgroup,
 hipError_t launch_argmin(const double *ll, int64_t n, int64_t flat_begin, double *partial_val, int64_t *partial_idx,
                          ArgminResult *result, ArgminResult *host_mirror, unsigned *queue_count, hipStream_t stream);
 
+// The same reduction and, beside it, the selection scan of covest/grid.py:65-70 started from `start`: the strict
+// running-minimum records below it, in index order, written to `scan` (page-locked host memory).  n <= kArgminSmall.
+constexpr int kScanCap = 120;
+struct ScanRecords {
+    int32_t n;         // records listed (written LAST, behind a system-scope fence)
+    int32_t truncated; // 1: there were more than kScanCap -- read the values back instead
+    double start;      // the minimum the scan started from (echo)
+    struct {
+        int64_t index; // GLOBAL flat index
+        double negll;
+    } rec[kScanCap];
+};
+hipError_t launch_argmin_scan(const double *ll, int64_t n, int64_t flat_begin, double start, ArgminResult *result,
+                              ArgminResult *host_mirror, ScanRecords *scan, unsigned *queue_count, hipStream_t stream);
+
 // ---- K-kmer: k-mer abundance histogram (kmer_count.hip), SURVEY 8(f) row F1 ----
 // Open-addressing table in HBM, slots = 2^log2_slots, one 16-byte entry per slot: {key, count}
 // (key all-ones = empty).  Key and count share a cache line on purpose: a k-mer costs ONE scattered

@@ -102,9 +102,15 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     // its log, the 2^-64 folded into the log's exponent arithmetic (all branches wave-uniform)
     const double clamp_s = p_clamp * kBasicScale;
     const double zero_s = zero_steps_scaled(kBasicScale);
+    // (TAIL: sp_j -- math.fsum of the p_j, covest/models.py:103 -- is summed plainly over the <= 32 keys of a tile,
+    // terms of one sign, and the compensated accumulator gets one value per tile: a relative 32 eps at worst, where the
+    // p_j themselves carry a few eps each.  Round 5: until then every key went through the two-sum, six dependent
+    // instructions a key on ONE chain through the whole walk; the compiler hid that chain behind the logs of many keys
+    // at once and spilled 266 registers doing so.)
+    double tile_sp = 0.0;
     auto account = [&](double ps, double h, int row) {
         if (TAIL)
-            acc_sp.add(ps); // (filler keys have scale 0: p == 0)
+            tile_sp += ps; // (filler keys have scale 0: p == 0)
         if (h != 0.0) { // filler keys and zero counts: no log (`if h`, covest/models.py:106)
             // log(max(p_j, p_clamp)): what a p_j deep in the subnormal range contributes is then a known constant,
             // which the strict evaluation of that key replaces later (direct_point.h); p_j = 0 is remembered below
@@ -125,8 +131,9 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
         }
     };
 
-    // One key tile with the streams 0 .. N-1 (N = S: all of them; N = 1: see below).
-    auto do_tile = [&](auto n_tag, int t, bool force_start) __attribute__((always_inline)) {
+    // One key tile with the streams 0 .. N-1 (N = S: all of them; N = 1: see below).  ll_done (wave-uniform, TAIL only):
+    // the tile's share of sum h_j log p_j is accounted for already (the closed form below) -- its keys only enter sp_j.
+    auto do_tile = [&](auto n_tag, int t, bool force_start, bool ll_done) __attribute__((always_inline)) {
         constexpr int N = decltype(n_tag)::value;
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
@@ -137,13 +144,17 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
         double xx[S]; // squared rates, recomputed per tile (N multiplies) rather than held in 2 S registers
         if (nb == kTileBins) {
 #pragma unroll
-            for (int s = 0; s < S; ++s)
-                xx[s] = s < N ? st.x[s] * st.x[s] : 0.0;
+            for (int s = 0; s < S; ++s) {
+                double xs = st.x[s];
+                if (TAIL && s < N) // (the empty asm: the squares are made per tile, not hoisted out of the walk and held --
+                    asm volatile("" : "+v"(xs)); // with a tail the walk's registers are short: 4 spilled at 3 waves a SIMD)
+                xx[s] = s < N ? xs * xs : 0.0;
+            }
         }
-        if (TAIL && tv.all_zero[t] != 0) {
-            // a tile without a single count (they exist only with a tail): its keys take no log, only their
-            // p_j enter sp_j (covest/models.py:103) -- add them up plainly (32 terms of one sign) and hand the
-            // compensated accumulator ONE value per tile
+        if (TAIL && (ll_done || tv.all_zero[t] != 0)) {
+            // a tile without a single count (they exist only with a tail), or one whose logs the closed form has
+            // taken care of: its keys take no log, only their p_j enter sp_j (covest/models.py:103) -- add them up
+            // plainly (32 terms of one sign) and hand the compensated accumulator ONE value per tile
             double tile_sum = 0.0;
             if (nb == kTileBins) {
 #pragma unroll
@@ -165,7 +176,9 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
                     tile_sum = fma(st.template step_n<N>(), scal[b], tile_sum);
             }
             acc_sp.add(tile_sum);
+            tile_sp = 0.0;
         } else if (nb == kTileBins) {
+            tile_sp = 0.0;
             // full tile: two straight-line halves of 16 keys, their scales and counts fetched
             // into SGPRs up front (s_load_dwordx16) so no key waits on the scalar cache; the
             // streams advance two keys per step (streams.h step2)
@@ -186,9 +199,12 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
                 }
             }
         } else {
+            tile_sp = 0.0;
             for (int b = 0; b < nb; ++b)
                 account(st.template step_n<N>() * scal[b], cnt[b], t * kTileBins + b);
         }
+        if (TAIL)
+            acc_sp.add(tile_sp);
         st.template leave_tile_n<N>(tv.renorm[t]);
     };
     // The rates of the error classes fall geometrically (covest/models.py:74-79): along the keys the streams go out
@@ -204,9 +220,9 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
         }
         if (st.only_first_left())
             break;
-        do_tile(std::integral_constant<int, S>{}, t, false);
+        do_tile(std::integral_constant<int, S>{}, t, false, false);
     }
-    // CLOSED FORM for the rest (round 3).  With one stream left and no tail, p_j = a_0 TP(x_0, j) for every later key
+    // CLOSED FORM for the rest (round 3).  With one stream left, p_j = a_0 TP(x_0, j) for every later key
     // -- the other classes' terms are below e^-760, exact zeros in the reference's doubles too -- so
     //     log p_j = c_0 + j ln x_0 - ln j!        (c_0 = ln a_0 - D(x_0): the stream's anchor constants, streams.h)
     // and the rest of the sum over the counted keys is three multiply-adds against sums the host made once per
@@ -217,17 +233,24 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     // a_0 <= 1) and the sum -inf (utils.safe_log).  A lane in between -- a p_j near or in the subnormal range -- sends
     // its WAVE through the key-by-key walk, which names the rows for the strict evaluation; in a grid that is a band
     // a few points wide.  C2 spends 330 of its 367 keys here.
+    // Round 5: WITH A TAIL the same.  What a tail adds is sp_j = sum of p_j over EVERY key (covest/models.py:103), and
+    // that needs the walk -- but a walk that only sums: two instructions a key for the one stream that is left, against
+    // twenty with the log.  So the decision below is taken as without a tail, the closed form supplies the logs' sum
+    // wherever it stands, and the tiles it covers are walked for their sum alone (do_tile with ll_done).  Until then a
+    // histogram with a tail -- what every real CovEst run hands the model, covest/histogram.py:105-134 -- took a log per
+    // key and point: C2 on all 10 000 keys 1.64 ms against 0.17 without the tail.
     bool walk_rest = t < tv.n_tiles;
+    bool sums_only = false; // (TAIL, wave-uniform) the logs of all the remaining tiles are accounted for
 #ifdef COVEST_DIAG
     // the point's route, for tools/dump_c2_classes.py: 0 the closed form was never asked (every tile walked with all
-    // streams, a tail, or no counted key left), 1 closed form taken, 2 -inf by its bound, 3 a lane that would have taken
+    // streams, or no counted key left), 1 closed form taken, 2 -inf by its bound, 3 a lane that would have taken
     // 1 or 2 but whose WAVE walks because of another lane, 4 a lane that sends its wave through the walk
     double diag_class = 0.0, diag_lp = NAN;
 #endif
-    if (!TAIL && walk_rest) {
+    if (walk_rest) {
         const double first = tv.suf_first[t];
         if (first == 0.0) {
-            walk_rest = false; // (wave-uniform) no counted key is left
+            sums_only = true; // (wave-uniform) no counted key is left
         } else {
             const double lx0 = st.an.lx(0), c0 = st.an.c(0);
             const double lp_first = fma(first, lx0, c0 - tv.suf_first_lg[t]);
@@ -241,7 +264,7 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
             diag_class = (finite && !fine && !none) ? 4.0 : diag_walks ? 3.0 : fine ? 1.0 : 2.0;
 #endif
             if (!__any(finite && !fine && !none)) { // wave-uniform
-                walk_rest = false;
+                sums_only = true;
                 dead |= __ballot(none && !fine);
                 if (fine)
                     acc_ll += fma(c0, tv.suf_h[t], fma(lx0, tv.suf_jh[t], -tv.suf_lgh[t]));
@@ -253,27 +276,32 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     // the strict evaluation and no zero, and its share of the sum is the closed form again -- three multiply-adds
     // against the tile's own sums (differences of the suffix sums).  Only the tiles some lane comes near the clamp in
     // are walked key by key -- for C2 the last two or three of the forty the walk used to take, which was a sixth of
-    // the kernel's instructions; the stream is anchored afresh behind skipped tiles, as at the start of a run.
-    if (walk_rest && !TAIL) {
+    // the kernel's instructions; without a tail the other tiles are skipped and the stream is anchored afresh behind
+    // them, as at the start of a run; with one they are walked for their sums.  (ONE call of do_tile for all of this:
+    // it is inlined, a thousand instructions a copy.)
+    if (walk_rest && (TAIL || !sums_only)) {
         const double lx0 = st.an.lx(0), c0 = st.an.c(0);
         bool skipped = false;
         for (; t < tv.n_tiles; ++t) {
-            const double k0 = tv.first_key[t];
-            const double lp_lo = fma(k0 - 1.0, lx0, c0 - tv.lgam_prev[t]); // (at the key before the tile: a superset)
-            const double lp_hi = fma(k0 + (double)(tv.n_bins[t] - 1), lx0, c0 - tv.lgam_last[t]);
-            const bool near = !(fmin(lp_lo, lp_hi) > sub_list.log_p_clamp + 0.5); // (a stream that is off, a NaN: near)
-            if (__any(finite && near)) { // wave-uniform
-                do_tile(std::integral_constant<int, 1>{}, t, skipped);
-                skipped = false;
-            } else {
-                acc_ll += fma(c0, tv.suf_h[t] - tv.suf_h[t + 1],
-                              fma(lx0, tv.suf_jh[t] - tv.suf_jh[t + 1], -(tv.suf_lgh[t] - tv.suf_lgh[t + 1])));
-                skipped = true;
+            bool ll_done = sums_only;
+            if (!sums_only) {
+                const double k0 = tv.first_key[t];
+                const double lp_lo = fma(k0 - 1.0, lx0, c0 - tv.lgam_prev[t]); // (at the key before the tile: a superset)
+                const double lp_hi = fma(k0 + (double)(tv.n_bins[t] - 1), lx0, c0 - tv.lgam_last[t]);
+                const bool near = !(fmin(lp_lo, lp_hi) > sub_list.log_p_clamp + 0.5); // (a stream that is off, a NaN: near)
+                if (!__any(finite && near)) { // wave-uniform
+                    acc_ll += fma(c0, tv.suf_h[t] - tv.suf_h[t + 1],
+                                  fma(lx0, tv.suf_jh[t] - tv.suf_jh[t + 1], -(tv.suf_lgh[t] - tv.suf_lgh[t + 1])));
+                    ll_done = true;
+                    if (!TAIL) {
+                        skipped = true;
+                        continue;
+                    }
+                }
             }
+            do_tile(std::integral_constant<int, 1>{}, t, skipped, ll_done);
+            skipped = false;
         }
-    } else if (walk_rest) {
-        for (; t < tv.n_tiles; ++t)
-            do_tile(std::integral_constant<int, 1>{}, t, false);
     }
 
     double tail_term = 0.0;
@@ -308,7 +336,7 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
 
 // The case the reference's `main` builds (max_error = 8): 4 waves per SIMD at 128 registers.
 template <bool TAIL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ll_basic_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ? 3 : 4, TAIL ? 3 : 4))) void ll_basic_kernel(
     const DevModel m, const int32_t n_tiles, const int32_t n_items, const double *__restrict__ tile_dbl,
     const int32_t *__restrict__ tile_int, const PointSource src, const int64_t n, double *__restrict__ out_ll,
     SubList sub_list)

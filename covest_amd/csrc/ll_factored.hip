@@ -60,6 +60,10 @@
 #include "streams.h"
 #include "wave.h"
 
+#ifndef COVEST_AB_FACTORED_CANCEL
+#define COVEST_AB_FACTORED_CANCEL 0
+#endif
+
 namespace covest {
 
 namespace {
@@ -120,7 +124,17 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     constexpr int NW = NT / kWave;
     constexpr int MU = 2 * HU; // accumulator slots per wave (6: the specialised step loops below assume it)
     static_assert(MU == 6, "contract loops are written for 6 slots");
-    constexpr bool NEED_SCAL = TAIL || !PLAIN; // p_j itself is needed somewhere: sp_j, or the chunks' shares
+    // SPO (round 5): a plain grid WITH A TAIL sums sp_j -- the sum of p_j over EVERY key, covest/models.py:103 -- per COPY
+    // NUMBER in phase A instead of per weight vector in phase C:
+    //     sp_q = sum_j sum_o b_o(q) G[o][j] = sum_o b_o(q) S[o],   S[o] = sum_j G[o][j]  (scaled: sum_j scal_j G'[j][o]),
+    // one fused multiply-add a key in the builder lane that holds G'[j][o] in a register anyway, a compensated add a tile,
+    // and ONE extra contraction at the very end whose two rows are S (hi, lo) -- instead of a multiply and a two-sum
+    // (seven dependent instructions) per row, unit and tile in phase C, twelve accumulator registers a lane, and a
+    // contraction per thirty-two count-less tiles.  The tiles without a count then only cost their walk, and a unit
+    // whose sums are all -inf needs nothing more at all (the tail term is finite or 0): the dead-unit skip and the
+    // last-tile-first order of the tail-less grids apply.
+    constexpr bool SPO = PLAIN && TAIL;
+    constexpr bool NEED_SCAL = !PLAIN; // p_j itself is needed row by row: the chunks' shares, a point list's sp_j
     constexpr int LOG_DEG = PLAIN ? 4 : 5;     // (point lists keep the 2e-16 log: refinements difference their values)
     const int LD = LDC ? LDC : plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
@@ -213,8 +227,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // dividing and taking ln a_os: 30 KB less code, the same bits -- 0.705 against 0.702 ms: no gain, although the three
     // waves that build nothing wait 23 k ticks at the first barrier by the stamps of the diagnostic build)
     if (wave_builds) { // (wave-uniform) the waves that build nothing skip the mixture weights' exps, divisions and logs
-        st.init(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab, log_tab, 8 * my_pass,
-                n_total);
+        // (the stream constants by the reference's own route for every lane: the lanes of a wave are copy numbers, their
+        // rates o x lambda_s span all three regimes of StreamSet::init's shortcut, and a wave that takes all three pays more
+        // than the one route costs -- measured: C3 + 1.7 % with the shortcut)
+        st.template init<COVEST_AB_FACTORED_CANCEL != 0>(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab,
+                                                        log_tab, 8 * my_pass, n_total);
     } else {
         st.gone = 0u;
 #pragma unroll
@@ -245,7 +262,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // (small threshold_o against large keys): 13 % of C3's logs.  Wave-uniform, bit k = slot k and its pieces.
     unsigned off_slots = 0;
     bool newly_dead = false; // a column of this wave's met its first zero in the item just logged
-    CompSum spacc[MU];
+    CompSum spacc[(TAIL && !SPO) ? MU : 1]; // (a point list's sp_j: per row, in phase C)
+    CompSum so = {0.0, 0.0};                // (SPO, builder lanes) S[o] of this lane's copy number, times 2^SC
     // wave w's block of MU slots in the unit tables
     auto wave_block = [&](int w) -> int {
         if (list) // block 0 is empty (waves with no unit); point i owns blocks 1 + 2 i and 2 + 2 i, for the last two waves
@@ -276,8 +294,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         r4[k] = plan.q_r4[slot];
         llacc[k] = 0.0;
         dead[k] = 0;
-        spacc[k].hi = 0.0;
-        spacc[k].lo = 0.0;
+        spacc[(TAIL && !SPO) ? k : 0].hi = 0.0;
+        spacc[(TAIL && !SPO) ? k : 0].lo = 0.0;
     }
 
     // what kind of slot k is, as bit k of a mask (wave-uniform; tested once per tile and slot): the first slot of a unit
@@ -318,10 +336,20 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
 #endif
     // the 32 keys of a full tile with the streams 0 .. N-1 (the others are zero in every lane of the wave).  One
     // region under the row mask, straight-line inside: the sums go to LDS as they stand (no scale, see above)
-    auto walk_tile = [&](auto n_tag, double *colp, double renorm) __attribute__((always_inline)) {
+    // SPO: returns sum_b u_b 2^SC of this lane's copy number over the tile's 32 keys (u_b: the true terms' sum at key
+    // b, streams.h) WITHOUT the keys' 32 scales: with  W_b = (u_0 + .. + u_b) / scal_b,  scal_(b-1) / scal_b = k0 + b
+    // (tiles.h) gives
+    //     W_b = W_(b-1) (k0 + b) + g_b,          g_b = the streams' sum at key b, what goes to LDS anyway,
+    // a fused multiply-add and an add a key on a counter that holds the key as a double (exact: keys <= 16384), and the
+    // tile's sum is W_31 scal_31 = W_31 renorm 2^-SC.  W stays inside the range the streams' own terms are scaled for
+    // (partial sums <= 2.5: at most 2.5 x 2^540 x 1e140).  No scalar is fetched in the walk (the tile's 32 scales
+    // through scalar registers cost the TAIL variants 45 more spilled scalars and an exposed scalar-cache latency a
+    // half).  Tiles with a FILLER key (a gap of the histogram: its scale is 0, it must add nothing) and short tiles
+    // take the key-by-key path of build_tile with the scales.
+    auto walk_tile = [&](auto n_tag, double *colp, double renorm, double k0) __attribute__((always_inline)) -> double {
         constexpr int N = decltype(n_tag)::value;
         if (!lane_in_row)
-            return; // (lanes past the row hold no copy number: nothing of theirs is ever read)
+            return 0.0; // (lanes past the row hold no copy number: nothing of theirs is ever read)
         // squared rates (the streams advance two keys per step, streams.h step2): N multiplies per tile
         // rather than 16 registers held through phases B and C -- the empty asm keeps the compiler from
         // hoisting them back out of the tile loop (it would spill them)
@@ -337,19 +365,38 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
         }
         double *row = colp; // (walked row by row: one vector add a store, no scalar multiply by the row's number)
+        double tsum = 0.0;
+        if (SPO) {
+            double kk = k0; // the key of row b
 #pragma unroll
-        for (int b = 0; b < kTileBins; b += 2) {
-            double g1, g2;
-            st.template step2n<N>(xx, g1, g2);
-            row[0] = g1;
-            row[LD] = g2;
-            row += 2 * LD;
+            for (int b = 0; b < kTileBins; b += 2) {
+                double g1, g2;
+                st.template step2n<N>(xx, g1, g2);
+                row[0] = g1;
+                row[LD] = g2;
+                row += 2 * LD;
+                tsum = fma(tsum, kk, g1);
+                kk += 1.0;
+                tsum = fma(tsum, kk, g2);
+                kk += 1.0;
+            }
+            tsum *= renorm;
+        } else {
+#pragma unroll
+            for (int b = 0; b < kTileBins; b += 2) {
+                double g1, g2;
+                st.template step2n<N>(xx, g1, g2);
+                row[0] = g1;
+                row[LD] = g2;
+                row += 2 * LD;
+            }
         }
         st.template leave_tile_n<N>(renorm);
+        return tsum;
     };
-    auto build_tile = [&](int t, bool seg_start, double *dst) __attribute__((always_inline)) {
+    auto build_tile = [&](int t, bool seg_start, double *dst) __attribute__((always_inline)) -> double {
         if (COVEST_SKIP_PHASE(plan, 1))
-            return;
+            return 0.0;
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
         // n_live: streams above it are zero in every lane of this wave (streams.h) -- most of them, for most tiles
@@ -361,35 +408,40 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             dg_t0 = now__;
         }
         double *colp = dst + (lane_in_row ? tid : 0);
-        if (nb == kTileBins) { // the common case: straight-line code
-            if (n_live > 4) {
-                walk_tile(std::integral_constant<int, 8>{}, colp, tv.renorm[t]);
-            } else if (n_live > 2) {
-                walk_tile(std::integral_constant<int, 4>{}, colp, tv.renorm[t]);
-            } else if (n_live == 2) {
-                walk_tile(std::integral_constant<int, 2>{}, colp, tv.renorm[t]);
-            } else if (n_live == 1) {
-                walk_tile(std::integral_constant<int, 1>{}, colp, tv.renorm[t]);
-            } else if (lane_in_row) { // nothing is on: G = 0 for this wave's copy numbers
+        const double *scal = tv.scal + (int64_t)t * kTileBins;
+        if (nb == kTileBins && !(SPO && tv.has_filler[t] != 0)) { // the common case: straight-line code
+            if (n_live > 4)
+                return walk_tile(std::integral_constant<int, 8>{}, colp, tv.renorm[t], k0);
+            if (n_live > 2)
+                return walk_tile(std::integral_constant<int, 4>{}, colp, tv.renorm[t], k0);
+            if (n_live == 2)
+                return walk_tile(std::integral_constant<int, 2>{}, colp, tv.renorm[t], k0);
+            if (n_live == 1)
+                return walk_tile(std::integral_constant<int, 1>{}, colp, tv.renorm[t], k0);
+            if (lane_in_row) { // nothing is on: G = 0 for this wave's copy numbers
                 if (diag)
                     dg_zero += 1;
 #pragma unroll
                 for (int b = 0; b < kTileBins; ++b)
                     colp[b * LD] = 0.0;
             }
-            return;
+            return 0.0;
         }
+        double tsum = 0.0;
         for (int b = 0; b < kTileBins; ++b) { // (rows past the tile's keys: 0 -- they carry no count and no scale)
             const double g = b < nb ? st.step() : 0.0;
+            if (SPO && b < nb)
+                tsum = fma(g, scal[b], tsum);
             if (lane_in_row)
                 colp[b * LD] = g;
         }
         st.leave_tile(tv.renorm[t]);
+        return tsum * 0x1p476; // (tv.scal carries 2^(kBasicShift - SC); S[o] is kept times 2^SC: exact)
     };
     // The same walk over a tile WITHOUT counts (tail != 0 only): sum_j G[o][j] over its keys stays in a register
     // -- 32 terms of one sign added plainly, the compensated accumulator of phase C gets their contraction --
     // and is returned instead of 32 stores.  These rows ARE scaled (a sum over keys needs every key's own scale).
-    auto sum_tile = [&](auto n_tag, const double *scal, double renorm) __attribute__((always_inline)) -> double {
+    auto sum_tile = [&](auto n_tag, const double *scal_ptr, double scal_or_k0, double renorm) __attribute__((always_inline)) -> double {
         constexpr int N = decltype(n_tag)::value; // the live streams, as in walk_tile
         double xx[8];
 #pragma unroll
@@ -403,6 +455,21 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
         }
         double gsum = 0.0;
+        if (SPO) { // (the W recurrence of walk_tile: no scales; `scal` is the tile's first key here, as a double)
+            double kk = scal_or_k0;
+#pragma unroll
+            for (int b = 0; b < kTileBins; b += 2) {
+                double g1, g2;
+                st.template step2n<N>(xx, g1, g2);
+                gsum = fma(gsum, kk, g1);
+                kk += 1.0;
+                gsum = fma(gsum, kk, g2);
+                kk += 1.0;
+            }
+            st.template leave_tile_n<N>(renorm);
+            return gsum * renorm;
+        }
+        const double *scal = SPO ? nullptr : scal_ptr;
         // two halves of 16 keys, each half's scales fetched into scalar registers up front (one s_load_dwordx16 pair,
         // as K-basic does): fetched pair by pair right before their use, every second key waited for the scalar cache
 #pragma unroll
@@ -429,20 +496,20 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
                                          tv.run_start[t] != 0 || seg_start);
         const double *scal = tv.scal + (int64_t)t * kTileBins;
-        if (nb == kTileBins) { // (the count-less tiles of a histogram's tail are full ones: the live streams only)
+        if (nb == kTileBins && !(SPO && tv.has_filler[t] != 0)) { // (the count-less tiles of a histogram's tail are full ones: the live streams only)
             if (n_live > 2)
-                return sum_tile(std::integral_constant<int, 8>{}, scal, tv.renorm[t]);
+                return sum_tile(std::integral_constant<int, 8>{}, scal, k0, tv.renorm[t]);
             if (n_live == 2)
-                return sum_tile(std::integral_constant<int, 2>{}, scal, tv.renorm[t]);
+                return sum_tile(std::integral_constant<int, 2>{}, scal, k0, tv.renorm[t]);
             if (n_live == 1)
-                return sum_tile(std::integral_constant<int, 1>{}, scal, tv.renorm[t]);
+                return sum_tile(std::integral_constant<int, 1>{}, scal, k0, tv.renorm[t]);
             return 0.0; // nothing is on
         }
         double gsum = 0.0;
         for (int b = 0; b < nb; ++b)
             gsum = fma(st.step(), scal[b], gsum);
         st.leave_tile(tv.renorm[t]);
-        return gsum * (1.0 / kBasicScale);
+        return SPO ? gsum * 0x1p476 : gsum * (1.0 / kBasicScale); // (SPO: S[o] is kept times 2^SC)
     };
     // One item into `dst`: a plain tile, or (TAIL) the per-tile sums of up to 32 count-less tiles as its rows.
     auto build_item = [&](int it, bool seg_start, double *dst) __attribute__((always_inline)) {
@@ -451,6 +518,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             if (COVEST_SKIP_PHASE(plan, 1))
                 return;
             const int n = __builtin_amdgcn_readfirstlane(tv.item_ntiles[it]);
+            if (SPO) { // the tiles without a count only enter S[o]: nothing is stored, nothing contracted
+                for (int r = 0; r < n; ++r)
+                    so.add(build_tile_sum(first + r, seg_start && r == 0));
+                return;
+            }
             double *colp = dst + (lane_in_row ? tid : 0);
             for (int r = 0; r < n; ++r) {
                 const double gsum = build_tile_sum(first + r, seg_start && r == 0);
@@ -461,7 +533,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 if (lane_in_row)
                     colp[r * LD] = 0.0;
         } else {
-            build_tile(first, seg_start, dst);
+            const double tsum = build_tile(first, seg_start, dst);
+            if (SPO)
+                so.add(tsum);
         }
     };
 
@@ -504,12 +578,27 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // rows alternate with the POSITION.  The streams are anchored afresh at the first position (the last tile: nothing
     // is on yet) and at the second (tile 0 is a run start anyway; what they know of the last tile -- `gone` -- is
     // forgotten there).
-    const bool last_first = PLAIN && !TAIL && t_end - t_begin >= 2;
-    auto tile_at = [&](int p) -> int { return last_first ? (p == t_begin ? t_end - 1 : p - 1) : p; };
+    // Round 5, WITH A TAIL (SPO): the same, with the last item that HOLDS A COUNT taken first (the items behind it are
+    // sums over count-less tiles: nothing dies there) -- sp_j no longer hangs on the contraction (S[o] above), and the
+    // streams are anchored afresh once more, at the item behind the one taken out of turn.
+    int last_item = t_end - 1; // the item taken first
+    if (SPO)
+        while (last_item > t_begin && tv.item_sum[last_item] != 0)
+            --last_item;
+    const bool last_first = PLAIN && t_end - t_begin >= 2 && last_item > t_begin;
+    auto tile_at = [&](int p) -> int { return last_first ? (p == t_begin ? last_item : (p <= last_item ? p - 1 : p)) : p; };
+    // SPO: one more position behind the items -- the contraction of S (rows 0 and 1 of the buffer: hi, lo)
+    const int t_endx = t_end + (SPO ? 1 : 0);
     fetch_rows(tile_at(t_begin));
-    for (int p = t_begin - (dbuf ? 1 : 0); p < t_end; ++p) {
+    for (int p = t_begin - (dbuf ? 1 : 0); p < t_endx; ++p) {
         const int pb = dbuf ? p + 1 : p;
-        if (pb < t_end) {
+        if (SPO && pb == t_end) {
+            if (wave_builds && lane_in_row) { // S[o] (x 2^-kBasicShift: exact) as the two rows of one more "item"
+                double *dst = Gs + (dbuf ? (pb & 1) * kTileBins * LD : 0) + tid;
+                dst[0] = so.hi * 0x1p-540;
+                dst[LD] = so.lo * 0x1p-540;
+            }
+        } else if (pb < t_end) {
             if (tid < kTileBins) { // read after the barrier that makes the item readable
                 rowc[pb & 1][tid] = make_double2(nxt_h, p_clamp * nxt_c);
                 if (NEED_SCAL)
@@ -519,14 +608,18 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             if (wave_builds) {
                 if (last_first && pb == t_begin + 1)
                     st.gone = 0u;
-                build_item(tile_at(pb), pb == t_begin || (last_first && pb == t_begin + 1),
+                build_item(tile_at(pb), pb == t_begin || (last_first && (pb == t_begin + 1 || pb == last_item + 1)),
                            Gs + (dbuf ? (pb & 1) * kTileBins * LD : 0));
             }
         }
         STAMP(dg_a)
         if (!dbuf)
             __syncthreads();
-        if (p >= t_begin) {
+        const bool sp_item = SPO && p == t_end; // (wave-uniform) the last position: S x b
+        // (SPO) where the units leave their shares of sp_j: [2][NW][MU][16] doubles in the buffer that is NOT contracted in
+        // the last interval (one buffer only: behind the two rows of S -- rows whose products nobody uses)
+        double *const sp_parts = dbuf ? Gs + ((t_end + 1) & 1) * kTileBins * LD + NW * MU * 16 : Gs + 2 * LD + NW * MU * 16;
+        if (p >= t_begin && !(SPO && !sp_item && tv.item_sum[tile_at(p)] != 0)) { // (SPO: a sum item was phase A only)
             const int t = tile_at(p); // the tile this interval contracts and logs
             const double *cur = Gs + (dbuf ? (p & 1) * kTileBins * LD : 0);
             // ================= phase B: P' = G' x b on the matrix pipe =================
@@ -662,7 +755,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 }
             STAMP(dg_b)
             // ================= phase C: h_j * log p_j from the accumulators =================
-            const bool item_is_sum = TAIL && tv.item_sum[t] != 0; // wave-uniform
+            const bool item_is_sum = TAIL && !SPO && tv.item_sum[t] != 0; // wave-uniform
             // f64 C/D layout: register r of a lane is row (lane>>4) + 4r, column lane&15.
 #pragma unroll
             for (int k = 0; k < MU; ++k) {
@@ -689,7 +782,16 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     }
                     continue;
                 }
-                if (TAIL && item_is_sum) { // rows are sums over count-less tiles (scaled ones): they only enter sp_j
+                if (SPO && sp_item) {
+                    // rows 0 and 1 are S (hi, lo): register 0 of the lanes with kq = 0 and kq = 1 holds this column's
+                    // sum_o b_o S_hi[o] and sum_o b_o S_lo[o].  Straight to where the last step below looks for them
+                    // (sp_parts: LDS nobody reads any more) -- held in registers until then they would be carried through
+                    // every interval of the walk.  A dead unit writes its zeros: its sum is -inf whatever sp_j is.
+                    if (qslot[k] >= 0 && !cont[k] && uhalf[k] == 0 && lane < 32)
+                        sp_parts[(kq * NW * MU + wave * MU + k) * 16 + col] = acc[k][0];
+                    continue;
+                }
+                if (TAIL && !SPO && item_is_sum) { // rows are sums over count-less tiles (scaled ones): they only enter sp_j
                     if ((m_first >> k) & 1u) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -712,7 +814,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                         h4[r] = hc.x;
                         c4[r] = hc.y;
                     }
-                    if (TAIL) { // sp_j needs p_j itself (filler and padding keys: scale 0), before the clamp
+                    if (TAIL && !SPO) { // sp_j needs p_j itself (filler and padding keys: scale 0), before the clamp
                         const double *sr = &rows[NEED_SCAL ? (p & 1) : 0][NEED_SCAL ? 16 * uhalf[k] + kq : 0];
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -827,7 +929,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     //      halves of each q-tile (they may live on different waves) through LDS ----
     const double lconst = lconst_s; // (read before the buffer below is reused: lconst_s is static LDS of its own)
     double *part_ll = Gs;                               // [NW][MU][16]
-    double *part_hi = Gs + (size_t)NW * MU * 16; // compensated sp_j parts
+    // compensated sp_j parts (SPO: where the last contraction left them -- behind part_ll if that is buffer 0)
+    double *part_hi = !SPO ? Gs + (size_t)NW * MU * 16
+                           : (plan.n_buf == 2 ? Gs + ((t_end + 1) & 1) * kTileBins * LD : Gs + 2 * LD) + NW * MU * 16;
     double *part_lo = part_hi + (size_t)NW * MU * 16;
     load_weights(); // (the slots' first weights once more: a NaN column is a NaN in them)
 #pragma unroll
@@ -841,8 +945,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             ll = isnan(ll) ? ll : -INFINITY; // h * -inf summed with finite terms
         ll += __shfl_xor(ll, 16, kWave);
         ll += __shfl_xor(ll, 32, kWave);
-        CompSum sp = spacc[k];
-        if (TAIL) {
+        CompSum sp = spacc[(TAIL && !SPO) ? k : 0];
+        if (TAIL && !SPO) {
 #pragma unroll
             for (int off = 16; off <= 32; off <<= 1) {
                 const double ohi = __shfl_xor(sp.hi, off, kWave);
@@ -855,7 +959,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         if (lane < 16) {
             const int at = (wave * MU + k) * 16 + lane;
             part_ll[at] = ll;
-            if (TAIL) {
+            if (TAIL && !SPO) {
                 part_hi[at] = sp.hi;
                 part_lo[at] = sp.lo;
             }
@@ -888,7 +992,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         if (TAIL) {
             hi = part_hi[e];
             lo = part_lo[e];
-            if (pe >= 0) {
+            if (pe >= 0 && !SPO) { // (SPO: the half-0 unit alone contracted S)
                 double err;
                 two_sum(hi, part_hi[pe], hi, err);
                 lo += part_lo[pe] + err;

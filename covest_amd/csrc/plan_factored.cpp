@@ -301,12 +301,14 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     double *dbase = buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
     {
-        // staged on the host in the device layout, ONE copy (a dozen small copies cost ~150 us of the plan build)
+        // staged on the host in the device layout, ONE copy (a dozen small copies cost ~150 us of the plan build);
+        // blocking through the process's staging buffer, or asynchronous through the handle's own (covest_grid_reset)
         const size_t stage_bytes = n_dbl * sizeof(double) + n_int * sizeof(int32_t);
-        SharedStage &ss = shared_stage();
-        std::lock_guard<std::mutex> hold(ss.mu);
-        HIP_TRY(ss.buf.reserve(stage_bytes));
-        double *sd = ss.buf.as<double>();
+        StageSlot slot;
+        const int src = grid_stage_begin(g, stage_bytes, slot);
+        if (src != COVEST_OK)
+            return src;
+        double *sd = reinterpret_cast<double *>(slot.ptr);
         int32_t *si = reinterpret_cast<int32_t *>(sd + n_dbl);
         std::copy(r4.begin(), r4.end(), sd);
         std::copy(piece_w.begin(), piece_w.end(), sd + n_slots);
@@ -322,7 +324,9 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
         std::copy(unit_cont.begin(), unit_cont.end(), sp + 5 * n_unit);
         std::copy(unit_nsh.begin(), unit_nsh.end(), sp + 6 * n_unit);
         std::copy(unit_pair.begin(), unit_pair.end(), sp + 7 * n_unit);
-        HIP_TRY(hipMemcpy(buf.ptr, sd, stage_bytes, hipMemcpyHostToDevice));
+        const int crc = grid_stage_commit(g, slot, buf.ptr, stage_bytes);
+        if (crc != COVEST_OK)
+            return crc;
     }
     pl = FactoredPlan{};
     pl.c_axis = g->src.axis[0];

@@ -134,7 +134,7 @@ __device__ __forceinline__ double copy_number_weight_by_squaring(double q1, doub
 __device__ __forceinline__ double exp_neg_rn(double x)
 {
     if (!(x < 0.015625))
-        return exp(-x);
+        return exp_fast(-x);
     const double p = x * x;
     const double pe = fma(x, x, -p); // x^2 = p + pe exactly
     const double tail = (p * x) * (-1.0 / 6 + x * (1.0 / 24 + x * (-1.0 / 120 + x * (1.0 / 720 +
@@ -194,7 +194,7 @@ __device__ __forceinline__ double log_trunc_norm(double x, double log_x, const d
         return base + (log_tab ? fast_log(m, log_tab) : log(m));
     }
     // ln(e^xr - 1) = xr + ln(1 - e^-xr), e^-xr <= 0.37: the rounding of 1 - e^-xr is an absolute 1.1e-16
-    return base + (xr + (log_tab ? fast_log(1.0 - exp(-xr), log_tab) : log1p(-exp(-xr))));
+    return base + (xr + (log_tab ? fast_log(1.0 - exp_fast(-xr), log_tab) : log1p(-exp_fast(-xr))));
 }
 
 } // namespace covest

@@ -73,6 +73,7 @@ struct StreamSet {
     // `s0`, `total`: this set holds the error classes s0 .. s0 + S - 1 of a model with MORE than S of them (the
     // classes of one copy number are then dealt to several lanes, ll_factored.hip); `total` is the sum of n_os over
     // ALL the model's classes, in s order -- a negative value means: the S classes here are all there are.
+    template <bool CANCEL = true>
     __device__ __forceinline__ void init(const DevModel &m, const double *lam, int o, bool live, const double *log_tab,
                                          const double *norm_tab = nullptr, int s0 = 0, double total = -1.0)
     {
@@ -89,13 +90,39 @@ struct StreamSet {
             tot = total;
         if (tot == 0.0)
             tot = 1.0; // fix_zero
+        // Round 5: the stream's constant  c = ln a_os - D(x)  WITHOUT the division, the log of the quotient and the
+        // normaliser's exp and log, wherever the reference's roundings leave room for it.  a_os = comb_s (1 - e^-x) / tot
+        // and, for x <= 200, D = ln(e^x - 1) = x + ln(1 - e^-x)  (c_src/covest_poissonmodule.c:29-31): the factor
+        // (1 - e^-x) CANCELS,
+        //     c = ln comb_s - ln tot - x                                   (2^-6 <= x <= 200),
+        // one log a LANE (ln tot) and a host constant a class instead of a division, two logs and an exp a STREAM.
+        // Beyond 200 the extension's normaliser is the 200-chunk one (log_trunc_norm: not ln(e^x - 1)) and 1 - e^-x is
+        // exactly 1 in a double: c = ln comb_s - ln tot - log_trunc_norm(x).  Below 2^-6 the reference's own roundings
+        // matter -- `1.0 - exp(-x)` carries a relative 1.1e-16 / x, and what the tail term makes of it (point_fetch.h
+        // exp_neg_rn, log_trunc_norm) -- so there the quotient is formed and logged as the reference forms it.  Between,
+        // those roundings are below 7e-15 relative, the size of the device's and glibc's difference in exp(-x) before.
+        const double ln_tot = CANCEL ? fast_log(tot, log_tab) : 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const double a = n_os[s] / tot;
             v[s] = 0.0;
-            if (live && x[s] > 0.0 && a > 0.0) {
+            if (live && x[s] > 0.0 && n_os[s] > 0.0) { // (a_os > 0 iff n_os > 0: tot is a finite positive number)
                 const double lx = fast_log(x[s], log_tab);
-                an.set(s, lx, fast_log(a, log_tab) - log_trunc_norm(x[s], lx, norm_tab));
+                double c;
+#ifdef COVEST_AB_INIT_PLAIN
+                if (true) {
+#else
+                if (CANCEL ? x[s] < 0.015625 : true) {
+#endif
+                    const double a = n_os[s] / tot;
+                    c = a > 0.0 ? fast_log(a, log_tab) - log_trunc_norm(x[s], lx, norm_tab) : -INFINITY;
+                } else if (x[s] <= 200.0) {
+                    c = (m.ln_comb[s0 + s] - ln_tot) - x[s];
+                } else {
+                    c = (m.ln_comb[s0 + s] - ln_tot) - log_trunc_norm(x[s], lx, norm_tab);
+                }
+                if (c == -INFINITY)
+                    x[s] = 0.0; // (a_os underflowed to 0: the stream contributes exactly 0)
+                an.set(s, c == -INFINITY ? 0.0 : lx, c);
             } else { // contributes exactly 0 (x == 0: TP returns 0, c_src/covest_poissonmodule.c:15)
                 x[s] = 0.0;
                 an.set(s, 0.0, -INFINITY);
@@ -155,13 +182,10 @@ struct StreamSet {
             for (int s = 0; s < N; ++s) {
                 if (m_need[s] == 0)
                     continue;
-                // 2^SC is applied exactly (v_ldexp_f64) wherever exp(a0) itself is a normal
-                // double: folding ln 2^SC = 374.3 into the argument would cost its ulp
-                // (5.7e-14) in every term, which tail*log(1 - sp_j) amplifies by 1/(1 - sp_j).
-                const double a0 = a0s[s];
-                const bool deep = a0 < -700.0;
-                const double e0 = exp(deep ? a0 + kScaleLn : a0);
-                const double anchored = deep ? e0 : ldexp(e0, kScaleBits);
+                // 2^SC is applied exactly, by the v_ldexp_f64 at the end of exp_scaled (fastmath.h): folding
+                // ln 2^SC = 374.3 into the argument would cost its ulp (5.7e-14) in every term, which
+                // tail*log(1 - sp_j) amplifies by 1/(1 - sp_j).
+                const double anchored = exp_scaled(a0s[s], kScaleBits);
                 v[s] = (m_need[s] & me) ? anchored : v[s];
             }
         }

@@ -29,7 +29,7 @@ constexpr double kBasicScale = 0x1p64;
 struct TileView {
     int32_t n_tiles;
     int32_t n_items;
-    // raw buffers behind the views below: [4*nt + 2*nt*32 + 3*ni*32 + ni + 5*(nt+1) + 2] doubles, [3*nt + 3*ni + 32*nt] int32.  The fast
+    // raw buffers behind the views below: [4*nt + 2*nt*32 + 3*ni*32 + ni + 5*(nt+1) + 2] doubles, [4*nt + 3*ni + 32*nt] int32.  The fast
     // kernels take these two as separate `const __restrict__` kernel arguments and rebuild the
     // view from them (tile_view_from): only then does hipcc know the table is read-only and
     // never aliased, and fetches the wave-uniform entries with s_load into SGPRs.
@@ -39,6 +39,7 @@ struct TileView {
     const int32_t *n_bins;     // [n_tiles] keys in the tile (1..32)
     const int32_t *run_start;  // [n_tiles] 1: keys are not contiguous with the previous tile -> re-anchor
     const int32_t *all_zero;   // [n_tiles] 1: every count of the tile is 0 (its keys only enter sp_j: tail != 0)
+    const int32_t *has_filler; // [n_tiles] 1: a row of the tile is a filler key (a gap of the histogram: scale 0)
     const double *lgam_prev;   // [n_tiles] lgamma(k0)       = ln (k0-1)!
     const double *lgam_last;   // [n_tiles] lgamma(k0 + nb)  = ln (k0+nb-1)!
     const double *renorm;      // [n_tiles] (k0-1)! / (k0+nb-1)!   carries v into the next tile
@@ -93,7 +94,8 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, int32_t ni, const
     tv.n_bins = ints;
     tv.run_start = ints + nt;
     tv.all_zero = ints + 2 * (int64_t)nt;
-    tv.item_first = ints + 3 * (int64_t)nt;
+    tv.has_filler = ints + 3 * (int64_t)nt;
+    tv.item_first = ints + 4 * (int64_t)nt;
     tv.item_ntiles = tv.item_first + ni;
     tv.item_sum = tv.item_ntiles + ni;
     tv.row_bin = tv.item_sum + ni;

@@ -196,7 +196,12 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
         if (item_sum[i2])
             for (int32_t r = 0; r < item_ntiles[i2]; ++r)
                 tile_zero[(size_t)(item_first[i2] + r)] = 1;
-    const size_t bytes = n_dbl * sizeof(double) + (3 * nt + 3 * ni + nt * kTileBins) * sizeof(int32_t);
+    std::vector<int32_t> tile_filler(nt, 0); // a row inside the tile's keys that is no key of the histogram
+    for (size_t t = 0; t < nt; ++t)
+        for (int b = 0; b < tiles[t].nb; ++b)
+            if (row_bin[t * kTileBins + (size_t)b] < 0)
+                tile_filler[t] = 1;
+    const size_t bytes = n_dbl * sizeof(double) + (4 * nt + 3 * ni + nt * kTileBins) * sizeof(int32_t);
     HIP_TRY(m->tiles_buf.reserve(bytes));
     double *base = m->tiles_buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(base + n_dbl);
@@ -224,6 +229,7 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     put(suf.data(), suf.size() * sizeof(double));
     put(ints.data(), 2 * nt * sizeof(int32_t));
     put(tile_zero.data(), nt * sizeof(int32_t));
+    put(tile_filler.data(), nt * sizeof(int32_t));
     put(item_first.data(), ni * sizeof(int32_t));
     put(item_ntiles.data(), ni * sizeof(int32_t));
     put(item_sum.data(), ni * sizeof(int32_t));

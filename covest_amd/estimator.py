@@ -140,28 +140,39 @@ class CoverageEstimator:
             return float(self.negll_points([x])[0])
         return -self.model.compute_loglikelihood(*self._model_args(x))
 
-    def negll_grid(self, axes, kernel="auto"):
-        """likelihood_f over itertools.product(*axes) -- the map of covest/grid.py:59-64 -- as ONE
-        dense-grid evaluation.  Returns an ndarray in product order."""
+    def _model_axes(self, axes):
         axes = [list(a) for a in axes]
         if self.fix is not None:
             axes = [a if f is None else [f] * len(a) for a, f in zip(axes, self.fix)]
         axes[self.ERROR_RATE] = [v / self.err_scale for v in axes[self.ERROR_RATE]]
+        return axes
+
+    def _grid_for(self, axes):
+        """One grid handle per estimator, re-configured for every grid (covest_grid_reset): its device memory stays."""
+        if self._grid is not None and self._grid._handle is not None and self._grid.model is self.model:
+            return self._grid.reset(axes)
+        self._grid = DenseGrid(self.model, axes)
+        return self._grid
+
+    def negll_grid(self, axes, kernel="auto", reference_specials=None):
+        """likelihood_f over itertools.product(*axes) -- the map of covest/grid.py:59-64 -- as ONE
+        dense-grid evaluation.  Returns an ndarray in product order.  reference_specials: None = the estimator's
+        setting; a search that wants the other one passes it here (optimize_grid) instead of changing the estimator
+        under the feet of whoever else is using it."""
+        specials = self.reference_specials if reference_specials is None else bool(reference_specials)
+        axes = self._model_axes(axes)
         t = self.timings
         t0 = time.perf_counter() if t is not None else 0.0
-        # one grid handle per estimator, re-configured for every grid (covest_grid_reset): its device memory stays
-        if self._grid is not None and self._grid._handle is not None and self._grid.model is self.model:
-            grid = self._grid.reset(axes)
-        else:
-            grid = self._grid = DenseGrid(self.model, axes)
+        grid = self._grid_for(axes)
         t1 = time.perf_counter() if t is not None else 0.0
         grid.evaluate(kernel=kernel)
         if t is not None:
             grid.argmin()  # (wait for the kernels: the split below is only meaningful with a sync here)
         t2 = time.perf_counter() if t is not None else 0.0
         out = -grid.loglikelihoods()
-        if self.reference_specials:
-            pts = np.array(list(itertools.product(*axes)), dtype=np.float64).reshape(-1, self.model.param_count)
+        if specials:
+            mesh = np.meshgrid(*[np.asarray(a, dtype=np.float64) for a in axes], indexing="ij")  # (product order)
+            pts = np.stack([m.reshape(-1) for m in mesh], axis=1)
             out = self._with_reference_specials(pts, out)
         if t is not None:
             t3 = time.perf_counter()
@@ -169,11 +180,36 @@ class CoverageEstimator:
                       "kernel": grid.work()[2]})
         return out
 
-    def negll_points(self, xs):
+    def negll_grid_scan(self, axes, min_val, kernel="auto", reference_specials=None):
+        """negll_grid for optimize_grid's selection loop (covest/grid.py:65-70), with the loop's scan done where the
+        values are: returns (records, values) -- records = (flat indices, -LL) of the strict running-minimum records
+        below `min_val` in product order (DenseGrid.scan_records) and values = None, or records = None and the values
+        as negll_grid returns them where the device's list does not apply (reference_specials, a list cut short)."""
+        if self.reference_specials if reference_specials is None else reference_specials:
+            return None, self.negll_grid(axes, kernel=kernel, reference_specials=True)
+        axes = self._model_axes(axes)
+        t = self.timings
+        t0 = time.perf_counter() if t is not None else 0.0
+        grid = self._grid_for(axes)
+        t1 = time.perf_counter() if t is not None else 0.0
+        grid.evaluate(kernel=kernel, scan_start=min_val)
+        if t is not None:
+            grid.argmin()
+        t2 = time.perf_counter() if t is not None else 0.0
+        records = grid.scan_records()
+        values = None if records is not None else -grid.loglikelihoods()
+        if t is not None:
+            t3 = time.perf_counter()
+            t.append({"points": len(grid), "create_s": t1 - t0, "eval_s": t2 - t1, "readback_s": t3 - t2,
+                      "kernel": grid.work()[2]})
+        return records, values
+
+    def negll_points(self, xs, reference_specials=None):
         """likelihood_f of several optimiser-space vectors in one launch: ndarray."""
         pts = np.array([self._model_args(x) for x in xs], dtype=np.float64)
         out = -self.model.loglikelihood_points(pts)
-        return self._with_reference_specials(pts, out) if self.reference_specials else out
+        specials = self.reference_specials if reference_specials is None else bool(reference_specials)
+        return self._with_reference_specials(pts, out) if specials else out
 
     def _with_reference_specials(self, pts, negll):
         """-LL with the reference's own result substituted where its pmf product overflows: the points the host

@@ -192,13 +192,35 @@ class DenseGrid:
     def __len__(self):
         return self.flat_range[1] - self.flat_range[0]
 
-    def evaluate(self, kernel="auto", stream=None):
+    def evaluate(self, kernel="auto", stream=None, scan_start=None):
         """Launch LL + arg-min for the block (asynchronous on `stream`, a raw
-        hipStream_t value such as torch.cuda.current_stream().cuda_stream)."""
+        hipStream_t value such as torch.cuda.current_stream().cuda_stream).  scan_start: also run the selection
+        scan of covest/grid.py:65-70 from that minimum on the device (covest_grid_eval_scan); scan_records()
+        returns what it found."""
         if stream:
             _capi.require_shared_runtime("DenseGrid.evaluate(stream=...)")
-        _capi.check(_capi.lib().covest_grid_eval(self._handle, _capi.KERNELS[kernel],
-                                                 ctypes.c_void_p(stream or 0)), "covest_grid_eval")
+        if scan_start is None:
+            _capi.check(_capi.lib().covest_grid_eval(self._handle, _capi.KERNELS[kernel],
+                                                     ctypes.c_void_p(stream or 0)), "covest_grid_eval")
+        else:
+            _capi.check(_capi.lib().covest_grid_eval_scan(self._handle, _capi.KERNELS[kernel], ctypes.c_void_p(stream or 0),
+                                                          float(scan_start)), "covest_grid_eval_scan")
+
+    _SCAN_CAP = 128
+
+    def scan_records(self):
+        """(flat indices, -LL values) of the strict running-minimum records below the scan_start of the last
+        evaluate(), in index order -- where the reference's selection loop changes its state --, or None when the
+        device's list is incomplete (the caller reads the values back: loglikelihoods())."""
+        if not hasattr(self, "_scan_buf"):
+            self._scan_buf = ((ctypes.c_int64 * self._SCAN_CAP)(), (ctypes.c_double * self._SCAN_CAP)(),
+                              ctypes.c_int32(), ctypes.c_int32())
+        idx, val, n, trunc = self._scan_buf
+        _capi.check(_capi.lib().covest_grid_scan(self._handle, self._SCAN_CAP, idx, val, ctypes.byref(n),
+                                                 ctypes.byref(trunc)), "covest_grid_scan")
+        if trunc.value:
+            return None
+        return idx[:n.value], val[:n.value]
 
     def argmin(self):
         """(min -LL, global flat index) of the last evaluate(); index -1 if none < +inf."""
@@ -266,11 +288,22 @@ def repeats_cost_weights(model, axes):
     return np.maximum(t.astype(np.float64) - 1.0, 0.0)
 
 
-def dense_grid_argmin(model, axes, kernel="auto", group=None, balance=True):
-    """Arg-min of -LL over a dense grid, block-partitioned over the process group.
+def dense_grid_argmin(model, axes, kernel="auto", group=None, balance=True, devices=None):
+    """Arg-min of -LL over a dense grid, block-partitioned over the process group -- or, with `devices`, over
+    several GPUs of THIS process.
 
     Returns (min_negll, flat_index, params).  Every rank returns the same answer.
+
+    devices: a list of HIP ordinals.  The reference's consumer of the grid map is ONE process that fans the points out
+    to workers (covest/covest.py:86-89 -> covest/grid.py:63-64); this is that shape on GPUs: one model handle and one
+    grid handle per device (the C ABI takes the device per handle, include/covest_amd.h), the flat index range cut into
+    contiguous blocks balanced by sum(T - 1), every block launched asynchronously on its device's default stream --
+    they run side by side --, and the N 16-byte (min, index) pairs scanned on the host with the reference's rule.  No
+    process group, no collective: nothing to exchange but what the arg-min kernels stored to page-locked memory.  An
+    ordinal may appear more than once (two blocks on one card: how a one-GPU box tests this).
     """
+    if devices is not None:
+        return _dense_grid_argmin_devices(model, axes, kernel, balance, list(devices))
     import torch.distributed as dist
     world, rank = 1, 0
     if dist.is_available() and dist.is_initialized():
@@ -296,6 +329,57 @@ def dense_grid_argmin(model, axes, kernel="auto", group=None, balance=True):
         params = grid.point(gidx) if gidx >= 0 else None
     finally:
         grid.close()
+    return gmin, gidx, params
+
+
+class DeviceBlocks:
+    """One dense grid cut into one block per entry of `devices`, all driven by this process (dense_grid_argmin with
+    `devices`).  Kept as an object so that a caller that evaluates the same grid shape repeatedly (bench.py) pays for
+    the handles once: evaluate() launches every block, argmin() waits for them and scans the pairs."""
+
+    def __init__(self, model, axes, devices, balance=True):
+        if not devices:
+            raise ValueError("devices: at least one HIP ordinal")
+        self.devices = [int(d) for d in devices]
+        shape = [len(a) for a in axes]
+        total = int(np.prod(shape, dtype=np.int64))
+        weights = repeats_cost_weights(model, axes) if balance and model.param_count == 5 and len(devices) > 1 else None
+        self.bounds = partition_flat_range(total, len(self.devices), weights)
+        self._own = []   # the per-device copies of the model this object made (closed with it)
+        self.grids = []
+        for i, d in enumerate(self.devices):
+            m = model.on_device(d) if hasattr(model, "on_device") else model
+            if m is not model:
+                self._own.append(m)
+            self.grids.append(DenseGrid(m, axes, (self.bounds[i], self.bounds[i + 1])))
+
+    def evaluate(self, kernel="auto"):
+        for g in self.grids:  # asynchronous: the devices work side by side
+            g.evaluate(kernel=kernel)
+
+    def argmin(self):
+        """(min -LL, global flat index): every block's pair, scanned in block order with the reference's rule."""
+        return scan_min_pairs([g.argmin() for g in self.grids])
+
+    def point(self, flat_index):
+        return self.grids[0].point(flat_index)
+
+    def close(self):
+        for g in self.grids:
+            g.close()
+        for m in self._own:
+            m.close()
+        self.grids, self._own = [], []
+
+
+def _dense_grid_argmin_devices(model, axes, kernel, balance, devices):
+    blocks = DeviceBlocks(model, axes, devices, balance=balance)
+    try:
+        blocks.evaluate(kernel=kernel)
+        gmin, gidx = blocks.argmin()
+        params = blocks.point(gidx) if gidx >= 0 else None
+    finally:
+        blocks.close()
     return gmin, gidx, params
 
 
@@ -329,6 +413,19 @@ def first_wins_scan(vals, min_val, sgn=1):
     return min_val, arg, diff
 
 
+def replay_records(indices, vals, min_val):
+    """first_wins_scan over the device's list (DenseGrid.scan_records): the loop of covest/grid.py:65-70 visits
+    exactly these points with a passing test, in this order -- the same comparisons and the same sums."""
+    diff = 0.0
+    arg = -1
+    for i, v in zip(indices, vals):
+        if v < min_val:
+            diff += min_val - v
+            min_val = v
+            arg = int(i)
+    return min_val, arg, diff
+
+
 def _batched_negll(fn):
     """If fn is CoverageEstimator.likelihood_f over a GPU-backed model, return a
     function evaluating a whole list of axes at once; else None."""
@@ -348,17 +445,10 @@ def optimize_grid(fn, initial_guess, bounds=None, maximize=False, fix=None,
     covest/grid.py:60,73-74) -- per call, so concurrent searches (the lock-step refinement runs threads) never
     share one.  `reference_specials` (fn = CoverageEstimator.likelihood_f only): True makes the search see what the
     REFERENCE's objective returns where its long-double pmf product overflows -- -(+inf), which the scan of
-    covest/grid.py:65-70 selects, or NaN -- for the duration of this call (CoverageEstimator.reference_specials);
-    None leaves the estimator as it is."""
+    covest/grid.py:65-70 selects, or NaN -- in THIS search: the flag travels with the evaluation requests
+    (CoverageEstimator.negll_grid(..., reference_specials=)), the estimator itself is not touched, so searches and
+    refinements that share it (the lock-step refinement runs threads) keep their own setting.  None: the estimator's."""
     est = getattr(fn, "__self__", None)
-    if reference_specials is not None and hasattr(est, "reference_specials"):
-        before = est.reference_specials
-        est.reference_specials = bool(reference_specials)
-        try:
-            return optimize_grid(fn, initial_guess, bounds=bounds, maximize=maximize, fix=fix, n_threads=n_threads,
-                                 trace=trace, reference_specials=None)
-        finally:
-            est.reference_specials = before
     def generate_axes(args, step, max_depth):
         def single(var, fixed=None):
             if fixed is None:
@@ -378,7 +468,16 @@ def optimize_grid(fn, initial_guess, bounds=None, maximize=False, fix=None,
         fix = [None] * len(initial_guess)
     sgn = -1 if maximize else 1
     batched = _batched_negll(fn)
-    min_val = sgn * fn(initial_guess)
+    # the selection scan on the device (estimator.negll_grid_scan): the values stay in HBM, a handful of records come back
+    scanned = getattr(est, "negll_grid_scan", None) if batched is not None and sgn == 1 else None
+    if batched is not None and reference_specials is not None:
+        specials = bool(reference_specials)
+        batched_all, scanned_all = batched, scanned
+        batched = lambda axes: batched_all(axes, reference_specials=specials)
+        scanned = None if scanned_all is None else (lambda axes, mv: scanned_all(axes, mv, reference_specials=specials))
+        min_val = sgn * float(est.negll_points([initial_guess], reference_specials=specials)[0])
+    else:
+        min_val = sgn * fn(initial_guess)
     min_args = initial_guess
     step = constants.STEP
     grid_depth = constants.GRID_DEPTH
@@ -391,13 +490,19 @@ def optimize_grid(fn, initial_guess, bounds=None, maximize=False, fix=None,
             n_iter += 1
             axes = generate_axes(min_args, step, grid_depth)
             n_points = int(np.prod([len(a) for a in axes], dtype=np.int64))
+            records = None
             if n_points == 0:
                 res = np.empty(0)
+            elif scanned is not None:
+                records, res = scanned(axes, min_val)
             elif batched is not None:
                 res = batched(axes)
             else:
                 res = np.array([fn(p) for p in itertools.product(*axes)], dtype=np.float64)
-            min_val, arg, diff = first_wins_scan(res, min_val, sgn)
+            if records is not None:
+                min_val, arg, diff = replay_records(records[0], records[1], min_val)
+            else:
+                min_val, arg, diff = first_wins_scan(res, min_val, sgn)
             if arg >= 0:
                 idx = np.unravel_index(arg, [len(a) for a in axes])
                 min_args = tuple(a[i] for a, i in zip(axes, idx))

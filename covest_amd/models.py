@@ -192,6 +192,17 @@ class BasicModel:
             self._handle = h
         return self._handle
 
+    def on_device(self, device):
+        """This model bound to HIP device `device`: itself where that is its device already, else a copy of its plain
+        data (what pickling ships to a Pool worker) whose handle is created on that device on first use.  How ONE
+        process puts the same histogram on several GPUs (covest_amd.grid.dense_grid_argmin(devices=...))."""
+        if int(device) == int(self.device):
+            return self
+        clone = self.__class__.__new__(self.__class__)
+        clone.__setstate__(self.__getstate__())
+        clone.device = int(device)
+        return clone
+
     def _register_grid(self, grid):
         """A grid handle borrows its model (include/covest_amd.h): the model closes the grids still open on it
         before it goes (DenseGrid calls this)."""

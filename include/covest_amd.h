@@ -141,7 +141,9 @@ int covest_grid_create(covest_model *m, int32_t n_axes, const double *const *axe
 void covest_grid_destroy(covest_grid *g);
 /* Give an existing handle other axes and/or another block (same meaning of the arguments as
  * covest_grid_create): the iterations of covest/grid.py:56-74 evaluate a new grid each time, and a
- * handle keeps its device memory.  Waits for the handle's last evaluation. */
+ * handle keeps its device memory.  Waits for the handle's last evaluation; what it uploads (axes, threshold_o
+ * table, K-factored's plan) is staged in page-locked memory of the handle and copied asynchronously on the default
+ * stream -- the next covest_grid_eval queues up behind the copies (on another stream: behind an event). */
 int covest_grid_reset(covest_grid *g, int32_t n_axes, const double *const *axes, const int64_t *axis_len,
                       int64_t flat_begin, int64_t flat_end);
 int64_t covest_grid_size(const covest_grid *g); /* flat_end - flat_begin */
@@ -157,6 +159,19 @@ int covest_grid_eval(covest_grid *g, int32_t kernel, void *stream);
  * lowest GLOBAL flat index wins ties, NaN never wins; argmin -1 if nothing is
  * < +inf. */
 int covest_grid_argmin(covest_grid *g, double *min_negll, int64_t *argmin_flat);
+
+/* covest_grid_eval and, in the same arg-min launch, the SELECTION SCAN of covest/grid.py:65-70 started from the
+ * minimum the caller holds (`start_min`: what optimize_grid's `min_val` is when an iteration begins, :49,67-69):
+ *     if sgn * val < min_val: diff += min_val - val; min_val = sgn * val; min_args = args
+ * changes its state exactly at the strict running-minimum records below start_min, taken in flat-index order -- a
+ * handful of points once a search is under way.  The device lists them (page-locked host memory, the kernel's own
+ * stores) and covest_grid_scan hands them over: index[i] (GLOBAL flat index, ascending) and negll[i] = -LL there,
+ * so the caller replays the loop over those alone instead of reading every value back (covest_grid_ll_host).
+ * *truncated != 0: the list is incomplete (more records than `cap` or than the device keeps -- 120 --, a block beyond
+ * 16384 points, or the last evaluation was a plain covest_grid_eval): read the values back instead.  A NaN never
+ * passes `<`, as in the reference.  maximize=False only (sgn = 1). */
+int covest_grid_eval_scan(covest_grid *g, int32_t kernel, void *stream, double start_min);
+int covest_grid_scan(covest_grid *g, int32_t cap, int64_t *index, double *negll, int32_t *n_records, int32_t *truncated);
 
 /* Device pointer of the reduction of the last covest_grid_eval as two doubles in HBM,
  * {min -LL, GLOBAL flat index of the arg-min as a double (-1 if none; flat indices stay

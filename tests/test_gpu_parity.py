@@ -927,6 +927,126 @@ def test_round4_shortcuts_on_awkward_shapes(hip_lib, oracle):
         m.close()
 
 
+def test_round5_tail_paths_on_awkward_shapes(hip_lib, oracle):
+    """Round 5 re-routed how a histogram WITH A TAIL is evaluated -- the shape every real CovEst run hands the model
+    (covest/histogram.py:105-134, covest/models.py:103-104).  K-factored sums sp_j per copy number in phase A and
+    contracts it once at the end (ll_factored.hip SPO), walks count-less tiles without contracting them, takes the last
+    COUNTED item first and skips dead units; K-basic takes the closed form for the logs and walks the tiles it covers for
+    their sums alone (ll_basic.hip).  Histograms for what those routes could trip over: a single partial tile; keys with
+    gaps that the recurrence bridges with filler keys (scale 0: they must add nothing to sp_j); long stretches of
+    zero-count keys (sum items) before, between and BEHIND the counted ones; a far counted key that dooms most of the
+    grid.  On every one: IEEE specials in the same places as K-direct over the whole grid, the same arg-min, and a
+    seeded sample against the oracle at 1e-9 with the graded tail slack."""
+    from covest_amd import BasicModel, DenseGrid, RepeatsModel
+
+    def falling(keys, top):
+        return {int(j): max(1, int(top * math.exp(-0.07 * i))) for i, j in enumerate(keys)}
+
+    zeros = lambda keys: {int(j): 0 for j in keys}
+    hists = {
+        "one partial tile": falling(range(1, 21), 5000),
+        "gaps bridged by filler keys": {j: c for j, c in falling(range(1, 90), 30000).items() if j % 7 != 3},
+        "count-less stretches": {**falling(range(1, 41), 9000), **zeros(range(41, 150)), **falling(range(150, 171), 700),
+                                 **zeros(range(171, 400))},
+        "a far key behind zeros": {**falling(range(1, 70), 50000), **zeros(range(70, 300)), 300: 3},
+    }
+    rng = np.random.default_rng(55)
+    for name, hist in hists.items():
+        top = max(j for j, c in hist.items() if c)
+        for tail in (777,):
+            rm = RepeatsModel(21, 100, hist, tail, max_error=8)
+            orm = oracle.OracleModel("repeats", 21, 100, hist, tail, max_error=8)
+            axes = [np.exp(np.linspace(np.log(0.4), np.log(max(4.0, 0.9 * top)), 12)), [0.004, 0.03, 0.2],
+                    np.linspace(0.35, 0.95, 4), [0.5], [0.05, 0.3, 0.6, 0.95]]
+            grid = DenseGrid(rm, axes)
+            grid.evaluate(kernel="factored")
+            assert grid.work()[2] == "ll_factored"
+            fast, best = grid.loglikelihoods(), grid.argmin()
+            grid.evaluate(kernel="direct")
+            ref = grid.loglikelihoods()
+            assert np.array_equal(np.isneginf(fast), np.isneginf(ref)) and np.array_equal(np.isnan(fast), np.isnan(ref)), name
+            assert np.isfinite(ref).any(), name
+            some = rng.choice(grid.total, size=48, replace=False)
+            pts = np.array([grid.point(int(i)) for i in some])
+            want = orm.compute_loglikelihood_many(pts, n_threads=16)
+            slack = _tail_noise(orm, pts, want, tail)
+            _slack_budget("round-5 tail paths, repeats, " + name, slack)
+            _check(fast[some], want, "round-5 tail paths, repeats, " + name, slack=slack)
+            k_ref = int(np.argmin(np.where(np.isnan(ref), np.inf, -ref)))
+            assert best[1] == k_ref or rel_err(float(fast[best[1]]), float(ref[k_ref])) <= TOL, name
+            grid.close()
+            rm.close()
+            m = BasicModel(21, 100, hist, tail, max_error=8)
+            om = oracle.OracleModel("basic", 21, 100, hist, tail, max_error=8)
+            cs = np.exp(np.linspace(np.log(0.3), np.log(3.0 * top), 320))
+            g = DenseGrid(m, [cs, [0.002, 0.05, 0.3, 0.5]])
+            g.evaluate(kernel="recur")
+            assert g.work()[2] == "ll_basic"
+            fast = g.loglikelihoods()
+            g.evaluate(kernel="direct")
+            ref = g.loglikelihoods()
+            assert np.array_equal(np.isneginf(fast), np.isneginf(ref)) and np.array_equal(np.isnan(fast), np.isnan(ref)), name
+            some = rng.choice(g.total, size=64, replace=False)
+            pts = np.array([g.point(int(i)) for i in some])
+            want = om.compute_loglikelihood_many(pts, n_threads=16)
+            slack = _tail_noise(om, pts, want, tail)
+            _slack_budget("round-5 tail paths, basic, " + name, slack)
+            _check(fast[some], want, "round-5 tail paths, basic, " + name, slack=slack)
+            g.close()
+            m.close()
+
+
+def test_selection_scan_on_the_device(hip_lib):
+    """covest_grid_eval_scan / covest_grid_scan (include/covest_amd.h): the records the device lists are exactly where
+    the reference's selection loop (covest/grid.py:65-70) changes its state, for any starting minimum -- replayed, the
+    loop's (min_val, arg, diff) come out bit for bit as first_wins_scan over the values read back.  Also: a NaN and
+    +inf never pass, ties keep the first index, a list longer than the device keeps comes back as None."""
+    from covest_amd import DenseGrid, RepeatsModel
+    from covest_amd.grid import first_wins_scan, replay_records
+    hist = load_hist("sim_c10_e0.05")
+    m = RepeatsModel(21, 100, hist, 0, max_error=8)
+    axes = [np.linspace(5.0, 60.0, 9), np.linspace(0.001, 0.3, 6), np.linspace(0.3, 1.0, 6), [0.2, 0.5, float("nan")],
+            np.linspace(0.05, 0.95, 8)]
+    grid = DenseGrid(m, axes)
+    grid.evaluate()
+    vals = -grid.loglikelihoods()
+    assert np.isnan(vals).any() and np.isposinf(vals).any() and np.isfinite(vals).any()
+    finite = np.sort(vals[np.isfinite(vals)])
+    starts = [math.inf, float(finite[-1]), float(np.median(finite)), float(finite[3]), float(finite[0]),
+              float(finite[0]) - 1.0, float(finite[len(finite) // 3]) + 1e-9]
+    for start in starts:
+        grid.evaluate(scan_start=start)
+        rec = grid.scan_records()
+        assert rec is not None
+        want = first_wins_scan(vals, start, 1)
+        got = replay_records(rec[0], rec[1], start)
+        assert got == want, (start, got, want)
+        assert list(rec[0]) == sorted(rec[0]) and all(vals[i] == v for i, v in zip(rec[0], rec[1]))
+        assert grid.argmin() == (float(np.nanmin(vals)), int(np.flatnonzero(vals == np.nanmin(vals))[0]))
+    # a block of the grid: the records carry GLOBAL flat indices
+    lo, hi = 1000, 5000
+    part = DenseGrid(m, axes, (lo, hi))
+    part.evaluate(scan_start=math.inf)
+    rec = part.scan_records()
+    want = first_wins_scan(vals[lo:hi], math.inf, 1)
+    got = replay_records(rec[0], rec[1], math.inf)
+    assert (got[0], got[1] - lo, got[2]) == want
+    part.close()
+    # more strict records than the device keeps (a steadily falling objective along the fastest axis): None
+    bm_axes = [np.linspace(30.0, 10.5, 400), [0.05], [0.9], [0.5], [0.5]]
+    long_grid = DenseGrid(m, bm_axes)
+    long_grid.evaluate(scan_start=math.inf)
+    v2 = -long_grid.loglikelihoods()
+    n_rec = len(np.flatnonzero(np.concatenate(([True], v2[1:] < np.minimum.accumulate(v2)[:-1]))))
+    assert n_rec > 128, n_rec
+    assert long_grid.scan_records() is None
+    long_grid.evaluate()  # a plain evaluation leaves no list either
+    assert long_grid.scan_records() is None
+    long_grid.close()
+    grid.close()
+    m.close()
+
+
 def test_estimator_fix_and_err_scale_on_gpu(hip_lib, oracle):
     """CoverageEstimator.likelihood_f (covest/covest.py:26-31) with `fix` and `err_scale != 1` -- the "4-D grid =
     q2 fixed" case of SURVEY discrepancy 1 -- on the GPU: the scalar objective, its batched form negll_grid, and

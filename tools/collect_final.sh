@@ -10,7 +10,7 @@ mkdir -p "$out"
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp && cd "$repo"
 timeout -k 10 500 python3 bench.py > "$out/bench_default.json" 2> "$out/bench_default.err" || echo "default bench failed"
-for w in c3 c2; do
+for w in c3 c2 c3t c2t; do
   timeout -k 10 200 python3 bench.py --workload $w --no-variants > "$out/bench_$w.json" 2> "$out/bench_$w.err" || echo "bench $w failed"
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$w" -o "$w" -- python3 bench.py --workload $w --steps 10 --warmup 2 --cpu-budget 0 --no-variants > "$out/bench_${w}_under_rocprof.json" 2> "$out/trace_$w.err" || echo "trace $w failed"
   find "$out/trace_$w" -name "*kernel_stats.csv" -exec cp {} "$out/${w}_kernel_stats.csv" \;

@@ -3,24 +3,36 @@
 per workload and kernel the HBM bytes per launch, (2 FETCH_SIZE + WRITE_SIZE) KB -- FETCH_SIZE doubled as
 MI355X_MICROARCH.md prescribes for gfx950 -- and the fp64 flops the kernel EXECUTED per launch,
 64 lanes x (2 FMA + MUL + ADD wave instructions) + 2048 per v_mfma_f64_16x16x4 (SQ_INSTS_VALU_MFMA_MOPS_F64 / 4).
-    python tools/pmc_to_traffic.py r03"""
+The file carries the hash of the sources the counters were taken on (bench.source_sha16): bench.py marks its
+executed-flop fraction stale when the library it measures was built from other sources.
+    python tools/pmc_to_traffic.py r05"""
 import json
 import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
-want = {"c3": ("ll_factored", "ll_factored_kernel<512,3,false,true>"), "c2": ("ll_basic", "ll_basic_kernel<false>")}
+sys.path.insert(0, REPO)
+from bench import source_sha16  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+# workload -> (short kernel name of covest_grid_work, prefix of the profiled kernel's name)
+want = {"c3": ("ll_factored", "ll_factored_kernel<512,3,false,true"), "c2": ("ll_basic", "ll_basic_kernel<false>"),
+        "c3t": ("ll_factored", "ll_factored_kernel<512,3,true,true"), "c2t": ("ll_basic", "ll_basic_kernel<true>")}
 out = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 and executed fp64 flops per launch from separate "
-                "rocprofv3 --pmc passes (tools/pmc_profile.sh, profiles/%s_c{3,2}_pmc_summary.json; tools/pmc_to_traffic.py); "
+                "rocprofv3 --pmc passes (tools/pmc_profile.sh, profiles/%s_<workload>_pmc_summary.json; tools/pmc_to_traffic.py); "
                 "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced read; uncalibrated for these "
                 "kernels' small reads, so the read side is an upper bound); the write side above the 8 B/point output is the "
-                "scratch of spilled registers" % tag}
+                "scratch of spilled registers" % tag,
+       "_source_sha16": source_sha16()}
 for w, (short, full) in want.items():
-    with open(os.path.join(REPO, "profiles", "%s_%s_pmc_summary.json" % (tag, w))) as f:
+    path = os.path.join(REPO, "profiles", "%s_%s_pmc_summary.json" % (tag, w))
+    if not os.path.exists(path):
+        continue
+    with open(path) as f:
         summary = json.load(f)
-    # (the headline shape of K-factored is compiled with its row stride as a fifth template argument since round 4)
-    d = summary.get(full) or next(v for k, v in summary.items() if k.startswith(full[:-1] + ","))
+    d = next((v for k, v in summary.items() if k.startswith(full)), None)
+    if d is None:
+        continue
     flops = 64.0 * (2.0 * d["SQ_INSTS_VALU_FMA_F64"] + d["SQ_INSTS_VALU_MUL_F64"] + d["SQ_INSTS_VALU_ADD_F64"]) \
         + 2048.0 * d.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) / 4.0
     out[w] = {short: int(round((2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0)),

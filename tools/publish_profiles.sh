@@ -1,10 +1,10 @@
 #!/bin/bash
 # Copy the evidence tools/collect_final.sh left under gpurun_out/<tag>/ into profiles/ under the round's names, and
-# refresh profiles/pmc_traffic.json from the PMC summaries:   tools/publish_profiles.sh <tag> [round prefix, default r04]
+# refresh profiles/pmc_traffic.json from the PMC summaries:   tools/publish_profiles.sh <tag> [round prefix, default r05]
 set -e
-tag=$1; r=${2:-r04}; src=gpurun_out/$tag
+tag=$1; r=${2:-r05}; src=gpurun_out/$tag
 cp $src/bench_default.json profiles/${r}_bench_default_with_variants.json
-for w in c3 c2; do
+for w in c3 c2 c3t c2t; do
   cp $src/bench_$w.json profiles/${r}_bench_$w.json
   cp $src/bench_${w}_under_rocprof.json profiles/${r}_bench_${w}_under_rocprof.json
   cp $src/${w}_kernel_stats.csv profiles/${r}_${w}_kernel_stats.csv
