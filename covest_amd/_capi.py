@@ -30,7 +30,7 @@ EXPORTS = (
     "covest_grid_work", "covest_grid_profile", "covest_grid_kernel_ms", "covest_grid_diag",
     "covest_kmer_create", "covest_kmer_destroy", "covest_kmer_reserve", "covest_kmer_add",
     "covest_kmer_add_device", "covest_kmer_histogram", "covest_kmer_slots", "covest_kmer_clear",
-    "covest_kmer_count_reads_device", "covest_kmer_partition_info", "covest_kmer_partition_ms",
+    "covest_kmer_count_reads_device", "covest_kmer_partition_info", "covest_kmer_partition_ms", "covest_kmer_memory_limit",
     "covest_kmer_scatter_rate",
     "covest_reads_open", "covest_reads_close", "covest_reads_next", "covest_reads_bytes",
     "covest_thin_histogram", "covest_thin_histogram_timed",
@@ -82,6 +82,24 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise CovestHipError("cannot load %s: %s" % (LIB_PATH, e))
+    if "COVEST_AMD_LIB" in os.environ:
+        # an A/B run against an OLDER build (tools/ab.sh): an entry point that build does not have yet is bound to a
+        # stub that fails loudly when called -- the shipped library (no override) must export every one of them
+        class _Tolerant:
+            def __init__(self, lib):
+                object.__setattr__(self, "_lib", lib)
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(self._lib, name)
+                except AttributeError:
+                    def missing(*a, **k):
+                        raise CovestHipError("%s is not exported by %s" % (name, LIB_PATH))
+                    missing.restype = missing.argtypes = None
+                    object.__setattr__(self, name, missing)
+                    return missing
+
+        L = _Tolerant(L)
     vp, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)
     i32, i64 = ctypes.c_int32, ctypes.c_int64
     L.covest_abi_version.restype = ctypes.c_int
@@ -107,10 +125,11 @@ def lib():
     L.covest_probabilities.restype = ctypes.c_int
     L.covest_probabilities.argtypes = [vp, dp, i32, dp]
     L.covest_grid_create.restype = ctypes.c_int
-    L.covest_grid_create.argtypes = [vp, i32, ctypes.POINTER(dp), ctypes.POINTER(i64), i64, i64,
-                                     ctypes.POINTER(vp)]
+    # (the axes' pointer array and the lengths as plain addresses: DenseGrid hands over two numpy arrays, one
+    # conversion each, instead of a ctypes object per axis -- an optimize_grid iteration re-configures its handle)
+    L.covest_grid_create.argtypes = [vp, i32, vp, vp, i64, i64, ctypes.POINTER(vp)]
     L.covest_grid_reset.restype = ctypes.c_int
-    L.covest_grid_reset.argtypes = [vp, i32, ctypes.POINTER(dp), ctypes.POINTER(i64), i64, i64]
+    L.covest_grid_reset.argtypes = [vp, i32, vp, vp, i64, i64]
     L.covest_grid_destroy.restype = None
     L.covest_grid_destroy.argtypes = [vp]
     L.covest_grid_size.restype = i64
@@ -151,6 +170,8 @@ def lib():
     L.covest_kmer_count_reads_device.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     L.covest_kmer_partition_info.restype = ctypes.c_int
     L.covest_kmer_partition_info.argtypes = [vp, i64p]
+    L.covest_kmer_memory_limit.restype = ctypes.c_int
+    L.covest_kmer_memory_limit.argtypes = [vp, i64]
     L.covest_kmer_partition_ms.restype = ctypes.c_int
     L.covest_kmer_partition_ms.argtypes = [vp, dp]
     L.covest_kmer_scatter_rate.restype = ctypes.c_int
@@ -185,14 +206,37 @@ COVEST_E_NOMEM = -4
 COVEST_E_UNSUPPORTED = -5
 
 
+def hip_runtimes_mapped():
+    """The distinct libamdhip64 files mapped into this process (/proc/self/maps; inode-distinct paths): one when torch
+    and this library bind the same runtime, two when the process hosts torch's bundled copy beside the system's."""
+    seen = {}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 6 and "libamdhip64" in os.path.basename(parts[5]):
+                    seen[(parts[3], parts[4])] = parts[5]  # (device, inode): one entry per file
+    except OSError:
+        return None
+    return sorted(seen.values())
+
+
 def require_shared_runtime(what):
-    """Called wherever device memory of this library is handed to torch (or torch's to it): fails loudly if the
-    process imported torch AFTER the library was loaded -- two HIP runtimes, the pointers would be garbage."""
-    if _lib is not None and _loaded_before_torch and "torch" in sys.modules:
+    """Called wherever device memory of this library is handed to torch (or torch's to it): fails loudly if the process
+    hosts TWO HIP runtimes -- the pointers of one mean nothing to the other.  Decided from what is mapped
+    (hip_runtimes_mapped: two different libamdhip64 files); where /proc is not readable, from the import order, which
+    is how a process ends up with two (torch ships its own copy and must be imported BEFORE this library is loaded,
+    INTEGRATION.md) -- a torch built against the system's ROCm binds the same file whatever the order, and is fine."""
+    if _lib is None or "torch" not in sys.modules:
+        return
+    mapped = hip_runtimes_mapped()
+    two = len(mapped) > 1 if mapped is not None else _loaded_before_torch
+    if two:
         raise CovestHipError(
-            "%s: torch was imported after libcovest_amd.so was loaded, so this process hosts two HIP runtimes and "
-            "device pointers cannot be shared between them -- `import torch` before the first covest_amd call "
-            "(INTEGRATION.md)" % what)
+            "%s: this process hosts two HIP runtimes (%s), so device pointers cannot be shared between torch and "
+            "libcovest_amd.so -- `import torch` before the first covest_amd call%s (INTEGRATION.md)"
+            % (what, ", ".join(mapped) if mapped else "torch was imported after the library was loaded",
+               "" if not _loaded_before_torch else ": here torch was imported after the library was loaded"))
 
 
 def last_error():

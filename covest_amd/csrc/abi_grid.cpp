@@ -167,6 +167,7 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
 static void grid_release(covest_grid *g)
 {
     (void)hipDeviceSynchronize(); // (the buffers go back to the process's cache, host.h: nothing may still work on them)
+    DeviceIdleScope idle;
     if (g->upload_ev) {
         (void)hipEventDestroy(g->upload_ev);
         g->upload_ev = nullptr;

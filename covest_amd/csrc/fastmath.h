@@ -56,9 +56,7 @@ __device__ __forceinline__ double fma_vvv(double a, double b, double c)
 // x = -inf gives 0, NaN propagates, results beyond the doubles' range are +inf / 0 as v_ldexp_f64 rounds them.
 __device__ __forceinline__ double exp_scaled(double x, int sc)
 {
-#ifdef COVEST_AB_EXP_LIB
-    return ldexp(exp(x), sc);
-#endif
+
     const double dn = __builtin_rint(x * 0x1.71547652b82fep+0);
     double t = fma(-dn, 0x1.62e42fefa39efp-1, x);
     t = fma(-dn, 0x1.abc9e3b39803fp-56, t);
@@ -163,20 +161,27 @@ __device__ __forceinline__ void fast_log_n(const double (&x)[N], double (&out)[N
 // price of v_frexp_exp_i32_f64 alone), so the scale costs nothing; x must be a NORMAL double (the callers clamp).
 // (Taking the mantissa off the bits too -- and, or -- was tried: the compiler copies the low word into a fresh
 // register pair for it, v_frexp_mant_f64 is cheaper.)  DEG: log1p(r) to r^DEG, |r| <= 2^-9: 5 -> truncation 9e-18
-// (as fast_log); 4 -> r^5 / 5 <= 5.7e-15, zero-mean over the mantissa (odd in r) -- one FMA less per log, for
-// dense grids (ll_factored.hip).
-template <int N, int DEG, int SC>
+// (as fast_log); 4 -> r^5 / 5 <= 5.7e-15, zero-mean over the mantissa (odd in r) -- one FMA less per log; 3 (round 5,
+// dense grids: ll_factored.hip) -> another FMA less: r - (1/2 + d) r^2 + r^3 / 3 with d = 0.2071 x 2^-18 chosen so
+// that d r^2 - r^4 / 4 equioscillates over |r| <= 2^-9 -- an absolute 6.2e-13 at most (3.6e-12 for the plain Taylor
+// cubic), against sums whose terms are |log p_j| >= 1 and a parity bar of 1e-9.
+// RAW (DEG 3 only): the exponent is not un-biased -- the result is log(x 2^-SC) + kLogRawBias(SC), one integer
+// subtract less per log; the caller takes the constant off once per SUM (h_j kLogRawBias summed over the counted keys
+// is a constant of the histogram).
+template <int SC>
+constexpr double kLogRawBias = (double)(1022 + SC) * 0.693147180559945309417232121458;
+template <int N, int DEG, int SC, bool RAW = false>
 __device__ __forceinline__ void fast_log_bits_n(const double (&x)[N], double (&out)[N], const double *tab_lds)
 {
     static_assert(kLogTableBits == 8, "table offset below takes the top 8 mantissa bits");
-    static_assert(DEG == 4 || DEG == 5, "log1p degree");
+    static_assert(DEG == 3 || DEG == 4 || DEG == 5, "log1p degree");
     double m[N], r[N], q[N], lp[N];
     int e[N];
     double2 ent[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int hi = __double2hiint(x[k]);
-        e[k] = (hi >> 20) - (1022 + SC);
+        e[k] = RAW ? (hi >> 20) : (hi >> 20) - (1022 + SC);
         m[k] = __builtin_amdgcn_frexp_mant(x[k]); // [0.5, 1): the mantissa bits are x's own
         const unsigned off = ((unsigned)hi >> 8) & 0xFF0u;
         ent[k] = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(tab_lds) + off);
@@ -191,14 +196,20 @@ __device__ __forceinline__ void fast_log_bits_n(const double (&x)[N], double (&o
 #pragma unroll
         for (int k = 0; k < N; ++k)
             q[k] = fma_vvs(r[k], q[k], 1.0 / 3.0);
-    } else {
+    } else if (DEG == 4) {
 #pragma unroll
         for (int k = 0; k < N; ++k)
             q[k] = fma_vvs(r[k], -0.25, 1.0 / 3.0);
     }
+    if (DEG == 3) {
 #pragma unroll
-    for (int k = 0; k < N; ++k)
-        q[k] = fma(r[k], q[k], -0.5);
+        for (int k = 0; k < N; ++k) // (1/3 in a vector register pair, as -1/4 was for degree 4: VOP3 reads ONE scalar pair)
+            q[k] = fma_vvs(r[k], 1.0 / 3.0, -(0.5 + 0.20710678118654752 * 0x1p-18));
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            q[k] = fma(r[k], q[k], -0.5);
+    }
 #pragma unroll
     for (int k = 0; k < N; ++k)
         lp[k] = fma(r[k] * r[k], q[k], r[k]);

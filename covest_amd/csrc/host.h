@@ -46,8 +46,17 @@ int fail_hip(hipError_t e, const char *what);
 // -- a quarter of a millisecond of a 1.1 ms time-to-argmin.  Per device, buffers of up to 8 MB, 64 MB at most; a buffer
 // is given only by an owner whose work on it is done (the destroy entry points wait for the device first), and taken by
 // best fit.  host_common.cpp.
-bool dev_cache_take(size_t bytes, void **ptr, size_t *cap);
-bool dev_cache_give(void *ptr, size_t cap);
+bool dev_cache_take(size_t bytes, void **ptr, size_t *cap, int *device);
+bool dev_cache_give(void *ptr, size_t cap, int device);
+// The cache protects itself (round 5): a buffer is handed on only once nothing can still be working on it.
+// An owner that has just waited for the device says so with a DeviceIdleScope around its releases (the destroy, clear
+// and grow paths); every other release -- a move-assignment, a destructor on an error path -- waits for the buffer's
+// device itself before it gives the buffer away, as the hipFree it replaces did.
+struct DeviceIdleScope {
+    DeviceIdleScope();
+    ~DeviceIdleScope();
+    static bool active();
+};
 // ... and the page-locked, device-mapped block (kPinnedBlockBytes) a grid handle's arg-min writes to: the winner in the
 // first 64 bytes, the records of the selection scan (kernels.h ScanRecords) behind them
 constexpr size_t kPinnedBlockBytes = 2048;
@@ -58,16 +67,17 @@ void pinned_block_give(void *p);
 struct DevBuf {
     void *ptr = nullptr;
     size_t cap = 0;
+    int device = -1; // the device the allocation lives on (the cache hands it to that device's handles only)
     DevBuf() = default;
     ~DevBuf() { release(); } // (round 4: an owner that goes away -- or an error path that returns -- frees what it holds)
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : ptr(o.ptr), cap(o.cap) { o.ptr = nullptr, o.cap = 0; }
+    DevBuf(DevBuf &&o) noexcept : ptr(o.ptr), cap(o.cap), device(o.device) { o.ptr = nullptr, o.cap = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept
     {
         if (this != &o) {
             release();
-            ptr = o.ptr, cap = o.cap;
+            ptr = o.ptr, cap = o.cap, device = o.device;
             o.ptr = nullptr, o.cap = 0;
         }
         return *this;
@@ -76,20 +86,36 @@ struct DevBuf {
     {
         if (bytes <= cap)
             return hipSuccess;
-        if (ptr)
-            (void)hipDeviceSynchronize(); // (growing: whatever still works on the old buffer finishes first -- hipFree waited too)
-        release();
-        if (dev_cache_take(bytes, &ptr, &cap))
+        release(); // (growing: whatever still works on the old buffer finishes first -- release waits, as hipFree did)
+        if (dev_cache_take(bytes, &ptr, &cap, &device))
             return hipSuccess;
         hipError_t e = hipMalloc(&ptr, bytes);
-        if (e == hipSuccess)
+        if (e == hipSuccess) {
             cap = bytes;
+            if (hipGetDevice(&device) != hipSuccess)
+                device = -1;
+        }
         return e;
     }
     void release()
     {
-        if (ptr && !dev_cache_give(ptr, cap))
-            (void)hipFree(ptr);
+        if (ptr) {
+            bool kept = false;
+            if (cap <= ((size_t)8 << 20) && device >= 0) { // (what the cache takes at all: host_common.cpp)
+                if (!DeviceIdleScope::active()) {
+                    int cur = -1;
+                    const bool other = hipGetDevice(&cur) == hipSuccess && cur != device;
+                    if (other)
+                        (void)hipSetDevice(device);
+                    (void)hipDeviceSynchronize();
+                    if (other)
+                        (void)hipSetDevice(cur);
+                }
+                kept = dev_cache_give(ptr, cap, device);
+            }
+            if (!kept)
+                (void)hipFree(ptr);
+        }
         ptr = nullptr;
         cap = 0;
     }
@@ -103,6 +129,7 @@ struct DevBuf {
 struct HostBuf {
     void *ptr = nullptr;
     size_t cap = 0;
+    unsigned flags = hipHostMallocPortable; // (any device of the process may copy from it)
     HostBuf() = default;
     ~HostBuf() { release(); }
     HostBuf(const HostBuf &) = delete;
@@ -116,7 +143,7 @@ struct HostBuf {
         ptr = nullptr;
         cap = 0;
         const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 16);
-        hipError_t e = hipHostMalloc(&ptr, want, hipHostMallocPortable); // (any device of the process may copy from it)
+        hipError_t e = hipHostMalloc(&ptr, want, flags);
         if (e == hipSuccess)
             cap = want;
         return e;
@@ -206,6 +233,7 @@ struct covest_model {
     // scratch for covest_eval_points / covest_probabilities
     DevBuf ws_params, ws_t, ws_out, ws_p, ws_plan, ws_plan2, ws_partial, ws_items;
     HostBuf ws_stage; // staging of a point list's tables (build_list_plan)
+    HostBuf ws_result; // page-locked, device-mapped: what a point-list launch leaves for the host (list mode 1's parts)
     DevBuf ws_sub_index, ws_sub_word, ws_sub_ctl; // the queue of handed-back points of a point-list launch (direct_point.h)
     std::mutex lock;
 };
@@ -280,6 +308,7 @@ struct covest_kmer {
     unsigned bulk_later_n = 0;              // buckets a workgroup (not a wave) counted
     unsigned long long bulk_to_table_n = 0; // buckets counted through the table in HBM
     bool bulk_table_used = false;           // ... and whether the table holds anything of the result
+    int64_t bulk_mem_limit = 0; // covest_kmer_memory_limit: bytes the buckets' records may take (0: what the device has free)
     hipEvent_t bulk_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // start, placed, scattered, counted, done
     float bulk_ms[4] = {0, 0, 0, 0};
     std::mutex lock;

@@ -50,7 +50,14 @@ DevCache &dev_cache()
 constexpr size_t kDevCacheEntryMax = (size_t)8 << 20, kDevCacheTotalMax = (size_t)64 << 20;
 } // namespace
 
-bool dev_cache_take(size_t bytes, void **ptr, size_t *cap)
+namespace {
+thread_local int tls_device_idle = 0;
+}
+DeviceIdleScope::DeviceIdleScope() { ++tls_device_idle; }
+DeviceIdleScope::~DeviceIdleScope() { --tls_device_idle; }
+bool DeviceIdleScope::active() { return tls_device_idle > 0; }
+
+bool dev_cache_take(size_t bytes, void **ptr, size_t *cap, int *device)
 {
     if (bytes == 0 || bytes > kDevCacheEntryMax)
         return false;
@@ -72,17 +79,15 @@ bool dev_cache_take(size_t bytes, void **ptr, size_t *cap)
         return false;
     *ptr = c.free_list[best].ptr;
     *cap = c.free_list[best].cap;
+    *device = dev;
     c.bytes -= c.free_list[best].cap;
     c.free_list.erase(c.free_list.begin() + (std::ptrdiff_t)best);
     return true;
 }
 
-bool dev_cache_give(void *ptr, size_t cap)
+bool dev_cache_give(void *ptr, size_t cap, int dev)
 {
-    if (!ptr || cap == 0 || cap > kDevCacheEntryMax)
-        return false;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess)
+    if (!ptr || cap == 0 || cap > kDevCacheEntryMax || dev < 0)
         return false;
     DevCache &c = dev_cache();
     std::lock_guard<std::mutex> hold(c.mu);

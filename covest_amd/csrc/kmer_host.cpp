@@ -135,6 +135,15 @@ int covest_kmer_clear(covest_kmer *c, void *stream)
     return COVEST_OK;
 }
 
+int covest_kmer_memory_limit(covest_kmer *c, int64_t max_bytes)
+{
+    if (!c || max_bytes < 0)
+        return fail(COVEST_E_INVALID, "covest_kmer_memory_limit: bad argument");
+    std::lock_guard<std::mutex> guard(c->lock);
+    c->bulk_mem_limit = max_bytes;
+    return COVEST_OK;
+}
+
 int covest_kmer_reserve(covest_kmer *c, int64_t min_slots)
 {
     if (!c)
@@ -418,8 +427,12 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const size_t have = c->bulk_recs.cap + c->bulk_ovf.cap;
-        if (((double)room + (double)p.overflow_cap * kOvfShards) * 16.0 > 0.85 * (double)(free_b + have))
+        const double want = ((double)room + (double)p.overflow_cap * kOvfShards) * 16.0;
+        if (want > 0.85 * (double)(free_b + have))
             return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: the buckets do not fit the free device memory");
+        if (c->bulk_mem_limit > 0 && want > (double)c->bulk_mem_limit)
+            return fail(COVEST_E_NOMEM, "covest_kmer_count_reads_device: the buckets do not fit the caller's limit "
+                                        "(covest_kmer_memory_limit)");
     }
     HIP_TRY(c->bulk_recs.reserve(std::max<size_t>((size_t)room, 1) * sizeof(ulonglong2)));
     HIP_TRY(c->bulk_ovf.reserve((size_t)p.overflow_cap * kOvfShards * sizeof(ulonglong2)));

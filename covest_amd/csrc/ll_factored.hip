@@ -60,10 +60,6 @@
 #include "streams.h"
 #include "wave.h"
 
-#ifndef COVEST_AB_FACTORED_CANCEL
-#define COVEST_AB_FACTORED_CANCEL 0
-#endif
-
 namespace covest {
 
 namespace {
@@ -135,7 +131,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // last-tile-first order of the tail-less grids apply.
     constexpr bool SPO = PLAIN && TAIL;
     constexpr bool NEED_SCAL = !PLAIN; // p_j itself is needed row by row: the chunks' shares, a point list's sp_j
-    constexpr int LOG_DEG = PLAIN ? 4 : 5;     // (point lists keep the 2e-16 log: refinements difference their values)
+    constexpr int LOG_DEG = PLAIN ? 3 : 5;     // (point lists keep the 2e-16 log: refinements difference their values;
+                                               // dense grids: 6e-13 absolute and the exponent's bias taken off per sum)
     const int LD = LDC ? LDC : plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
     __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
@@ -196,8 +193,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         for (int t = t_begin + lane; t < t_end; t += kWave)
             lc += tv.item_lconst[t];
         lc = wave_sum(lc);
-        if (lane == 0)
-            lconst_s = lc;
+        if (lane == 0) // (PLAIN: the logs come with the exponent's bias on, fastmath.h RAW -- off again for the whole sum:
+                       // sum of h_j over the counted keys of this workgroup's items, tiles.h suf_h; a plain grid has one segment)
+            lconst_s = PLAIN ? lc - kLogRawBias<kScaleBits> * tv.suf_h[0] : lc;
     }
     __syncthreads();
 
@@ -229,8 +227,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     if (wave_builds) { // (wave-uniform) the waves that build nothing skip the mixture weights' exps, divisions and logs
         // (the stream constants by the reference's own route for every lane: the lanes of a wave are copy numbers, their
         // rates o x lambda_s span all three regimes of StreamSet::init's shortcut, and a wave that takes all three pays more
-        // than the one route costs -- measured: C3 + 1.7 % with the shortcut)
-        st.template init<COVEST_AB_FACTORED_CANCEL != 0>(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab,
+        // than the one route costs -- measured, round 5: C3 0.675 against 0.667 ms with the shortcut)
+        st.template init<false>(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab,
                                                         log_tab, 8 * my_pass, n_total);
     } else {
         st.gone = 0u;
@@ -868,7 +866,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     // no branch on h (it differs between the lanes' rows): the four logs of a unit go through
                     // fast_log_bits_n stage by stage, their table reads in flight together.  (A dead lane's row may be
                     // 0 here: the log of those bits is a finite number nobody uses.)
-                    fast_log_bits_n<4, LOG_DEG, kScaleBits>(x4, lg4, log_tab);
+                    fast_log_bits_n<4, LOG_DEG, kScaleBits, PLAIN>(x4, lg4, log_tab);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         llacc[k] = fma(h4[r], lg4[r], llacc[k]);

@@ -408,11 +408,13 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
 {
     covest_model *m = g->model;
     g->has_plan = false;
-    if (!g->long_parts.empty())
+    if (!g->long_parts.empty()) {
         (void)hipDeviceSynchronize(); // (their buffers go back to the process's cache, host.h)
-    for (covest_grid::Part &part : g->long_parts)
-        part.buf.release();
-    g->long_parts.clear();
+        DeviceIdleScope idle;
+        for (covest_grid::Part &part : g->long_parts)
+            part.buf.release();
+        g->long_parts.clear();
+    }
     g->n_long_tiles = 0;
     if (!m->has_tiles || m->n_par != 5 || m->dm.n_err > 32)
         return COVEST_OK;
@@ -635,7 +637,9 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
         iptr.push_back(ibase + off);
         off += pr.second;
     }
-    HIP_TRY(hipMemcpy(buf.ptr, stage, stage_bytes, hipMemcpyHostToDevice));
+    // (asynchronous, from the model's page-locked staging memory: the launch queues up behind the copy on the null stream,
+    // and the caller waits for the stream before it builds another list -- covest_eval_points)
+    HIP_TRY(hipMemcpyAsync(buf.ptr, stage, stage_bytes, hipMemcpyHostToDevice, nullptr));
     pl = FactoredPlan{};
     pl.c_axis = dptr[0];
     pl.e_axis = dptr[0] + n;

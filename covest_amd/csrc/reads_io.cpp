@@ -149,6 +149,7 @@ struct covest_reads {
     bool wrapped = false; // FASTQ whose sequence / quality run over several lines (Bio.SeqIO reads those too): the general
                           // grammar, one record after the other, single-threaded (see parse_fastq_wrapped)
     const uint8_t *strict_malformed = nullptr; // where the 4-line parser gave up and handed over to the general grammar
+    const uint8_t *strict_bad = nullptr;       // ... or the "base" it refused there (a quality line it took for a sequence)
     int n_strategy = 0;
     uint64_t seed = 0;
     int n_threads = 1;
@@ -526,6 +527,9 @@ int covest_reads_next(covest_reads *r, int64_t max_bases, const uint8_t **bases,
                                                               std::to_string((long long)(r->strict_malformed - r->map)) +
                                                               " (@id, sequence, +, quality -- or wrapped: sequence lines, "
                                                               "+, as many quality characters)");
+            if (pc.malformed && r->strict_bad) // (the 4-line parser's complaint stands: the general grammar has no reading either)
+                return covest::set_error(COVEST_E_INVALID, std::string("covest_reads_next: base '") + (char)*r->strict_bad +
+                                                              "' outside acgtn (single_hash raises KeyError)");
             if (pc.malformed)
                 return covest::set_error(COVEST_E_INVALID, "covest_reads_next: malformed FASTQ record at byte " +
                                                               std::to_string((long long)(pc.malformed - r->map)) +
@@ -550,6 +554,8 @@ int covest_reads_next(covest_reads *r, int64_t max_bases, const uint8_t **bases,
         r->pos = (size_t)(stop - r->map);
         if (r->strict_malformed && stop > r->strict_malformed)
             r->strict_malformed = nullptr; // (the general grammar took what the 4-line parser could not)
+        if (r->strict_bad && stop > r->strict_bad)
+            r->strict_bad = nullptr;
         *bases = out.bases;
         *offsets = out.offsets.data();
         *n_reads = (int64_t)pc.lens.size();
@@ -601,6 +607,17 @@ int covest_reads_next(covest_reads *r, int64_t max_bases, const uint8_t **bases,
         if (pc.malformed) { // not a 4-line record: a file that wraps its lines from here on?  The general grammar decides
             r->wrapped = true;
             r->strict_malformed = pc.malformed;
+            r->cur ^= 1; // (this call's batch buffer again)
+            return covest_reads_next(r, max_bases, bases, offsets, n_reads);
+        }
+        // A "bad base" of the 4-line parser in a FASTQ file may be a QUALITY character: where only the quality wraps and
+        // its second line starts with '@' -- behind more plain records than fastq_looks_wrapped reads -- the parser takes
+        // that line for a header and the next '@id' line for a sequence (400 plain records, then
+        // "@w / ACGTACGT / + / IIII / @III / @x ..." is a file Bio.SeqIO reads).  The general grammar decides from this
+        // batch's start; the complaint is kept for the case that it has no reading either.
+        if (pc.bad && r->fastq) {
+            r->wrapped = true;
+            r->strict_bad = pc.bad;
             r->cur ^= 1; // (this call's batch buffer again)
             return covest_reads_next(r, max_bases, bases, offsets, n_reads);
         }

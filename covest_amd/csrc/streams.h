@@ -101,6 +101,8 @@ struct StreamSet {
         // matter -- `1.0 - exp(-x)` carries a relative 1.1e-16 / x, and what the tail term makes of it (point_fetch.h
         // exp_neg_rn, log_trunc_norm) -- so there the quotient is formed and logged as the reference forms it.  Between,
         // those roundings are below 7e-15 relative, the size of the device's and glibc's difference in exp(-x) before.
+        // CANCEL = false: every stream by the reference's route (K-factored: the lanes of a wave are copy numbers, their
+        // rates o x lambda_s span all three regimes, and a wave that takes all three pays more than the one route costs).
         const double ln_tot = CANCEL ? fast_log(tot, log_tab) : 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -108,11 +110,7 @@ struct StreamSet {
             if (live && x[s] > 0.0 && n_os[s] > 0.0) { // (a_os > 0 iff n_os > 0: tot is a finite positive number)
                 const double lx = fast_log(x[s], log_tab);
                 double c;
-#ifdef COVEST_AB_INIT_PLAIN
-                if (true) {
-#else
                 if (CANCEL ? x[s] < 0.015625 : true) {
-#endif
                     const double a = n_os[s] / tot;
                     c = a > 0.0 ? fast_log(a, log_tab) - log_trunc_norm(x[s], lx, norm_tab) : -INFINITY;
                 } else if (x[s] <= 200.0) {

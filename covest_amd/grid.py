@@ -145,37 +145,45 @@ class DenseGrid:
         if len(axes) != model.param_count:
             raise ValueError("need one axis per model parameter")
         self.model = model
-        self.axes = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in axes]
-        self.shape = tuple(len(a) for a in self.axes)
-        self.total = int(np.prod(self.shape, dtype=np.int64))
-        begin, end = (0, self.total) if flat_range is None else flat_range
-        self.flat_range = (int(begin), int(end))
+        ptrs, lens = self._take_axes(axes, flat_range)
         L = _capi.lib()
-        n = len(self.axes)
-        ptrs = (_DP * n)(*[a.ctypes.data_as(_DP) for a in self.axes])
-        lens = (ctypes.c_int64 * n)(*self.shape)
         h = ctypes.c_void_p()
-        _capi.check(L.covest_grid_create(model.handle, n, ptrs, lens, self.flat_range[0],
+        _capi.check(L.covest_grid_create(model.handle, len(self.axes), ptrs.ctypes.data, lens.ctypes.data, self.flat_range[0],
                                          self.flat_range[1], ctypes.byref(h)), "covest_grid_create")
         self._handle = h
         if hasattr(model, "_register_grid"):
             model._register_grid(self)
+
+    def _take_axes(self, axes, flat_range):
+        """The axes as ONE contiguous float64 buffer (self.axes are views into it) and what the C ABI wants of them:
+        an array of the axes' addresses and one of their lengths.  Kept cheap on purpose -- optimize_grid does this
+        every iteration."""
+        parts = [a if type(a) is np.ndarray and a.dtype == np.float64 and a.ndim == 1
+                 else np.asarray(a, dtype=np.float64).reshape(-1) for a in axes]
+        lens = [p.shape[0] for p in parts]
+        flat = np.concatenate(parts) if len(parts) > 1 else np.ascontiguousarray(parts[0])
+        self._flat = flat
+        self.axes, offs, at = [], [], 0
+        for n in lens:
+            self.axes.append(flat[at:at + n])
+            offs.append(at)
+            at += n
+        self.shape = tuple(lens)
+        self.total = math.prod(lens)
+        begin, end = (0, self.total) if flat_range is None else flat_range
+        self.flat_range = (int(begin), int(end))
+        base = flat.ctypes.data
+        self._abi_axes = (np.array([base + 8 * o for o in offs], dtype=np.uint64), np.array(lens, dtype=np.int64))
+        return self._abi_axes
 
     def reset(self, axes, flat_range=None):
         """Other axes and/or another block on the SAME handle (covest_grid_reset): the device memory stays; what
         optimize_grid does between its iterations."""
         if len(axes) != self.model.param_count:
             raise ValueError("need one axis per model parameter")
-        self.axes = [np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in axes]
-        self.shape = tuple(len(a) for a in self.axes)
-        self.total = int(np.prod(self.shape, dtype=np.int64))
-        begin, end = (0, self.total) if flat_range is None else flat_range
-        self.flat_range = (int(begin), int(end))
-        n = len(self.axes)
-        ptrs = (_DP * n)(*[a.ctypes.data_as(_DP) for a in self.axes])
-        lens = (ctypes.c_int64 * n)(*self.shape)
-        _capi.check(_capi.lib().covest_grid_reset(self._handle, n, ptrs, lens, self.flat_range[0], self.flat_range[1]),
-                    "covest_grid_reset")
+        ptrs, lens = self._take_axes(axes, flat_range)
+        _capi.check(_capi.lib().covest_grid_reset(self._handle, len(self.axes), ptrs.ctypes.data, lens.ctypes.data,
+                                                  self.flat_range[0], self.flat_range[1]), "covest_grid_reset")
         return self
 
     def close(self):

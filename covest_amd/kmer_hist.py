@@ -186,6 +186,12 @@ class KmerCounts:
             self.add_device(d_bases_ptr, n_reads, read_len, stream=stream)
         return "table"
 
+    def memory_limit(self, max_bytes):
+        """Bytes the partitioned path may allocate for its buckets' records (0: no cap but the free device memory); a
+        count_reads_device that would pass it takes the table path instead (covest_kmer_memory_limit)."""
+        _capi.check(_capi.lib().covest_kmer_memory_limit(self._handle, int(max_bytes)), "covest_kmer_memory_limit")
+        return self
+
     def partition_info(self):
         """How the last partitioned count went (covest_kmer_partition_info), as a dict."""
         out = (ctypes.c_int64 * 8)()

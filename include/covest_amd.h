@@ -248,6 +248,10 @@ int covest_kmer_count_reads_device(covest_kmer *c, const uint8_t *d_bases, const
  * found their bucket full, [5] buckets counted by a workgroup instead of a wave, [6] buckets counted through the table
  * in HBM, [7] records pass 1 wrote.  Diagnostics for the caller's log; no reference counterpart. */
 int covest_kmer_partition_info(const covest_kmer *c, int64_t out[8]);
+/* A cap on what the partitioned path may allocate for its buckets' records (bytes; 0 = no cap but the device's free
+ * memory): a caller that shares the card names its budget, and covest_kmer_count_reads_device answers COVEST_E_NOMEM
+ * where the buckets would pass it -- before it allocates them. */
+int covest_kmer_memory_limit(covest_kmer *c, int64_t max_bytes);
 /* ... and how long its steps took on the device, milliseconds (HIP events on the caller's stream): out[0] pass 0
  * (sample of the reads, room per bucket, their places), [1] pass 1 (records to their buckets), [2] pass 2 (the buckets
  * counted in LDS), [3] what was left for the table in HBM. */

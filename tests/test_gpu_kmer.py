@@ -367,6 +367,32 @@ run("k - 1 bases", ["A" * 20, "ACGTTGCAAGGCTTAACCGG"], 21, False)
 # k the partitioned path does not take
 run("k=12", genome_reads(3000, 60, 5000), 12, True, fixed_len=60, expect="table")
 assert any(p == "partitioned" for _, _, p in taken)
+# COVEST_E_NOMEM and what becomes of the memory (ADVICE round 3: a failed partitioned call left its buckets' records
+# allocated -- gigabytes at scale -- when the table path the wrapper falls back to needed them).  The caller's cap
+# (covest_kmer_memory_limit) makes the call answer COVEST_E_NOMEM before it allocates; the wrapper clears and counts
+# through the table, exactly; a partitioned count that did succeed gives its records back at clear().
+big = genome_reads(250000, 100, 1500000)          # 25 Mbp: ~4e6 records, ~100 MB of room for them
+blob = torch.from_numpy(np.frombuffer("".join(big).encode(), dtype=np.uint8).copy()).to(dev)
+want = ko.histogram(big, 21, canonical=True)
+torch.cuda.synchronize()
+c = kh.KmerCounts(21, canonical=True, min_slots=1 << 12)
+free0 = torch.cuda.mem_get_info()[0]
+assert c.count_reads_device(blob.data_ptr(), len(big), 100) == "partitioned"
+assert c.histogram() == want
+held = free0 - torch.cuda.mem_get_info()[0]
+assert held > 64 << 20, held                      # the records (and the small per-bucket arrays) are what it holds
+c.clear()
+torch.cuda.synchronize()
+after_clear = free0 - torch.cuda.mem_get_info()[0]
+assert after_clear < held - (64 << 20), (held, after_clear)    # ... and clear() gives the records back
+c.memory_limit(1 << 20)                           # a cap the buckets cannot meet
+assert c.count_reads_device(blob.data_ptr(), len(big), 100) == "table"
+assert "limit" in c.why_not_partitioned, c.why_not_partitioned
+assert c.histogram() == want                      # the fall-back counted every k-mer
+c.memory_limit(0)
+c.clear()
+assert c.count_reads_device(blob.data_ptr(), len(big), 100) == "partitioned" and c.histogram() == want
+c.close()
 print("partitioned ok", taken)
 """
 

@@ -1003,10 +1003,10 @@ def test_selection_scan_on_the_device(hip_lib):
     +inf never pass, ties keep the first index, a list longer than the device keeps comes back as None."""
     from covest_amd import DenseGrid, RepeatsModel
     from covest_amd.grid import first_wins_scan, replay_records
-    hist = load_hist("sim_c10_e0.05")
+    hist = {1: 1000, 2: 500, 150: 6000, 151: 40, 153: 7}  # (small coverages leave the far keys a p_j of 0: LL = -inf)
     m = RepeatsModel(21, 100, hist, 0, max_error=8)
-    axes = [np.linspace(5.0, 60.0, 9), np.linspace(0.001, 0.3, 6), np.linspace(0.3, 1.0, 6), [0.2, 0.5, float("nan")],
-            np.linspace(0.05, 0.95, 8)]
+    axes = [np.exp(np.linspace(np.log(0.05), np.log(60.0), 9)), np.linspace(0.001, 0.3, 6), np.linspace(0.3, 1.0, 6),
+            [0.2, 0.5, float("nan")], np.linspace(0.05, 0.95, 8)]
     grid = DenseGrid(m, axes)
     grid.evaluate()
     vals = -grid.loglikelihoods()
@@ -1033,7 +1033,7 @@ def test_selection_scan_on_the_device(hip_lib):
     assert (got[0], got[1] - lo, got[2]) == want
     part.close()
     # more strict records than the device keeps (a steadily falling objective along the fastest axis): None
-    bm_axes = [np.linspace(30.0, 10.5, 400), [0.05], [0.9], [0.5], [0.5]]
+    bm_axes = [np.linspace(20.0, 120.0, 400), [0.05], [0.9], [0.5], [0.5]]  # (towards the optimum near c = 150)
     long_grid = DenseGrid(m, bm_axes)
     long_grid.evaluate(scan_start=math.inf)
     v2 = -long_grid.loglikelihoods()

@@ -178,3 +178,16 @@ def test_fastq_with_wrapped_lines(tmp_path):
     n.write_text("@a\nACNN\nNGT\n+\nIIII\nIII\n")
     assert list(kh.load_reads(str(n), kh.NS_IGNORE)) == ["acgt"]
     assert list(kh.load_reads(str(n), kh.NS_SINGLE)) == ["acaaagt"]
+    # only the QUALITY wraps, its second line starts with '@', behind more plain records than the first look at the file
+    # reads: the 4-line parser takes "@III" for a header and "@x" for a sequence -- a "bad base" that
+    # is none; the general grammar reads the file as Bio.SeqIO does
+    q = tmp_path / "quality_wraps.fq"
+    q.write_text("".join("@p%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(400)) +
+                 "@w\nACGTACGT\n+\nIIII\n@III\n@x\nTTTTGGGG\n+\nIIIIIIII\n")
+    assert list(kh.load_reads(str(q), kh.NS_IGNORE)) == ["acgtacgtac"] * 400 + ["acgtacgt", "ttttgggg"]
+    # ... and a base that IS bad stays an error, whichever grammar looks at it
+    b = tmp_path / "bad_base.fq"
+    b.write_text("".join("@p%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(400)) + "@w\nACGXACGT\n+\nIIIIIIII\n")
+    with pytest.raises(Exception) as err:
+        list(kh.load_reads(str(b), kh.NS_IGNORE))
+    assert "outside acgtn" in str(err.value) or isinstance(err.value, KeyError)
