@@ -17,11 +17,11 @@ int grid_stage_begin(covest_grid *g, size_t bytes, StageSlot &slot)
     }
     const size_t at = (g->stage_off + 63) / 64 * 64;
     if (at + bytes > g->stage.cap) {
-        // (growing frees the old block: the copies queued from it finish first.  What they staged is then on the device,
-        // so the new block starts empty)
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        // (the block is outgrown: what it holds may still be read -- copies in flight, a small grid's axes read in
+        // place -- so it is set aside until the next reset, and a larger one takes over)
+        if (g->stage.ptr)
+            g->stage_retired.push_back(std::move(g->stage));
         HIP_TRY(g->stage.reserve(std::max<size_t>(2 * (at + bytes), 1 << 18)));
-        g->stage_off = 0;
         slot.ptr = g->stage.as<char>();
         g->stage_off = bytes;
         return COVEST_OK;
@@ -83,15 +83,20 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
     if (nq)
         threshold_table(m, axes[2], n1, axes[3], n2, axes[4], n3, table.data());
 
-    // arena layout: [axes | queue counter (8 B) | t_table] uploaded together, then the outputs
+    // arena layout: [queue counter (8 B, always at the start: its place does not move from grid to grid) | axes | t_table]
+    // uploaded together, then the outputs
     auto up8 = [](size_t v) { return (v + 7) / 8 * 8; };
-    const size_t o_axes = 0, o_ctl = o_axes + (size_t)n_values * sizeof(double), o_table = o_ctl + 8;
+    const size_t o_ctl = 0, o_axes = 8, o_table = o_axes + (size_t)n_values * sizeof(double);
     const size_t o_ll = up8(o_table + (size_t)nq * sizeof(int32_t)), n_pts = (size_t)(n > 0 ? n : 1);
     const size_t o_idx = o_ll + n_pts * sizeof(double), o_word = o_idx + n_pts * sizeof(int64_t);
     const size_t o_pv = o_word + n_pts * sizeof(unsigned long long), o_pi = o_pv + kArgminBlocks * sizeof(double);
     const size_t o_res = o_pi + kArgminBlocks * sizeof(int64_t), bytes = o_res + sizeof(ArgminResult);
+    const void *arena_before = g->arena.ptr;
+    const bool counter_clean = g->counter_clean; // (the queue counter is 0: set below, kept by every arg-min launch)
     HIP_TRY(g->arena.reserve(bytes));
     char *base = g->arena.as<char>();
+    char *host_base = nullptr;
+    bool in_place = false;
     {
         StageSlot slot;
         const int src = grid_stage_begin(g, o_ll, slot);
@@ -99,7 +104,7 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
             return src;
         char *stage = slot.ptr;
         std::memset(stage, 0, o_ll);
-        double *sa = reinterpret_cast<double *>(stage);
+        double *sa = reinterpret_cast<double *>(stage + o_axes);
         for (int d = 0; d < n_axes; ++d) {
             g->len[d] = axis_len[d];
             std::copy(axes[d], axes[d] + axis_len[d], sa);
@@ -109,13 +114,29 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
             g->len[d] = 1;
         if (nq)
             std::memcpy(stage + o_table, table.data(), (size_t)nq * sizeof(int32_t));
-        const int crc = grid_stage_commit(g, slot, base, o_ll);
-        if (crc != COVEST_OK)
-            return crc;
+        // A SMALL grid of a handle that is re-configured (optimize_grid's: a few thousand points, a kilobyte of axes and
+        // threshold_o) reads its axes and the table WHERE THEY ARE STAGED -- page-locked host memory mapped into the
+        // device's address space: every workgroup reads a handful of values, and the copy engine's start-up (11 us by
+        // the trace of a search, a sixth of an iteration) is not paid.  The queue counter behind the axes is device
+        // memory all the same (atomics): cleared by a memset on the stream.  Large grids -- every point of 10^6 reads
+        // its axes -- keep the copy.
+        in_place = g->async_uploads && n <= kArgminSmall;
+        if (in_place) {
+            host_base = stage;
+            // (the counter's place depends on the axes' lengths: cleared unless it is where a clean one was left)
+            if (!(counter_clean && g->arena.ptr == arena_before && g->sub_ctl.ptr == base + o_ctl)) {
+                HIP_TRY(hipMemsetAsync(base + o_ctl, 0, 8, nullptr));
+                g->upload_pending = true;
+            }
+        } else {
+            const int crc = grid_stage_commit(g, slot, base, o_ll);
+            if (crc != COVEST_OK)
+                return crc;
+        }
     }
-    g->axes.ptr = base + o_axes;
+    g->axes.ptr = (in_place ? host_base : base) + o_axes;
     g->sub_ctl.ptr = base + o_ctl;
-    g->t_table.ptr = base + o_table;
+    g->t_table.ptr = (in_place ? host_base : base) + o_table;
     g->ll.ptr = base + o_ll;
     g->sub_index.ptr = base + o_idx;
     g->sub_word.ptr = base + o_word;
@@ -160,6 +181,7 @@ static int grid_configure(covest_grid *g, int32_t n_axes, const double *const *a
             HIP_TRY(hipEventCreateWithFlags(&g->upload_ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(g->upload_ev, nullptr));
     }
+    g->counter_clean = true;
     g->configured = true;
     return COVEST_OK;
 }
@@ -173,6 +195,7 @@ static void grid_release(covest_grid *g)
         g->upload_ev = nullptr;
     }
     g->stage.release();
+    g->stage_retired.clear();
     if (g->result_host) {
         pinned_block_give(g->result_host);
         g->result_host = nullptr;
@@ -234,6 +257,7 @@ int covest_grid_reset(covest_grid *g, int32_t n_axes, const double *const *axes,
     if (g->upload_pending && !g->evaluated)
         HIP_TRY(hipStreamSynchronize(nullptr)); // (a reset that was never evaluated: its copies read the staging memory)
     g->upload_pending = false;
+    g->stage_retired.clear(); // (nothing of the last configuration is read any more)
     g->async_uploads = true; // (from the first reset on: a handle that is re-configured is re-configured often)
     return grid_configure(g, n_axes, axes, axis_len, flat_begin, flat_end, "covest_grid_reset");
 }

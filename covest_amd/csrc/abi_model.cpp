@@ -296,6 +296,9 @@ hipError_t launch_ll(const covest_model *m, int kernel, const PointSource &src, 
 
 } // namespace covest
 
+constexpr int64_t kInPlaceMaxPoints = 256;   // point lists up to this size: parameters and values in mapped host memory
+constexpr int64_t kInPlaceMaxListPoints = 4; // repeats model, list mode: tables read in place (13 KB a point, 8 workgroups each)
+
 static int reserve_point_queue(covest_model *m, int64_t n)
 {
     HIP_TRY(m->ws_sub_index.reserve((size_t)n * sizeof(int64_t)));
@@ -379,27 +382,57 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
     if (rc != COVEST_OK)
         return rc;
     const int P = m->n_par;
-    HIP_TRY(m->ws_params.reserve((size_t)n * P * sizeof(double)));
-    HIP_TRY(m->ws_out.reserve((size_t)n * sizeof(double)));
-    HIP_TRY(m->ws_t.reserve((size_t)n * sizeof(int32_t)));
-    {
-        const int qrc = reserve_point_queue(m, n);
-        if (qrc != COVEST_OK)
-            return qrc;
-    }
-    const SubList queue = sub_list_of(m, m->n_par == 5 ? 513 : 2, m->ws_sub_index.ptr, m->ws_sub_word.ptr, m->ws_sub_ctl.ptr);
+    // A SMALL list (what scipy's refinement issues: a point and its P finite-difference neighbours) moves nothing through
+    // the copy engine (round 5): its parameters are read, and its values written, IN PLACE in page-locked host memory
+    // mapped into the device's address space -- one launch (two with the strict pass) and one wait for the stream; a
+    // blocking copy either side of the launch was two thirds of a basic-model evaluation's 48 us.
+    const bool in_place = n <= kInPlaceMaxPoints;
     PointSource src{};
     src.is_grid = 0;
-    src.params = m->ws_params.as<double>();
-    src.t_list = P == 5 ? m->ws_t.as<int32_t>() : nullptr;
-    if (kern != COVEST_KERNEL_FACTORED) // (the list mode uploads its own tables: every copy is ~10 us of latency)
-        HIP_TRY(hipMemcpy(m->ws_params.ptr, params, (size_t)n * P * sizeof(double), hipMemcpyHostToDevice));
-    if (P == 5 && kern != COVEST_KERNEL_FACTORED) {
-        std::vector<int32_t> t((size_t)n);
-        for (int64_t i = 0; i < n; ++i)
-            t[(size_t)i] = threshold_for_point(m, params + i * P);
+    double *out_dev = nullptr; // where the kernels leave the values: HBM, or (in_place) the mapped host block
+    SubList queue = sub_list_of(m, m->n_par == 5 ? 513 : 2, nullptr, nullptr, nullptr); // (list mode and K-direct hand nothing back)
+    if (kern != COVEST_KERNEL_FACTORED) {
+        std::vector<int32_t> t;
+        if (P == 5) {
+            t.resize((size_t)n);
+            for (int64_t i = 0; i < n; ++i)
+                t[(size_t)i] = threshold_for_point(m, params + i * P);
+        }
+        const size_t par_bytes = (size_t)n * P * sizeof(double), t_bytes = ((size_t)n * sizeof(int32_t) + 7) / 8 * 8;
+        if (in_place) {
+            HIP_TRY(m->ws_stage.reserve(par_bytes + t_bytes));
+            HIP_TRY(m->ws_result.reserve((size_t)n * sizeof(double)));
+            char *st = m->ws_stage.as<char>();
+            std::memcpy(st, params, par_bytes);
+            if (P == 5)
+                std::memcpy(st + par_bytes, t.data(), (size_t)n * sizeof(int32_t));
+            src.params = reinterpret_cast<const double *>(st);
+            src.t_list = P == 5 ? reinterpret_cast<const int32_t *>(st + par_bytes) : nullptr;
+            out_dev = m->ws_result.as<double>();
+        } else {
+            HIP_TRY(m->ws_params.reserve(par_bytes));
+            HIP_TRY(m->ws_out.reserve((size_t)n * sizeof(double)));
+            HIP_TRY(hipMemcpy(m->ws_params.ptr, params, par_bytes, hipMemcpyHostToDevice));
+            src.params = m->ws_params.as<double>();
+            if (P == 5) {
+                HIP_TRY(m->ws_t.reserve((size_t)n * sizeof(int32_t)));
+                HIP_TRY(hipMemcpy(m->ws_t.ptr, t.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+                src.t_list = m->ws_t.as<int32_t>();
+            }
+            out_dev = m->ws_out.as<double>();
+        }
+        if (kern == COVEST_KERNEL_RECUR) { // K-basic hands points back through the queue (direct_point.h): empty on entry
+            HIP_TRY(m->ws_sub_index.reserve((size_t)n * sizeof(int64_t)));
+            HIP_TRY(m->ws_sub_word.reserve((size_t)n * sizeof(unsigned long long)));
+            HIP_TRY(m->ws_sub_ctl.reserve(sizeof(unsigned)));
+            HIP_TRY(hipMemsetAsync(m->ws_sub_ctl.ptr, 0, sizeof(unsigned), nullptr));
+            queue = sub_list_of(m, 2, m->ws_sub_index.ptr, m->ws_sub_word.ptr, m->ws_sub_ctl.ptr);
+        }
+    } else {
+        HIP_TRY(m->ws_out.reserve((size_t)n * sizeof(double)));
+        HIP_TRY(m->ws_params.reserve((size_t)n * P * sizeof(double)));
         HIP_TRY(m->ws_t.reserve((size_t)n * sizeof(int32_t)));
-        HIP_TRY(hipMemcpy(m->ws_t.ptr, t.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+        src.params = m->ws_params.as<double>();
         src.t_list = m->ws_t.as<int32_t>();
     }
     if (kern == COVEST_KERNEL_FACTORED) {
@@ -424,7 +457,8 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
                 sub_t[k] = t[(size_t)fits[k]];
             }
             FactoredPlan pl;
-            rc = build_list_plan(m, (int64_t)fits.size(), sub_par.data(), sub_t, nullptr, m->ws_plan, pl);
+            rc = build_list_plan(m, (int64_t)fits.size(), sub_par.data(), sub_t, nullptr, m->ws_plan, pl,
+                                 (int64_t)fits.size() <= kInPlaceMaxListPoints);
             if (rc != COVEST_OK)
                 return rc;
             // {LL part, sp_j part (hi, lo), side word} per (point, key segment); the segments are added here, in order
@@ -533,8 +567,13 @@ int covest_eval_points(covest_model *m, int64_t n, const double *params, double 
         return fix_points_host(m, n, params, out_ll, words);
     }
     // (K-basic is followed by the pass that patches the points it handed back: launch_ll)
-    HIP_TRY(launch_ll(m, kern, src, n, m->ws_out.as<double>(), queue, nullptr, nullptr));
-    HIP_TRY(hipMemcpy(out_ll, m->ws_out.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(launch_ll(m, kern, src, n, out_dev, queue, nullptr, nullptr));
+    if (in_place) {
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        std::memcpy(out_ll, out_dev, (size_t)n * sizeof(double));
+    } else {
+        HIP_TRY(hipMemcpy(out_ll, out_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return COVEST_OK;
 }
 

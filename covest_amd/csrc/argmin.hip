@@ -371,27 +371,49 @@ __global__ __launch_bounds__(256) void argmin_stage2(const double *__restrict__ 
 }
 
 // A small grid (optimize_grid's have a few thousand points, C1 2 500): both stages in ONE workgroup and one launch.
-__global__ __launch_bounds__(256) void argmin_small(const double *__restrict__ ll, int64_t n, int64_t flat_begin,
-                                                    ArgminResult *__restrict__ result, ArgminResult *__restrict__ host_mirror,
-                                                    unsigned *__restrict__ queue_count)
+// kSmallThreads threads, every thread's loads issued four at a time (round 5: 256 threads walked their 31 values of a
+// 7 776-point grid one dependent load after the other -- 12 us for 62 KB by the trace of an optimize_grid search).
+constexpr int kSmallThreads = 1024;
+
+// The values of a small grid, negated, through `take(i, -ll[i])` in ascending i per thread.
+template <class Take>
+__device__ __forceinline__ void small_grid_values(const double *__restrict__ ll, int64_t n, Take take)
+{
+    for (int64_t base = threadIdx.x; base < n; base += 4 * kSmallThreads) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = base + (int64_t)u * kSmallThreads;
+            v[u] = i < n ? -ll[i] : INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = base + (int64_t)u * kSmallThreads;
+            if (i < n)
+                take(i, v[u]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSmallThreads) void argmin_small(const double *__restrict__ ll, int64_t n, int64_t flat_begin,
+                                                             ArgminResult *__restrict__ result, ArgminResult *__restrict__ host_mirror,
+                                                             unsigned *__restrict__ queue_count)
 {
     if (threadIdx.x == 0 && queue_count)
         *queue_count = 0;
     Cand c;
     c.v = INFINITY;
     c.i = INT64_MAX;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { // ascending i within a thread: strict < keeps the first
-        const double v = -ll[i];
+    small_grid_values(ll, n, [&](int64_t i, double v) { // ascending i within a thread: strict < keeps the first
         if (v < c.v) {
             c.v = v;
             c.i = i;
         }
-    }
+    });
     c = block_best(c);
     if (threadIdx.x == 0)
         publish(c, flat_begin, result, host_mirror);
 }
-
 
 // The selection scan of covest/grid.py:65-70 ON THE DEVICE, for the caller that runs it every iteration
 // (optimize_grid): started from `start` -- the minimum the search holds when the iteration begins -- the loop
@@ -403,47 +425,57 @@ __global__ __launch_bounds__(256) void argmin_small(const double *__restrict__ l
 // One workgroup (grids up to kArgminSmall points); the values are staged in LDS, every thread owns a contiguous run of
 // them: its minimum, an exclusive prefix minimum across the threads, then its own records behind a prefix sum.  A NaN
 // never passes `<`.  More than kScanCap records: `truncated`, and the caller reads the array back as before.
-__global__ __launch_bounds__(256) void argmin_scan_small(const double *__restrict__ ll, int64_t n, int64_t flat_begin, double start,
-                                                         ArgminResult *__restrict__ result, ArgminResult *__restrict__ host_mirror,
-                                                         ScanRecords *__restrict__ scan, unsigned *__restrict__ queue_count)
+__global__ __launch_bounds__(kSmallThreads) void argmin_scan_small(const double *__restrict__ ll, int64_t n, int64_t flat_begin,
+                                                                  double start, ArgminResult *__restrict__ result,
+                                                                  ArgminResult *__restrict__ host_mirror,
+                                                                  ScanRecords *__restrict__ scan, unsigned *__restrict__ queue_count)
 {
+    constexpr int NW = kSmallThreads / kWave;
     extern __shared__ double vals[]; // [n] -LL
-    __shared__ double pre_v[256];
-    __shared__ int pre_n[256];
-    const int tid = threadIdx.x;
+    __shared__ double wave_min[NW];
+    __shared__ int wave_cnt[NW];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
     if (tid == 0 && queue_count)
         *queue_count = 0;
     Cand c;
     c.v = INFINITY;
     c.i = INT64_MAX;
-    for (int64_t i = tid; i < n; i += 256) { // coalesced; ascending i within a thread: strict < keeps the first
-        const double v = -ll[i];
+    small_grid_values(ll, n, [&](int64_t i, double v) { // coalesced; ascending i within a thread: strict < keeps the first
         vals[i] = v;
         if (v < c.v) {
             c.v = v;
             c.i = i;
         }
-    }
+    });
     c = block_best(c); // (ends with a barrier: vals is complete)
     if (tid == 0)
         publish(c, flat_begin, result, host_mirror);
-    const int chunk = (int)((n + 255) / 256);
+    // every thread a contiguous run of the values; prefix minimum and prefix count across the threads by shuffles
+    // inside a wave and a word per wave across them (two barriers in all)
+    const int chunk = (int)((n + kSmallThreads - 1) / kSmallThreads);
     const int lo = min((int)n, tid * chunk), hi = min((int)n, lo + chunk);
     double m = INFINITY;
     for (int i = lo; i < hi; ++i)
         m = vals[i] < m ? vals[i] : m;
-    pre_v[tid] = m;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) { // inclusive prefix minimum (Hillis-Steele)
-        const double o = tid >= off ? pre_v[tid - off] : INFINITY;
-        __syncthreads();
-        pre_v[tid] = o < pre_v[tid] ? o : pre_v[tid];
-        __syncthreads();
+    double incl = m; // inclusive prefix minimum inside the wave
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const double o = __shfl_up(incl, off, kWave);
+        if (lane >= off)
+            incl = o < incl ? o : incl;
     }
-    // the running minimum this thread's run starts from: `start`, or the smallest value before the run
+    if (lane == kWave - 1)
+        wave_min[w] = incl;
+    __syncthreads();
+    // the running minimum this thread's run starts from: `start`, the waves before, the lanes before
     double run0 = start;
-    if (tid > 0 && pre_v[tid - 1] < run0)
-        run0 = pre_v[tid - 1];
+    for (int k = 0; k < w; ++k)
+        run0 = wave_min[k] < run0 ? wave_min[k] : run0;
+    {
+        const double before = __shfl_up(incl, 1, kWave);
+        if (lane > 0 && before < run0)
+            run0 = before;
+    }
     double run = run0;
     int cnt = 0;
     for (int i = lo; i < hi; ++i)
@@ -451,15 +483,22 @@ __global__ __launch_bounds__(256) void argmin_scan_small(const double *__restric
             run = vals[i];
             ++cnt;
         }
-    pre_n[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) { // inclusive prefix sum
-        const int o = tid >= off ? pre_n[tid - off] : 0;
-        __syncthreads();
-        pre_n[tid] += o;
-        __syncthreads();
+    int pre = cnt; // inclusive prefix count inside the wave
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(pre, off, kWave);
+        if (lane >= off)
+            pre += o;
     }
-    int at = pre_n[tid] - cnt;
+    if (lane == kWave - 1)
+        wave_cnt[w] = pre;
+    __syncthreads();
+    int at = pre - cnt, total = 0;
+    for (int k = 0; k < NW; ++k) {
+        if (k < w)
+            at += wave_cnt[k];
+        total += wave_cnt[k];
+    }
     run = run0;
     for (int i = lo; i < hi; ++i)
         if (vals[i] < run) {
@@ -470,11 +509,10 @@ __global__ __launch_bounds__(256) void argmin_scan_small(const double *__restric
             }
             ++at;
         }
-    if (tid == 255) {
+    if (tid == 0) {
         scan->start = start;
-        scan->truncated = pre_n[255] > kScanCap ? 1 : 0;
-        __threadfence_system(); // (the records before the count that says they are there)
-        scan->n = min(pre_n[255], kScanCap);
+        scan->truncated = total > kScanCap ? 1 : 0;
+        scan->n = min(total, kScanCap);
     }
 }
 
@@ -497,7 +535,7 @@ hipError_t launch_argmin_scan(const double *ll, int64_t n, int64_t flat_begin, d
             return e;
         raised[dev] = true;
     }
-    hipLaunchKernelGGL(argmin_scan_small, dim3(1), dim3(256), lds, stream, ll, n, flat_begin, start, result, host_mirror, scan,
+    hipLaunchKernelGGL(argmin_scan_small, dim3(1), dim3(kSmallThreads), lds, stream, ll, n, flat_begin, start, result, host_mirror, scan,
                        queue_count);
     return hipGetLastError();
 }
@@ -523,7 +561,7 @@ hipError_t launch_argmin(const double *ll, int64_t n, int64_t flat_begin, double
                          ArgminResult *result, ArgminResult *host_mirror, unsigned *queue_count, hipStream_t stream)
 {
     if (n <= kArgminSmall) {
-        hipLaunchKernelGGL(argmin_small, dim3(1), dim3(256), 0, stream, ll, n, flat_begin, result, host_mirror, queue_count);
+        hipLaunchKernelGGL(argmin_small, dim3(1), dim3(kSmallThreads), 0, stream, ll, n, flat_begin, result, host_mirror, queue_count);
         return hipGetLastError();
     }
     // (a small grid needs no more workgroups than it has waves of points)

@@ -129,11 +129,13 @@ struct DevBuf {
 struct HostBuf {
     void *ptr = nullptr;
     size_t cap = 0;
-    unsigned flags = hipHostMallocPortable; // (any device of the process may copy from it)
+    unsigned flags = hipHostMallocPortable | hipHostMallocMapped; // (any device of the process may copy from it -- or read
+                                                                  // and write it in place: small point lists, abi_model.cpp)
     HostBuf() = default;
     ~HostBuf() { release(); }
     HostBuf(const HostBuf &) = delete;
     HostBuf &operator=(const HostBuf &) = delete;
+    HostBuf(HostBuf &&o) noexcept : ptr(o.ptr), cap(o.cap), flags(o.flags) { o.ptr = nullptr, o.cap = 0; }
     hipError_t reserve(size_t bytes)
     {
         if (bytes <= cap)
@@ -274,11 +276,14 @@ struct covest_grid {
     ArgminResult *result_host = nullptr; // page-locked mirror of `result` (+ the scan's records: scan_host())
     ScanRecords *scan_host() const { return reinterpret_cast<ScanRecords *>(reinterpret_cast<char *>(result_host) + 64); }
     bool scan_valid = false; // the last evaluation left the records of the selection scan (covest_grid_eval_scan)
+    bool counter_clean = false; // the hand-back queue's counter (sub_ctl) is known to be 0 where it lies
     // covest_grid_reset stages what it uploads in page-locked memory OF THE HANDLE and copies asynchronously (the null
     // stream; an evaluation on another stream waits for upload_ev): the kernels queue up behind the copies and an
     // optimize_grid iteration waits for the device once, when it reads its result.  The staging memory of one reset
     // stays untouched until the next (stage_off only grows; a buffer that must grow waits for the copies first).
     HostBuf stage;
+    std::vector<HostBuf> stage_retired; // blocks the staging outgrew during a reset: what they hold may still be read
+                                        // (copies in flight, tables read in place) -- freed by the next reset
     size_t stage_off = 0;
     bool async_uploads = false;
     bool upload_pending = false;
@@ -357,7 +362,7 @@ double copy_number_weight_host(double q1, double q2, double q, int o);
 int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t *axis_len,
                         const std::vector<int32_t> &t_table);
 int build_list_plan(covest_model *m, int64_t n, const double *params, const std::vector<int32_t> &t_list,
-                    const std::vector<int32_t> *o_base_list, DevBuf &buf, FactoredPlan &pl);
+                    const std::vector<int32_t> *o_base_list, DevBuf &buf, FactoredPlan &pl, bool in_place = false);
 
 // ---- abi_model.cpp: kernel dispatch shared with the grid entry points
 int resolve_kernel(const covest_model *m, int32_t kernel, const covest_grid *g);

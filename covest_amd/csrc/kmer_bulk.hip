@@ -499,7 +499,10 @@ __device__ __forceinline__ unsigned lds_slot(u64 key, unsigned smask)
 // Every k-mer of the lane's record (none: rec.y == 0) into the table, false: the table is full.  The lanes of a wave
 // go through their records side by side but each at its own pace -- ONE flat loop, a probe per turn: a lane whose probe
 // hit counts and moves on to its next k-mer while its neighbours still probe (nested loops -- k-mers outside, probes
-// inside -- cost three scalar instructions of mask bookkeeping per vector instruction).
+// inside -- cost three scalar instructions of mask bookkeeping per vector instruction).  (Measured and not kept, round 5:
+// TWO windows of a record per turn, the even and the odd ones with a probe state each, so that a wave has two
+// compare-and-swaps in flight -- pass 2 43.8 -> 55.2 ms at 10 Gbp, profiles/r05_c5_ab_two_windows_per_turn_not_kept.txt:
+// the LDS applies a wave's atomics one after the other either way, and the second state costs registers and selects.)
 __device__ __forceinline__ bool insert_record(ulonglong2 rec, u64 *keys, unsigned *cnts, unsigned slots, u64 kmask,
                                               const KmerBulk &p)
 {

@@ -194,6 +194,8 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
                 for (int b = 0; b < 16; b += 2) {
                     double g1, g2;
                     st.template step2n<N>(xx, g1, g2);
+                    // (measured and not kept, round 5: the two logs of a key pair through fast_log_bits_n<2>, their table
+                    // reads in flight together -- 6 spilled registers at 128, C2 0.176 against 0.166 ms)
                     account(g1 * sc[b], hc[b], t * kTileBins + 16 * half + b);
                     account(g2 * sc[b + 1], hc[b + 1], t * kTileBins + 16 * half + b + 1);
                 }
@@ -283,7 +285,32 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
         const double lx0 = st.an.lx(0), c0 = st.an.c(0);
         bool skipped = false;
         for (; t < tv.n_tiles; ++t) {
+            // (the one stream has GONE -- off in every lane of the wave, outside the window, past its mode, streams.h -- and
+            // the rest only enters sp_j: every later p_j is an exact zero.  The far end of a long histogram: with c around
+            // 4000 the keys beyond 4500 of C2's 10 000 add nothing, and walking them was most of a tail-carrying launch)
+            if (sums_only && (st.gone & 1u))
+                break;
             bool ll_done = sums_only;
+            if (sums_only) {
+                // ... and long before it has gone it has stopped MATTERING to a sum: sp_j is a sum of p_j <= 2.5 whose
+                // error is felt in absolute terms (tail * log(1 - sp_j)), so a key whose p_j is below e^-60 = 9e-27 adds
+                // nothing a double of sp_j can hold -- ten thousand of them 1e-22.  log p_j is concave in j: over a tile
+                // that does not hold the mode x_0 its largest value is at an end.  A tile that is negligible for every
+                // lane is skipped (the stream anchored afresh behind it), and once every lane is past its mode the walk
+                // ends: the stream is walked 11 standard deviations either side of its mode instead of 39.
+                const double k0 = tv.first_key[t], klast = k0 + (double)(tv.n_bins[t] - 1);
+                const double lp_lo = fma(k0 - 1.0, lx0, c0 - tv.lgam_prev[t]);
+                const double lp_hi = fma(klast, lx0, c0 - tv.lgam_last[t]);
+                const double x0 = st.x[0];
+                const bool holds_mode = x0 >= k0 - 2.0 && x0 <= klast + 1.0;
+                const bool matters = !(fmax(lp_lo, lp_hi) < -60.0) || holds_mode; // (a NaN: matters)
+                if (!__any(finite && matters)) { // wave-uniform
+                    if (!__any(finite && !(x0 < k0 - 2.0)))
+                        break; // every lane is past its mode: nothing later matters either
+                    skipped = true;
+                    continue;
+                }
+            }
             if (!sums_only) {
                 const double k0 = tv.first_key[t];
                 const double lp_lo = fma(k0 - 1.0, lx0, c0 - tv.lgam_prev[t]); // (at the key before the tile: a superset)

@@ -108,7 +108,7 @@ __device__ __forceinline__ void contract_step(int i, const double *cur, const in
 // LDC: the row stride of G as a COMPILE-TIME constant (0: plan.ld) -- kLdWide = 290, the stride of every plain grid whose
 // largest threshold_o - 1 lies in 257 .. 288 (C3: 284): the 32 stores of a tile's walk and the fragments' offsets become
 // immediates (round 4).
-constexpr int kLdWide = 290;
+[[maybe_unused]] constexpr int kLdWide = 290;
 template <int NT, int HU, bool TAIL, bool PLAIN, int LDC = 0>
 __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                          const double *__restrict__ tile_dbl,
@@ -392,6 +392,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         st.template leave_tile_n<N>(renorm);
         return tsum;
     };
+    // (streams.h: classes that no longer matter beside a lower one are retired lane by lane -- in the tiles with counts,
+    // wherever the keys are walked in ascending order from here on: not in the tile a plain grid takes out of turn, the
+    // last one first)
+    bool drop_ok = true;
     auto build_tile = [&](int t, bool seg_start, double *dst) __attribute__((always_inline)) -> double {
         if (COVEST_SKIP_PHASE(plan, 1))
             return 0.0;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const int nb = tv.n_bins[t];
         // n_live: streams above it are zero in every lane of this wave (streams.h) -- most of them, for most tiles
         const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                                         tv.run_start[t] != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
+                                         tv.run_start[t] != 0 || seg_start, drop_ok); // (a key segment starts like a run: every stream anchored)
         if (diag) { // (diagnostic builds: entering the tile apart from walking it)
             const long long now__ = (long long)clock64();
             dg_enter += now__ - dg_t0;
@@ -491,8 +495,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     auto build_tile_sum = [&](int t, bool seg_start) __attribute__((always_inline)) -> double {
         const double k0 = tv.first_key[t];
         const int nb = tv.n_bins[t];
-        const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                                         tv.run_start[t] != 0 || seg_start);
+        // (SPO: the tile only enters S[o] -- streams.h enter_sum_tile: a stream is on where it matters to a sum)
+        const int n_live = SPO ? st.enter_sum_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
+                                                   tv.run_start[t] != 0 || seg_start)
+                               : st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
+                                               tv.run_start[t] != 0 || seg_start);
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         if (nb == kTileBins && !(SPO && tv.has_filler[t] != 0)) { // (the count-less tiles of a histogram's tail are full ones: the live streams only)
             if (n_live > 2)
@@ -517,8 +524,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 return;
             const int n = __builtin_amdgcn_readfirstlane(tv.item_ntiles[it]);
             if (SPO) { // the tiles without a count only enter S[o]: nothing is stored, nothing contracted
-                for (int r = 0; r < n; ++r)
+                for (int r = 0; r < n; ++r) {
+                    // (every stream of this wave's copy numbers has GONE -- off in all lanes, outside the window, past its
+                    // mode, streams.h: exact zeros from here on.  The far end of a long histogram: a wave of small copy
+                    // numbers is done with H10k_rep's 10 000 keys after the first two thousand)
+                    if (st.gone == 0xFFu && !(seg_start && r == 0))
+                        break;
                     so.add(build_tile_sum(first + r, seg_start && r == 0));
+                }
                 return;
             }
             double *colp = dst + (lane_in_row ? tid : 0);
@@ -604,6 +617,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
             fetch_rows(pb + 1 < t_end ? tile_at(pb + 1) : t_end);
             if (wave_builds) {
+                drop_ok = !(last_first && pb == t_begin); // (the tile taken out of turn: tile 0 follows it)
+#ifdef COVEST_EXP_NO_DROP
+                drop_ok = false;
+#endif
                 if (last_first && pb == t_begin + 1)
                     st.gone = 0u;
                 build_item(tile_at(pb), pb == t_begin || (last_first && (pb == t_begin + 1 || pb == last_item + 1)),

@@ -555,8 +555,12 @@ int build_factored_plan(covest_grid *g, const double *const *axes, const int64_t
 // K-direct's single wave looping over every (key, o, s).  Built per call: ~13 KB of tables per point.
 // An item is a point (o_base 0, list_mode 1) or a chunk of a point's copy numbers (list_mode 2): params of the
 // point, threshold_o of the point, copy numbers before the chunk.
+// in_place: the kernel reads the tables where they are staged -- page-locked host memory mapped into the device's
+// address space -- instead of from a copy in HBM: for a handful of points (13 KB of tables each, read once by the
+// point's 8 workgroups) the reads over the link cost less than the copy engine's start-up, 15-20 us of a single
+// evaluation's 65.
 int build_list_plan(covest_model *m, int64_t n, const double *params, const std::vector<int32_t> &t_list,
-                    const std::vector<int32_t> *o_base_list, DevBuf &buf, FactoredPlan &pl)
+                    const std::vector<int32_t> *o_base_list, DevBuf &buf, FactoredPlan &pl, bool in_place)
 {
     constexpr int NW = 8, MU = kMaxUnits;
     auto o_base_of = [&](int64_t i) { return o_base_list ? (*o_base_list)[(size_t)i] : 0; };
@@ -616,12 +620,13 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
         n_dbl += pr.second;
     for (auto &pr : iparts)
         n_int += pr.second;
-    HIP_TRY(buf.reserve(n_dbl * sizeof(double) + n_int * sizeof(int32_t)));
     // one staging buffer (page-locked, the model's), one copy
     const size_t stage_bytes = n_dbl * sizeof(double) + n_int * sizeof(int32_t);
     HIP_TRY(m->ws_stage.reserve(stage_bytes));
     char *stage = m->ws_stage.as<char>();
-    double *dbase = buf.as<double>();
+    if (!in_place)
+        HIP_TRY(buf.reserve(stage_bytes));
+    double *dbase = in_place ? reinterpret_cast<double *>(stage) : buf.as<double>();
     int32_t *ibase = reinterpret_cast<int32_t *>(dbase + n_dbl);
     std::vector<const double *> dptr;
     std::vector<const int32_t *> iptr;
@@ -639,7 +644,8 @@ int build_list_plan(covest_model *m, int64_t n, const double *params, const std:
     }
     // (asynchronous, from the model's page-locked staging memory: the launch queues up behind the copy on the null stream,
     // and the caller waits for the stream before it builds another list -- covest_eval_points)
-    HIP_TRY(hipMemcpyAsync(buf.ptr, stage, stage_bytes, hipMemcpyHostToDevice, nullptr));
+    if (!in_place)
+        HIP_TRY(hipMemcpyAsync(buf.ptr, stage, stage_bytes, hipMemcpyHostToDevice, nullptr));
     pl = FactoredPlan{};
     pl.c_axis = dptr[0];
     pl.e_axis = dptr[0] + n;

@@ -136,21 +136,42 @@ struct StreamSet {
     // changes no bit.  The error classes' rates fall geometrically with s (covest/models.py:74-79), so along the
     // keys the streams go out from the top: beyond the first few hundred keys one or two of the eight are left.
     __device__ __forceinline__ int enter_tile(double km1, double klast, double lgam_prev,
-                                              double lgam_last, bool run_start)
+                                              double lgam_last, bool run_start, bool drop_ok = false)
     {
-        return enter_tile_n<S>(km1, klast, lgam_prev, lgam_last, run_start);
+        return enter_tile_n<S>(km1, klast, lgam_prev, lgam_last, run_start, drop_ok);
+    }
+
+    // Entering a tile whose keys only enter a SUM (sp_j, covest/models.py:103: the tiles without a count of a histogram
+    // with a tail): a term below e^-60 = 9e-27 adds nothing a double of that sum can hold (p_j <= 2.5; ten thousand
+    // such terms are 1e-22), so a stream is anchored only once its log-term passes kSumWindowLn inside the tile, and one
+    // that is on, has fallen below it and is past its mode is switched off -- a stream is walked 11 standard deviations
+    // either side of its mode instead of 39.  `gone` is still decided on the real window: a later tile WITH counts takes
+    // logs of p_j down to e^-745 and anchors the stream again if it reaches that far.
+    static constexpr double kSumWindowLn = -60.0;
+    __device__ __forceinline__ int enter_sum_tile(double km1, double klast, double lgam_prev, double lgam_last, bool run_start)
+    {
+        return enter_tile_n<S, true>(km1, klast, lgam_prev, lgam_last, run_start, false);
     }
 
     // ... looking at the streams 0 .. N-1 only: for a caller that has seen the others go for good (`gone`)
-    template <int N>
+    // drop_ok (wave-uniform; keys walked in ASCENDING order from here on): a stream that no longer matters beside a
+    // stream of a lower class is retired for good, lane by lane (round 5).  The classes' rates fall with s
+    // (covest/models.py:74-79: x_(s+1) / x_s = e / (3 (1 - e)) < 1 for e < 3/4), and the ratio of two streams' terms at
+    // key j, u_s(j) / u_s'(j) ~ (x_s / x_s')^j for s' < s, only FALLS along the keys: once v[s] <= 2^-60 v[s'] it stays
+    // so for every later key -- the stream adds less than 1e-18 of p_j there, nothing a double of p_j can hold -- and it
+    // is switched off in that lane (its anchor constants go, so it is never anchored again).  Without this a class
+    // stays live until its terms underflow to exact zeros, e^-760: the first hundreds of keys are walked with all eight
+    // streams though two or three carry every bit of p_j -- for a histogram trimmed as the reference trims it that is
+    // every tile.
+    template <int N, bool SUM_ONLY = false>
     __device__ __forceinline__ int enter_tile_n(double km1, double klast, double lgam_prev,
-                                                double lgam_last, bool run_start)
+                                                double lgam_last, bool run_start, bool drop_ok = false)
     {
         // Round 4: the questions of all streams are asked FIRST (compares into scalar masks, no branch), then ONE branch
         // for the rare case that some stream must be anchored, then the masks of what is live / gone.  (Until then every
         // stream took three compare-then-branch round trips through the scalar unit, one after the other: a tenth of a
         // builder wave's time in K-factored.)  Same decisions, same arithmetic, stream by stream.
-        uint64_t m_window[N], m_need[N];
+        uint64_t m_window[N], m_need[N], m_real[SUM_ONLY ? N : 1];
         double a0s[N];
         uint64_t any_need = 0;
 #pragma unroll
@@ -167,7 +188,13 @@ struct StreamSet {
             // anchor was a SUBNORMAL double, a handful of significant bits carried along by every later multiply;
             // below -745 it was 0 and the stream re-entered correctly.  Found by the C3 fixture with a tail:
             // sp_j off by 2e-10 where those streams have their mass.)
-            m_window[s] = __ballot(fmax(a0, a1) > kWindowLn);
+            const double top = fmax(a0, a1);
+            m_window[s] = __ballot(top > (SUM_ONLY ? kSumWindowLn : kWindowLn));
+            if (SUM_ONLY) {
+                m_real[s] = __ballot(top > kWindowLn);
+                // on, below what a sum can hold at both ends of the tile, past its mode (it only falls from here): off
+                v[s] = (!(top > kSumWindowLn) && km1 >= x[s]) ? 0.0 : v[s];
+            }
             m_need[s] = run_start ? m_window[s] : (__ballot(v[s] == 0.0) & m_window[s]);
             if (run_start)
                 v[s] = 0.0; // what is left of the run before means nothing here
@@ -187,6 +214,21 @@ struct StreamSet {
                 v[s] = (m_need[s] & me) ? anchored : v[s];
             }
         }
+        if (N > 2 && drop_ok) { // (wave-uniform)
+            double vmax = v[0]; // the largest term among the lower classes that are on in this lane
+#pragma unroll
+            for (int s = 1; s < N; ++s) {
+                if ((gone >> s) & 1u)
+                    continue;
+                const bool drop = v[s] != 0.0 && v[s] <= vmax * 0x1p-60;
+                if (__any(drop)) { // wave-uniform, a few tiles per stream
+                    v[s] = drop ? 0.0 : v[s];
+                    x[s] = drop ? 0.0 : x[s];
+                    an.set(s, drop ? 0.0 : an.lx(s), drop ? -INFINITY : an.c(s));
+                }
+                vmax = fmax(vmax, v[s]);
+            }
+        }
         int n_live = 0;
 #pragma unroll
         for (int s = 0; s < N; ++s) {
@@ -195,7 +237,7 @@ struct StreamSet {
             const uint64_t m_on = __ballot(v[s] != 0.0);
             // off, outside the window and past the mode (the log-term is concave in the key, its top near x): in every
             // lane, for every later key
-            const uint64_t m_stay = m_window[s] | __ballot(!(km1 >= x[s]));
+            const uint64_t m_stay = (SUM_ONLY ? m_real[s] : m_window[s]) | __ballot(!(km1 >= x[s]));
             if (m_on != 0)
                 n_live = s + 1; // wave-uniform
             else if (m_stay == 0)

@@ -117,7 +117,10 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, int32_t ni, const
 constexpr int kMaxUnits = 6;       // accumulator slots per wave
 constexpr int kHalfUnits = 3;      // (kept for the 256-thread capacity rule: 4 waves x 6 slots)
 constexpr int kBuildCost = 18;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3; 36 before round 3 took the scales and the scalar-load stalls out of phase A)
-constexpr int kListSegments = 8;   // key segments of a point-list evaluation (list mode): latency of ONE point
+#ifndef COVEST_LIST_SEGMENTS
+#define COVEST_LIST_SEGMENTS 16 // (8 until round 5: one evaluation on a 10 000-key histogram 53 -> 45 us, six 67 -> 56; 64: 173 -> 215)
+#endif
+constexpr int kListSegments = COVEST_LIST_SEGMENTS; // key segments of a point-list evaluation (list mode): latency of ONE point
 constexpr int kMinPieceSteps = 6;  // pieces are not made shorter than this
 constexpr int kSharedStepsPerMfma = 4; // cost of the shared steps in the assignment: this many weigh one MFMA step (5 until the fine sweep at the end of round 4: -0.7 %)
 constexpr int kMinSharedSteps = 3; // fewer shared steps than this are left to the MFMA steps

@@ -14,7 +14,7 @@ One session-local alias is needed: covest/models.py:10 does
 copied.  Interpreter-dependent semantics are recorded in every fixture's "env".
 
 Usage:  python tests/golden/make_golden.py [section ...]
-Sections: tp basic repeats threshold hists c1 c2 c2classes c2trim c3 c3tail c3trim c3argmin gridtrace overflow   (default: all)
+Sections: tp basic repeats threshold hists c1 c2 c2classes c2trim c2argmin c3 c3tail c3trim c3argmin gridtrace overflow   (default: all)
 (c3argmin reads c3_candidates_gpu.json: flat indices written on the GPU box by tools/dump_c3_candidates.py;
  c2classes reads c2_classes_gpu.json: flat indices written on the GPU box by tools/dump_c2_classes.py)
 """
@@ -638,6 +638,32 @@ def section_c3argmin(pool):
                                 hist="H10k_rep", k=21, r=100, max_error=8))
 
 
+def section_c2argmin(pool):
+    """SURVEY.md 8(d) parity procedure for config 2 without a tail (round 5: until then its arg-min was judged by the
+    oracle, config 3's by the reference): the REFERENCE evaluated at the GPU's top-64 candidates and at the 2 P axis
+    neighbours of the GPU's arg-min (flat indices written on the GPU box by tools/dump_c3_candidates.py into
+    c2_candidates_gpu.json; only indices are taken from that file), and the reference's own winner among them under
+    the scan of covest/grid.py:65-70 (strict <, first index wins)."""
+    hist = synth_hist("H10k_basic", pool)
+    src = os.environ.get("COVEST_C2_CANDIDATES", os.path.join(HERE, "c2_candidates_gpu.json"))
+    with open(src) as f:
+        cand_all = json.load(f)
+    cand = sorted(int(i) for i in cand_all["tail0"]["candidates"])
+    res = pool.map(_ll_sp_job, [("basic", hist, 0, c2_point(i)) for i in cand], chunksize=2)
+    ll = [v for v, _, _ in res]
+    best, arg = None, -1
+    for i, v in zip(cand, ll):
+        if v == v and (best is None or -v < best):
+            best, arg = -v, i
+    out = {"tail0": {"flat_index": cand, "points": [list(c2_point(i)) for i in cand], "ll": ll, "sp": [s for _, _, s in res],
+                     "cpu_seconds_per_point": [t for _, t, _ in res], "reference_argmin_flat": arg,
+                     "reference_min_negll": best, "gpu_argmin_flat": int(cand_all["tail0"]["argmin_flat"])}}
+    print("c2argmin reference winner", arg, best, "GPU said", cand_all["tail0"]["argmin_flat"], flush=True)
+    dump("c2_argmin.json", dict(out, what="config 2 arg-min candidates (GPU top-64 + axis neighbours of its arg-min) "
+                                          "evaluated by the reference; BasicModel on H10k_basic.hist, tail 0",
+                                hist="H10k_basic", k=21, r=100, max_error=8))
+
+
 # ----------------------------------------------------------------------------- (7) grid traces
 class NegLogLikelihood:
     """Picklable adapter with the contract of CoverageEstimator.likelihood_f
@@ -726,13 +752,13 @@ def section_overflow():
 
 
 def main():
-    wanted = sys.argv[1:] or ["tp", "basic", "repeats", "threshold", "hists", "c1", "c2", "c2classes", "c2trim", "c3", "c3tail", "c3trim",
-                              "c3argmin", "gridtrace", "overflow"]
+    wanted = sys.argv[1:] or ["tp", "basic", "repeats", "threshold", "hists", "c1", "c2", "c2classes", "c2trim", "c2argmin", "c3", "c3tail",
+                              "c3trim", "c3argmin", "gridtrace", "overflow"]
     pool = multiprocessing.Pool(int(os.environ.get("COVEST_GOLDEN_PROCS", "8")))
     for name in wanted:
         t0 = time.time()
         fn = globals()["section_" + name]
-        if name in ("hists", "c1", "c2", "c2classes", "c2trim", "c3", "c3tail", "c3trim", "c3argmin"):
+        if name in ("hists", "c1", "c2", "c2classes", "c2trim", "c2argmin", "c3", "c3tail", "c3trim", "c3argmin"):
             fn(pool)
         else:
             fn()

@@ -1,10 +1,8 @@
-# A/B of two builds of libcovest_amd.so in ONE GPU run (same box, same clocks):
-#   tools/ab.sh <lib_a.so> <lib_b.so> [workloads...]     (default workloads: c2 c3; 400 timed steps behind 50 warm-up
-#   steps: at 20 steps the device's clocks are still coming up, profiles/r04_clock_ramp.txt)
-a=$1; b=$2; shift 2
-wl=${*:-c2 c3}
+# A/B of several builds of libcovest_amd.so in ONE GPU run (same box, same clocks), two rounds each:
+#   WL="c3 c3t" tools/ab.sh lib_a.so lib_b.so ...      (columns: ms per step, kernel bracket ms, roofline.frac)
+wl=${WL:-c2 c3}
 for i in 1 2; do
-  for lib in "$a" "$b"; do
+  for lib in "$@"; do
     for w in $wl; do
       echo -n "$(basename $lib) $w: "
       COVEST_AMD_LIB=$PWD/$lib python bench.py --workload $w --steps ${AB_STEPS:-400} --warmup 50 --cpu-budget 0 --no-variants 2>/dev/null |

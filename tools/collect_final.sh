@@ -1,5 +1,5 @@
 #!/bin/bash
-# The evidence the bench line's numbers rest on, for the round's FINAL library (the long form is collect_profiles.sh):
+# The evidence the bench line's numbers rest on, for the round's FINAL library:
 #   tools/collect_final.sh <tag>   -> gpurun_out/<tag>/: the default bench line (with its child-run variants), rocprofv3
 #   kernel stats and PMC passes of C3 and C2 (separate runs, program after `--`, no child processes under the profiler),
 #   the phase stamps of the diagnostic build, the whole GPU test suite.

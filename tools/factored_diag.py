@@ -9,11 +9,12 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("COVEST_FACTORED_DIAG", "1")
-from bench import load_hist, workload  # noqa: E402
+from bench import load_hist, workload, workload_tail  # noqa: E402
 from covest_amd import DenseGrid, RepeatsModel, _capi  # noqa: E402
 
-kind, hname, axes = workload("c3", 1)
-m = RepeatsModel(21, 100, load_hist(hname), float(os.environ.get("COVEST_DIAG_TAIL", "0")), max_error=8)  # COVEST_DIAG_TAIL=1000: all 10 000 keys
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"  # c3, or c3t: the trimmed histogram with its tail
+kind, hname, axes = workload(wl, 1)
+m = RepeatsModel(21, 100, load_hist(hname), float(os.environ.get("COVEST_DIAG_TAIL", str(workload_tail(wl)))), max_error=8)  # COVEST_DIAG_TAIL=1000 with c3: all 10 000 keys
 g = DenseGrid(m, axes)
 g.evaluate(kernel="factored")
 g.argmin()
@@ -24,7 +25,7 @@ L.covest_grid_diag(g._handle, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
 d = buf.reshape(-1, 8, 8)[:, :, :4].astype(np.float64)  # [wg][wave][build, contract, log, barrier]
 extra = buf.reshape(-1, 8, 8)
 print("workgroups", d.shape[0])
-print("key tiles (of %d) whose 64 G columns of a builder wave were all zero: " % 31 +
+print("key tiles (of %d) whose 64 G columns of a builder wave were all zero: " % m.bins_evaluated +
       "  ".join("wave %d: %.1f" % (w, extra[:, w, 5].mean()) for w in range(5)))
 tot = d.sum(axis=2)
 print("mean cycles per wave (s_memtime ticks): total %.0f" % tot.mean())
