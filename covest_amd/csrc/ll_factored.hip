@@ -392,10 +392,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         st.template leave_tile_n<N>(renorm);
         return tsum;
     };
-    // (streams.h: classes that no longer matter beside a lower one are retired lane by lane -- in the tiles with counts,
-    // wherever the keys are walked in ascending order from here on: not in the tile a plain grid takes out of turn, the
-    // last one first)
-    bool drop_ok = true;
     auto build_tile = [&](int t, bool seg_start, double *dst) __attribute__((always_inline)) -> double {
         if (COVEST_SKIP_PHASE(plan, 1))
             return 0.0;
@@ -403,7 +399,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const int nb = tv.n_bins[t];
         // n_live: streams above it are zero in every lane of this wave (streams.h) -- most of them, for most tiles
         const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                                         tv.run_start[t] != 0 || seg_start, drop_ok); // (a key segment starts like a run: every stream anchored)
+                                         tv.run_start[t] != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
         if (diag) { // (diagnostic builds: entering the tile apart from walking it)
             const long long now__ = (long long)clock64();
             dg_enter += now__ - dg_t0;
@@ -517,6 +513,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         return SPO ? gsum * 0x1p476 : gsum * (1.0 / kBasicScale); // (SPO: S[o] is kept times 2^SC)
     };
     // One item into `dst`: a plain tile, or (TAIL) the per-tile sums of up to 32 count-less tiles as its rows.
+    bool resync = false; // (SPO, wave-uniform) tiles were skipped: the next one walked anchors every stream afresh
     auto build_item = [&](int it, bool seg_start, double *dst) __attribute__((always_inline)) {
         const int first = TAIL ? __builtin_amdgcn_readfirstlane(tv.item_first[it]) : it;
         if (TAIL && tv.item_sum[it] != 0) {
@@ -524,13 +521,42 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 return;
             const int n = __builtin_amdgcn_readfirstlane(tv.item_ntiles[it]);
             if (SPO) { // the tiles without a count only enter S[o]: nothing is stored, nothing contracted
+                // The whole item -- up to 32 tiles, 1024 keys -- at a glance first: a stream's log-term is concave in the
+                // key, so where the item does not hold its mode its largest value over the item is at an end.  If that is
+                // below what a sum can hold (streams.h kSumWindowLn) for every stream of every lane of this wave, nothing
+                // of the item reaches S[o]: it is skipped for the price of two multiply-adds a stream, where entering
+                // each of its tiles in turn costs a thousand cycles a tile -- the long count-less stretch of a 10 000-key
+                // histogram is mostly such items (a wave's copy numbers have their mass within a few hundred keys).
+                // The streams are anchored afresh at the next tile that is walked (resync), as at the start of a run.
+                if (!seg_start) {
+                    const int tl = first + n - 1;
+                    const double ka = tv.first_key[first] - 1.0, kb = tv.first_key[tl] + (double)(tv.n_bins[tl] - 1);
+                    const double lga = tv.lgam_prev[first], lgb = tv.lgam_last[tl];
+                    bool matters = false;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        if ((st.gone >> s) & 1u)
+                            continue; // (wave-uniform)
+                        const double lx = st.an.lx(s), c = st.an.c(s);
+                        const double top = fmax(fma(ka, lx, c - lga), fma(kb, lx, c - lgb));
+                        matters = matters || !(top < StreamSet<8>::kSumWindowLn) || (st.x[s] >= ka - 1.0 && st.x[s] <= kb + 1.0);
+                    }
+                    if (!__any(matters)) { // wave-uniform
+#pragma unroll
+                        for (int s = 0; s < 8; ++s)
+                            st.v[s] = 0.0;
+                        resync = true;
+                        return;
+                    }
+                }
                 for (int r = 0; r < n; ++r) {
                     // (every stream of this wave's copy numbers has GONE -- off in all lanes, outside the window, past its
                     // mode, streams.h: exact zeros from here on.  The far end of a long histogram: a wave of small copy
                     // numbers is done with H10k_rep's 10 000 keys after the first two thousand)
                     if (st.gone == 0xFFu && !(seg_start && r == 0))
                         break;
-                    so.add(build_tile_sum(first + r, seg_start && r == 0));
+                    so.add(build_tile_sum(first + r, (seg_start && r == 0) || resync));
+                    resync = false;
                 }
                 return;
             }
@@ -544,7 +570,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 if (lane_in_row)
                     colp[r * LD] = 0.0;
         } else {
-            const double tsum = build_tile(first, seg_start, dst);
+            const double tsum = build_tile(first, seg_start || (SPO && resync), dst);
+            resync = false;
             if (SPO)
                 so.add(tsum);
         }
@@ -617,10 +644,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             }
             fetch_rows(pb + 1 < t_end ? tile_at(pb + 1) : t_end);
             if (wave_builds) {
-                drop_ok = !(last_first && pb == t_begin); // (the tile taken out of turn: tile 0 follows it)
-#ifdef COVEST_EXP_NO_DROP
-                drop_ok = false;
-#endif
                 if (last_first && pb == t_begin + 1)
                     st.gone = 0u;
                 build_item(tile_at(pb), pb == t_begin || (last_first && (pb == t_begin + 1 || pb == last_item + 1)),

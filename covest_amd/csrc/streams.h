@@ -136,9 +136,9 @@ struct StreamSet {
     // changes no bit.  The error classes' rates fall geometrically with s (covest/models.py:74-79), so along the
     // keys the streams go out from the top: beyond the first few hundred keys one or two of the eight are left.
     __device__ __forceinline__ int enter_tile(double km1, double klast, double lgam_prev,
-                                              double lgam_last, bool run_start, bool drop_ok = false)
+                                              double lgam_last, bool run_start)
     {
-        return enter_tile_n<S>(km1, klast, lgam_prev, lgam_last, run_start, drop_ok);
+        return enter_tile_n<S>(km1, klast, lgam_prev, lgam_last, run_start);
     }
 
     // Entering a tile whose keys only enter a SUM (sp_j, covest/models.py:103: the tiles without a count of a histogram
@@ -150,22 +150,19 @@ struct StreamSet {
     static constexpr double kSumWindowLn = -60.0;
     __device__ __forceinline__ int enter_sum_tile(double km1, double klast, double lgam_prev, double lgam_last, bool run_start)
     {
-        return enter_tile_n<S, true>(km1, klast, lgam_prev, lgam_last, run_start, false);
+        return enter_tile_n<S, true>(km1, klast, lgam_prev, lgam_last, run_start);
     }
 
     // ... looking at the streams 0 .. N-1 only: for a caller that has seen the others go for good (`gone`)
-    // drop_ok (wave-uniform; keys walked in ASCENDING order from here on): a stream that no longer matters beside a
-    // stream of a lower class is retired for good, lane by lane (round 5).  The classes' rates fall with s
-    // (covest/models.py:74-79: x_(s+1) / x_s = e / (3 (1 - e)) < 1 for e < 3/4), and the ratio of two streams' terms at
-    // key j, u_s(j) / u_s'(j) ~ (x_s / x_s')^j for s' < s, only FALLS along the keys: once v[s] <= 2^-60 v[s'] it stays
-    // so for every later key -- the stream adds less than 1e-18 of p_j there, nothing a double of p_j can hold -- and it
-    // is switched off in that lane (its anchor constants go, so it is never anchored again).  Without this a class
-    // stays live until its terms underflow to exact zeros, e^-760: the first hundreds of keys are walked with all eight
-    // streams though two or three carry every bit of p_j -- for a histogram trimmed as the reference trims it that is
-    // every tile.
+    // (Measured and not kept, round 5: RELATIVE retirement -- a stream switched off, lane by lane, once its term is below
+    // 2^-60 of a lower class's, which it then stays for every later key (the ratio of two classes' terms falls like
+    // (x_s / x_s')^j).  It takes the classes 2 .. 7 out of the first four tiles instead of the first two, and costs a
+    // compare and a select per live class and tile, 26 more spilled scalars and, with a tail, 13 spilled vector
+    // registers: C3 0.695 against 0.677 ms, the trimmed histogram 0.432 against 0.414 --
+    // profiles/r05_c3_ab_relative_retirement_not_kept.txt.)
     template <int N, bool SUM_ONLY = false>
     __device__ __forceinline__ int enter_tile_n(double km1, double klast, double lgam_prev,
-                                                double lgam_last, bool run_start, bool drop_ok = false)
+                                                double lgam_last, bool run_start)
     {
         // Round 4: the questions of all streams are asked FIRST (compares into scalar masks, no branch), then ONE branch
         // for the rare case that some stream must be anchored, then the masks of what is live / gone.  (Until then every
@@ -212,21 +209,6 @@ struct StreamSet {
                 // tail*log(1 - sp_j) amplifies by 1/(1 - sp_j).
                 const double anchored = exp_scaled(a0s[s], kScaleBits);
                 v[s] = (m_need[s] & me) ? anchored : v[s];
-            }
-        }
-        if (N > 2 && drop_ok) { // (wave-uniform)
-            double vmax = v[0]; // the largest term among the lower classes that are on in this lane
-#pragma unroll
-            for (int s = 1; s < N; ++s) {
-                if ((gone >> s) & 1u)
-                    continue;
-                const bool drop = v[s] != 0.0 && v[s] <= vmax * 0x1p-60;
-                if (__any(drop)) { // wave-uniform, a few tiles per stream
-                    v[s] = drop ? 0.0 : v[s];
-                    x[s] = drop ? 0.0 : x[s];
-                    an.set(s, drop ? 0.0 : an.lx(s), drop ? -INFINITY : an.c(s));
-                }
-                vmax = fmax(vmax, v[s]);
             }
         }
         int n_live = 0;

@@ -1,19 +1,30 @@
 #!/bin/bash
 # Copy the evidence tools/collect_final.sh left under gpurun_out/<tag>/ into profiles/ under the round's names, and
 # refresh profiles/pmc_traffic.json from the PMC summaries:   tools/publish_profiles.sh <tag> [round prefix, default r05]
-set -e
 tag=$1; r=${2:-r05}; src=gpurun_out/$tag
-cp $src/bench_default.json profiles/${r}_bench_default_with_variants.json
+put() { [ -s "$src/$1" ] && cp "$src/$1" "profiles/${r}_$2"; }
+put bench_default.json bench_default_with_variants.json
 for w in c3 c2 c3t c2t; do
-  cp $src/bench_$w.json profiles/${r}_bench_$w.json
-  cp $src/bench_${w}_under_rocprof.json profiles/${r}_bench_${w}_under_rocprof.json
-  cp $src/${w}_kernel_stats.csv profiles/${r}_${w}_kernel_stats.csv
-  cp $src/${w}_pmc_summary.json profiles/${r}_${w}_pmc_summary.json
+  put bench_$w.json bench_$w.json
+  put bench_${w}_under_rocprof.json bench_${w}_under_rocprof.json
+  put ${w}_kernel_stats.csv ${w}_kernel_stats.csv
+  put ${w}_pmc_summary.json ${w}_pmc_summary.json
 done
-[ -s $src/c3_factored_phase_stamps.txt ] && cp $src/c3_factored_phase_stamps.txt profiles/${r}_c3_factored_phase_stamps.txt
-cp $src/time_to_argmin_split.txt profiles/${r}_time_to_argmin_split.txt
-cp $src/bench_og.json profiles/${r}_bench_og.json
-cp $src/bench_c3_strong_1gpu.json profiles/${r}_bench_c3_strong_1gpu.json
-cp $src/gpu_tests_full.log profiles/${r}_gpu_tests_full.log
+put c3_factored_phase_stamps.txt c3_factored_phase_stamps.txt
+put c3t_factored_phase_stamps.txt c3t_factored_phase_stamps.txt
+put tail_timing.txt tail_timing.txt
+put time_to_argmin_split.txt time_to_argmin_split.txt
+put latency_single_evaluation.txt latency_single_evaluation.txt
+put bench_og.json bench_og.json
+put bench_c3_strong_1gpu.json bench_c3_strong_1gpu.json
+put bench_c1.json bench_c1.json
+put bench_f2.json bench_f2.json
+put bench_f3.json bench_f3.json
+put gpu_tests_full.log gpu_tests_full.log
+put gpu_tests_fuzz300_seeds.log gpu_tests_fuzz300_seeds.log
+put own_optimum.log own_optimum.log
+put bench_c5_10gbp.json bench_c5_10gbp.json
+put c5_10gbp_kernel_stats.csv c5_10gbp_kernel_stats.csv
+put c5_10gbp_pmc_summary.json c5_10gbp_pmc_summary.json
 python3 tools/pmc_to_traffic.py $r > /dev/null
 ls profiles | grep -c "^${r}_"
