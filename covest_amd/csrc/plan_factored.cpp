@@ -104,7 +104,9 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     // (decided by the WHOLE grid's (c, e) count, not the block's: a point's value may not depend on how the grid was
     // cut into blocks, and the assignment of units to waves fixes the order of its sums)
     const int64_t n_ce_grid = std::max<int64_t>(1, g->len[0] * g->len[1]);
-    const int want_blocks = n_ce_grid >= 192 ? 1 : (int)std::min<int64_t>(n_qtiles, (256 + n_ce_grid - 1) / n_ce_grid);
+    // (as many as FIT the chip in one round: 36 (c, e) pairs x 8 would be 288 workgroups for 256 CUs, a second round for the
+    // last 32 -- round 5: 7, by the trace of an optimize_grid search whose K-factored launches took 25 us for 15 keys)
+    const int want_blocks = n_ce_grid >= 192 ? 1 : (int)std::min<int64_t>(n_qtiles, std::max<int64_t>(1, 256 / n_ce_grid));
     const int n_qblocks = std::max(std::max(1, (n_units + cap_block - 1) / cap_block), want_blocks);
     // cost model of the assignment, in MFMA steps: a unit costs its steps (in every pass) plus its share of the
     // logs; a builder wave starts with the cost of phase A (tuned on C3 with the in-kernel stamps)
