@@ -884,7 +884,7 @@ def main():
                 rec = doc.get(args.workload, {})
                 traffic = rec.get(kernel_name)
                 executed = rec.get(kernel_name + "_executed_flops")
-                profile_sha = doc.get("_source_sha16")
+                profile_sha = rec.get("_source_sha16", doc.get("_source_sha16"))
             except (OSError, ValueError):
                 traffic = None
         out = {
@@ -904,6 +904,7 @@ def main():
                                     "grid c%dxe1000" % (model.bins_evaluated, tail, shape[0]),
                              "c1": "C1: BasicModel k=21 r=100 S=8, H256.hist, grid c%dxe50" % shape[0]}[args.workload],
                 "grid_points": total, "points_per_gpu": n_local, "kernel": kernel_name,
+                "library_source_sha16": source_sha16(),
                 "partition": "contiguous flat-index block per GPU balanced by sum(T-1), one RCCL all-gather of 16-byte "
                              "(min, index) pairs per step (taken from the arg-min kernel's output in HBM, scanned on the "
                              "device, 16 bytes copied back)",

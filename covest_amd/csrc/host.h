@@ -223,6 +223,7 @@ struct covest_model {
     // work accounting of K-factored over the item table (tiles.h): rows that are contracted (32 per item: a sum item
     // stands for up to 1024 keys) and keys that take a log
     double rows_contracted = 0.0, keys_logged = 0.0;
+    double low_tile_share = 0.0; // share of the tile table's tiles that start at a key <= kLowKeyTile (plan_factored.cpp)
     bool tail_is_zero = true;
     double threshold = 0.0;
     bool has_threshold = true;

@@ -135,10 +135,11 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     // the tile's share of sum h_j log p_j is accounted for already (the closed form below) -- its keys only enter sp_j.
     auto do_tile = [&](auto n_tag, int t, bool force_start, bool ll_done) __attribute__((always_inline)) {
         constexpr int N = decltype(n_tag)::value;
-        const double k0 = tv.first_key[t];
-        const int nb = tv.n_bins[t];
-        st.template enter_tile_n<N>(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                                    tv.run_start[t] != 0 || force_start); // (behind skipped tiles: anchored afresh)
+        const TileRec rc = tv.rec[t]; // (the tile's constants: one scalar load of one cache line, tiles.h)
+        const double k0 = rc.k0;
+        const int nb = rc.nb;
+        st.template enter_tile_n<N>(k0 - 1.0, k0 + (double)(nb - 1), rc.lgam_prev, rc.lgam_last,
+                                    rc.run_start != 0 || force_start); // (behind skipped tiles: anchored afresh)
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         const double *cnt = tv.cnt + (int64_t)t * kTileBins;
         double xx[S]; // squared rates, recomputed per tile (N multiplies) rather than held in 2 S registers
@@ -151,7 +152,7 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
                 xx[s] = s < N ? xs * xs : 0.0;
             }
         }
-        if (TAIL && (ll_done || tv.all_zero[t] != 0)) {
+        if (TAIL && (ll_done || rc.all_zero != 0)) {
             // a tile without a single count (they exist only with a tail), or one whose logs the closed form has
             // taken care of: its keys take no log, only their p_j enter sp_j (covest/models.py:103) -- add them up
             // plainly (32 terms of one sign) and hand the compensated accumulator ONE value per tile
@@ -207,7 +208,7 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
         }
         if (TAIL)
             acc_sp.add(tile_sp);
-        st.template leave_tile_n<N>(tv.renorm[t]);
+        st.template leave_tile_n<N>(rc.renorm);
     };
     // The rates of the error classes fall geometrically (covest/models.py:74-79): along the keys the streams go out
     // from the top, and once every class but the error-free one has gone for good in all lanes of the wave
@@ -217,8 +218,8 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
     int t = 0;
     for (; t < tv.n_tiles; ++t) {
         if (tv.run_start[t] != 0 && t > 0) { // (wave-uniform) a gap in the keys: who is left on the far side of it?
-            const double k0 = tv.first_key[t];
-            st.retire_at_run_start(k0 - 1.0, k0 + (double)(tv.n_bins[t] - 1), tv.lgam_prev[t], tv.lgam_last[t]);
+            const TileRec rc = tv.rec[t];
+            st.retire_at_run_start(rc.k0 - 1.0, rc.k0 + (double)(rc.nb - 1), rc.lgam_prev, rc.lgam_last);
         }
         if (st.only_first_left())
             break;
@@ -298,10 +299,25 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
                 // that does not hold the mode x_0 its largest value is at an end.  A tile that is negligible for every
                 // lane is skipped (the stream anchored afresh behind it), and once every lane is past its mode the walk
                 // ends: the stream is walked 11 standard deviations either side of its mode instead of 39.
-                const double k0 = tv.first_key[t], klast = k0 + (double)(tv.n_bins[t] - 1);
-                const double lp_lo = fma(k0 - 1.0, lx0, c0 - tv.lgam_prev[t]);
-                const double lp_hi = fma(klast, lx0, c0 - tv.lgam_last[t]);
-                const double x0 = st.x[0];
+                const TileRec rc = tv.rec[t];
+                const double k0 = rc.k0, x0 = st.x[0];
+                const double lp_lo = fma(k0 - 1.0, lx0, c0 - rc.lgam_prev);
+                // (inside a stretch that is being skipped: EIGHT tiles at a glance first -- the same test at the two ends
+                // of the eight, one record more -- so that a long dead stretch costs a test per 256 keys)
+                if (skipped && t + 7 < tv.n_tiles) {
+                    const TileRec r8 = tv.rec[t + 7];
+                    const double klast8 = r8.k0 + (double)(r8.nb - 1);
+                    const double lp_hi8 = fma(klast8, lx0, c0 - r8.lgam_last);
+                    const bool matters8 = !(fmax(lp_lo, lp_hi8) < -60.0) || (x0 >= k0 - 2.0 && x0 <= klast8 + 1.0);
+                    if (!__any(finite && matters8)) { // wave-uniform
+                        if (!__any(finite && !(x0 < k0 - 2.0)))
+                            break;
+                        t += 7;
+                        continue;
+                    }
+                }
+                const double klast = k0 + (double)(rc.nb - 1);
+                const double lp_hi = fma(klast, lx0, c0 - rc.lgam_last);
                 const bool holds_mode = x0 >= k0 - 2.0 && x0 <= klast + 1.0;
                 const bool matters = !(fmax(lp_lo, lp_hi) < -60.0) || holds_mode; // (a NaN: matters)
                 if (!__any(finite && matters)) { // wave-uniform
@@ -312,9 +328,10 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
                 }
             }
             if (!sums_only) {
-                const double k0 = tv.first_key[t];
-                const double lp_lo = fma(k0 - 1.0, lx0, c0 - tv.lgam_prev[t]); // (at the key before the tile: a superset)
-                const double lp_hi = fma(k0 + (double)(tv.n_bins[t] - 1), lx0, c0 - tv.lgam_last[t]);
+                const TileRec rc = tv.rec[t];
+                const double k0 = rc.k0;
+                const double lp_lo = fma(k0 - 1.0, lx0, c0 - rc.lgam_prev); // (at the key before the tile: a superset)
+                const double lp_hi = fma(k0 + (double)(rc.nb - 1), lx0, c0 - rc.lgam_last);
                 const bool near = !(fmin(lp_lo, lp_hi) > sub_list.log_p_clamp + 0.5); // (a stream that is off, a NaN: near)
                 if (!__any(finite && near)) { // wave-uniform
                     acc_ll += fma(c0, tv.suf_h[t] - tv.suf_h[t + 1],

@@ -395,11 +395,12 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     auto build_tile = [&](int t, bool seg_start, double *dst) __attribute__((always_inline)) -> double {
         if (COVEST_SKIP_PHASE(plan, 1))
             return 0.0;
-        const double k0 = tv.first_key[t];
-        const int nb = tv.n_bins[t];
+        const TileRec rc = tv.rec[t]; // (the tile's constants: one scalar load of one cache line, tiles.h)
+        const double k0 = rc.k0;
+        const int nb = rc.nb;
         // n_live: streams above it are zero in every lane of this wave (streams.h) -- most of them, for most tiles
-        const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                                         tv.run_start[t] != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
+        const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), rc.lgam_prev, rc.lgam_last,
+                                         rc.run_start != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
         if (diag) { // (diagnostic builds: entering the tile apart from walking it)
             const long long now__ = (long long)clock64();
             dg_enter += now__ - dg_t0;
@@ -407,15 +408,15 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         }
         double *colp = dst + (lane_in_row ? tid : 0);
         const double *scal = tv.scal + (int64_t)t * kTileBins;
-        if (nb == kTileBins && !(SPO && tv.has_filler[t] != 0)) { // the common case: straight-line code
+        if (nb == kTileBins && !(SPO && rc.has_filler != 0)) { // the common case: straight-line code
             if (n_live > 4)
-                return walk_tile(std::integral_constant<int, 8>{}, colp, tv.renorm[t], k0);
+                return walk_tile(std::integral_constant<int, 8>{}, colp, rc.renorm, k0);
             if (n_live > 2)
-                return walk_tile(std::integral_constant<int, 4>{}, colp, tv.renorm[t], k0);
+                return walk_tile(std::integral_constant<int, 4>{}, colp, rc.renorm, k0);
             if (n_live == 2)
-                return walk_tile(std::integral_constant<int, 2>{}, colp, tv.renorm[t], k0);
+                return walk_tile(std::integral_constant<int, 2>{}, colp, rc.renorm, k0);
             if (n_live == 1)
-                return walk_tile(std::integral_constant<int, 1>{}, colp, tv.renorm[t], k0);
+                return walk_tile(std::integral_constant<int, 1>{}, colp, rc.renorm, k0);
             if (lane_in_row) { // nothing is on: G = 0 for this wave's copy numbers
                 if (diag)
                     dg_zero += 1;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             if (lane_in_row)
                 colp[b * LD] = g;
         }
-        st.leave_tile(tv.renorm[t]);
+        st.leave_tile(rc.renorm);
         return tsum * 0x1p476; // (tv.scal carries 2^(kBasicShift - SC); S[o] is kept times 2^SC: exact)
     };
     // The same walk over a tile WITHOUT counts (tail != 0 only): sum_j G[o][j] over its keys stays in a register
@@ -489,27 +490,28 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         return gsum * (1.0 / kBasicScale); // (tv.scal carries 2^kBasicShift, tiles.h)
     };
     auto build_tile_sum = [&](int t, bool seg_start) __attribute__((always_inline)) -> double {
-        const double k0 = tv.first_key[t];
-        const int nb = tv.n_bins[t];
+        const TileRec rc = tv.rec[t];
+        const double k0 = rc.k0;
+        const int nb = rc.nb;
         // (SPO: the tile only enters S[o] -- streams.h enter_sum_tile: a stream is on where it matters to a sum)
-        const int n_live = SPO ? st.enter_sum_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                                                   tv.run_start[t] != 0 || seg_start)
-                               : st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), tv.lgam_prev[t], tv.lgam_last[t],
-                                               tv.run_start[t] != 0 || seg_start);
+        const int n_live = SPO ? st.enter_sum_tile(k0 - 1.0, k0 + (double)(nb - 1), rc.lgam_prev, rc.lgam_last,
+                                                   rc.run_start != 0 || seg_start)
+                               : st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), rc.lgam_prev, rc.lgam_last,
+                                               rc.run_start != 0 || seg_start);
         const double *scal = tv.scal + (int64_t)t * kTileBins;
-        if (nb == kTileBins && !(SPO && tv.has_filler[t] != 0)) { // (the count-less tiles of a histogram's tail are full ones: the live streams only)
+        if (nb == kTileBins && !(SPO && rc.has_filler != 0)) { // (the count-less tiles of a histogram's tail are full ones: the live streams only)
             if (n_live > 2)
-                return sum_tile(std::integral_constant<int, 8>{}, scal, k0, tv.renorm[t]);
+                return sum_tile(std::integral_constant<int, 8>{}, scal, k0, rc.renorm);
             if (n_live == 2)
-                return sum_tile(std::integral_constant<int, 2>{}, scal, k0, tv.renorm[t]);
+                return sum_tile(std::integral_constant<int, 2>{}, scal, k0, rc.renorm);
             if (n_live == 1)
-                return sum_tile(std::integral_constant<int, 1>{}, scal, k0, tv.renorm[t]);
+                return sum_tile(std::integral_constant<int, 1>{}, scal, k0, rc.renorm);
             return 0.0; // nothing is on
         }
         double gsum = 0.0;
         for (int b = 0; b < nb; ++b)
             gsum = fma(st.step(), scal[b], gsum);
-        st.leave_tile(tv.renorm[t]);
+        st.leave_tile(rc.renorm);
         return SPO ? gsum * 0x1p476 : gsum * (1.0 / kBasicScale); // (SPO: S[o] is kept times 2^SC)
     };
     // One item into `dst`: a plain tile, or (TAIL) the per-tile sums of up to 32 count-less tiles as its rows.
@@ -530,8 +532,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 // The streams are anchored afresh at the next tile that is walked (resync), as at the start of a run.
                 if (!seg_start) {
                     const int tl = first + n - 1;
-                    const double ka = tv.first_key[first] - 1.0, kb = tv.first_key[tl] + (double)(tv.n_bins[tl] - 1);
-                    const double lga = tv.lgam_prev[first], lgb = tv.lgam_last[tl];
+                    const TileRec ra = tv.rec[first], rb = tv.rec[tl];
+                    const double ka = ra.k0 - 1.0, kb = rb.k0 + (double)(rb.nb - 1);
+                    const double lga = ra.lgam_prev, lgb = rb.lgam_last;
                     bool matters = false;
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {

@@ -118,7 +118,8 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
     // (with a tail an item may stand for up to 32 count-less tiles, tiles.h: the builders walk every one of them
     // while the contraction sees one item -- charge them for the tiles an item holds on average)
     if (m->has_tiles && m->tv.n_items > 0)
-        build_cost = (int)std::lround((double)kBuildCost * (double)m->tv.n_tiles / (double)m->tv.n_items);
+        build_cost = (int)std::lround((double)(m->low_tile_share >= 0.75 ? kBuildCostLowKeys : kBuildCost) *
+                                      (double)m->tv.n_tiles / (double)m->tv.n_items);
 #if defined(COVEST_DIAG) || defined(COVEST_TUNE)
     if (const char *v = std::getenv("COVEST_FACTORED_UNIT_OVERHEAD"))
         unit_overhead = std::atoi(v);

@@ -104,6 +104,8 @@ struct StreamSet {
         // CANCEL = false: every stream by the reference's route (K-factored: the lanes of a wave are copy numbers, their
         // rates o x lambda_s span all three regimes, and a wave that takes all three pays more than the one route costs).
         const double ln_tot = CANCEL ? fast_log(tot, log_tab) : 0.0;
+        // (measured and not kept, round 5: the classes' ln x four at a time through fast_log_n, their table reads in flight
+        // together -- 4 spilled registers at 128, C2 0.167 against 0.166 ms: profiles/r05_c2_ab_staged_prologue_logs_not_kept.txt)
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             v[s] = 0.0;

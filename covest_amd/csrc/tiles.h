@@ -26,6 +26,16 @@ constexpr double kBasicScale = 0x1p64;
 // is mostly such keys): none of their keys takes a log, only the sum of their p_j is needed, and
 // sum_j sum_o b_o G[o][j] = sum_o b_o (sum_j G[o][j]) -- so the builders add G over a tile's keys in registers
 // and the item's 32 rows are those per-tile sums: one contraction and no log for 1024 keys.
+// A tile's constants in ONE 64-byte record (round 5): a kernel entering a tile fetches it with one scalar load of one
+// cache line, where the six values used to come from six arrays -- six lines, and two round trips through the scalar
+// cache, the second load's address waiting for n_bins.
+struct alignas(64) TileRec {
+    double k0, lgam_prev, lgam_last, renorm;         // first_key, ln (k0-1)!, ln (k0+nb-1)!, (k0-1)!/(k0+nb-1)!
+    int32_t nb, run_start, all_zero, has_filler;     // n_bins and the tile's flags
+    double pad[2];
+};
+static_assert(sizeof(TileRec) == 64, "one cache line");
+
 struct TileView {
     int32_t n_tiles;
     int32_t n_items;
@@ -65,7 +75,16 @@ struct TileView {
     const int32_t *item_sum;   // [n_items] 1 = sum item
     const int32_t *row_bin;    // [n_tiles][32] index of the row's key in DevModel::bins (-1: filler / padding): how a
                                //   recurrence kernel names a key it hands back (direct_point.h)
+    const TileRec *rec;        // [n_tiles] the per-tile values above, gathered (64-byte aligned: tile_dbl_count)
 };
+
+// doubles of the raw double buffer: the arrays, rounded up to a whole cache line, then the records
+inline __host__ __device__ int64_t tile_arrays_dbl(int32_t nt, int32_t ni)
+{
+    const int64_t n = 4 * (int64_t)nt + 2 * (int64_t)nt * kTileBins + 3 * (int64_t)ni * kTileBins + ni + 5 * ((int64_t)nt + 1) + 2;
+    return (n + 7) / 8 * 8;
+}
+inline __host__ __device__ int64_t tile_dbl_count(int32_t nt, int32_t ni) { return tile_arrays_dbl(nt, ni) + 8 * (int64_t)nt; }
 
 // The layout of tiles_host.cpp: build_tiles.
 inline __host__ __device__ TileView tile_view_from(int32_t nt, int32_t ni, const double *dbl, const int32_t *ints)
@@ -99,6 +118,7 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, int32_t ni, const
     tv.item_ntiles = tv.item_first + ni;
     tv.item_sum = tv.item_ntiles + ni;
     tv.row_bin = tv.item_sum + ni;
+    tv.rec = reinterpret_cast<const TileRec *>(dbl + tile_arrays_dbl(nt, ni));
     return tv;
 }
 
@@ -117,6 +137,11 @@ inline __host__ __device__ TileView tile_view_from(int32_t nt, int32_t ni, const
 constexpr int kMaxUnits = 6;       // accumulator slots per wave
 constexpr int kHalfUnits = 3;      // (kept for the 256-thread capacity rule: 4 waves x 6 slots)
 constexpr int kBuildCost = 18;     // phase A of one wave and key tile, in MFMA-step equivalents (tuned on C3; 36 before round 3 took the scales and the scalar-load stalls out of phase A)
+constexpr int kBuildCostLowKeys = 24; // ... of a histogram whose tiles are (nearly) all at low keys, where every error class is
+                                   //   live in every tile -- what the reference's trimming leaves (380 keys of H10k_rep): swept on it in
+                                   //   round 5, 0.4015 against 0.4103 ms at 18 (profiles/r05_factored_builder_charge_sweep.txt); C3 itself,
+                                   //   a third of whose tiles are such, stays best at 18
+constexpr int kLowKeyTile = 384;   // a tile that starts at or below this key counts as one of those
 #ifndef COVEST_LIST_SEGMENTS
 #define COVEST_LIST_SEGMENTS 16 // (8 until round 5: one evaluation on a 10 000-key histogram 53 -> 45 us, six 67 -> 56; 64: 173 -> 215)
 #endif

@@ -135,6 +135,12 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     }
     const size_t ni = item_first.size();
     m->rows_contracted = (double)ni * kTileBins;
+    {
+        size_t low = 0;
+        for (const Tile &tl : tiles)
+            low += tl.k0 <= kLowKeyTile ? 1 : 0;
+        m->low_tile_share = nt ? (double)low / (double)nt : 0.0;
+    }
     m->keys_logged = 0.0;
     for (double c : cnt)
         m->keys_logged += c != 0.0 ? 1.0 : 0.0;
@@ -190,7 +196,10 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
             suf[4 * (nt + 1) + t] = first_lg;
         }
     }
-    const size_t n_dbl = 4 * nt + 2 * nt * kTileBins + 3 * ni * kTileBins + ni + suf.size();
+    const size_t n_arrays = 4 * nt + 2 * nt * kTileBins + 3 * ni * kTileBins + ni + suf.size();
+    const size_t n_dbl = (size_t)tile_dbl_count((int32_t)nt, (int32_t)ni); // (the arrays, padded to a cache line, + the records)
+    if ((size_t)tile_arrays_dbl((int32_t)nt, (int32_t)ni) < n_arrays)
+        return fail(COVEST_E_INVALID, "tile table layout (internal)");
     std::vector<int32_t> tile_zero(nt, 0);
     for (size_t i2 = 0; i2 < ni; ++i2)
         if (item_sum[i2])
@@ -227,6 +236,24 @@ int build_tiles(covest_model *m, std::vector<HostBin> bins)
     put(item_iscal.data(), ni * kTileBins * sizeof(double));
     put(item_lconst.data(), ni * sizeof(double));
     put(suf.data(), suf.size() * sizeof(double));
+    {
+        std::vector<double> gap((size_t)tile_arrays_dbl((int32_t)nt, (int32_t)ni) - n_arrays, 0.0);
+        put(gap.data(), gap.size() * sizeof(double));
+        std::vector<TileRec> recs(nt);
+        for (size_t t = 0; t < nt; ++t) {
+            TileRec &r = recs[t];
+            r.k0 = dbl[t];
+            r.lgam_prev = dbl[nt + t];
+            r.lgam_last = dbl[2 * nt + t];
+            r.renorm = dbl[3 * nt + t];
+            r.nb = ints[t];
+            r.run_start = ints[nt + t];
+            r.all_zero = tile_zero[t];
+            r.has_filler = tile_filler[t];
+            r.pad[0] = r.pad[1] = 0.0;
+        }
+        put(recs.data(), nt * sizeof(TileRec));
+    }
     put(ints.data(), 2 * nt * sizeof(int32_t));
     put(tile_zero.data(), nt * sizeof(int32_t));
     put(tile_filler.data(), nt * sizeof(int32_t));

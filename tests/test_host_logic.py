@@ -59,6 +59,60 @@ def test_first_wins_scan_matches_oracle(oracle):
             assert diff == d or (math.isnan(diff) and math.isnan(d))
 
 
+def _device_scan_model(vals, start, threads=1024, cap=120):
+    """The algorithm of argmin.hip argmin_scan_small in numpy: a contiguous run of the values per thread, an exclusive
+    prefix minimum across the threads seeded with `start`, then every thread lists the strict running-minimum records
+    of its run -- (indices, values, truncated)."""
+    v = np.asarray(vals, dtype=np.float64)
+    n = len(v)
+    chunk = (n + threads - 1) // threads if n else 0
+    idx, out = [], []
+    run0 = start
+    for t in range(threads):
+        lo, hi = min(n, t * chunk), min(n, t * chunk + chunk)
+        run = run0
+        for i in range(lo, hi):
+            if v[i] < run:
+                run = v[i]
+                idx.append(i)
+                out.append(float(v[i]))
+        if hi > lo:
+            with np.errstate(invalid="ignore"):
+                m = np.fmin.reduce(np.where(np.isnan(v[lo:hi]), np.inf, v[lo:hi]))
+            run0 = min(run0, float(m))
+    return idx[:cap], out[:cap], len(idx) > cap
+
+
+def test_replaying_the_device_records_is_the_selection_loop():
+    """optimize_grid's selection loop (covest/grid.py:65-70) over the records the device lists
+    (covest_grid_eval_scan: the strict running-minimum records below the starting minimum, in index order) ends in the
+    same (min_val, arg, diff), bit for bit, as the loop over every value -- NaN, +inf, ties and all."""
+    from covest_amd.grid import first_wins_scan, replay_records
+    rng = np.random.default_rng(7)
+    inf, nan = math.inf, math.nan
+    cases = [[3.0, 1.0, 1.0, 2.0], [nan, 5.0, nan, 4.0], [inf, inf], [1.0, -inf, -inf], [], [5.0, 6.0]]
+    for _ in range(120):
+        v = rng.normal(size=rng.integers(1, 3000)) * 10.0 ** rng.integers(0, 9)
+        v[rng.random(len(v)) < 0.1] = nan
+        v[rng.random(len(v)) < 0.05] = inf
+        if rng.random() < 0.5:
+            v = np.round(v, 1)  # many ties
+        cases.append(v.tolist())
+    cases.append(np.linspace(1e6, 1.0, 200).tolist())  # steadily falling: more records than the device keeps
+    for v in cases:
+        finite = [x for x in v if x == x and abs(x) != inf]
+        starts = [inf, 0.3] + ([float(np.median(finite)), min(finite), min(finite) - 1.0] if finite else [])
+        for start in starts:
+            idx, vals, truncated = _device_scan_model(v, start)
+            if truncated:
+                assert len(v) == 200
+                continue
+            assert idx == sorted(idx)
+            got = replay_records(idx, vals, start)
+            want = first_wins_scan(v, start)
+            assert got[:2] == want[:2] and (got[2] == want[2] or (math.isnan(got[2]) and math.isnan(want[2]))), (start, got, want)
+
+
 def test_threshold_through_capi_on_host(hip_lib):
     from covest_amd import RepeatsModel
     g = load_golden("threshold_o.json")

@@ -1,2 +1,4 @@
-bash tools/kstat_ab.sh c3 tools/bin/libcovest_amd_r04.so covest_amd/lib/libcovest_amd.so tools/bin/lib_fixlibexp.so 2>&1 | tail -16
-bash tools/collect_final.sh r5final c
+mkdir -p gpurun_out/r5l
+timeout -k 10 800 python -m pytest tests -m gpu -q -x > gpurun_out/r5l/gpu_tests.log 2>&1; tail -4 gpurun_out/r5l/gpu_tests.log
+WL="c3 c3t c2 c2t" AB_STEPS=300 timeout -k 10 400 bash tools/ab.sh tools/bin/libcovest_r5k.so covest_amd/lib/libcovest_amd.so 2>&1 | tee gpurun_out/r5l/ab.txt
+for lib in tools/bin/libcovest_r5k.so covest_amd/lib/libcovest_amd.so; do echo $lib; COVEST_AMD_LIB=$PWD/$lib timeout -k 10 120 python tools/time_tail.py; done 2>&1 | tee gpurun_out/r5l/tail_timing.txt
