@@ -138,8 +138,13 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
         const TileRec rc = tv.rec[t]; // (the tile's constants: one scalar load of one cache line, tiles.h)
         const double k0 = rc.k0;
         const int nb = rc.nb;
-        st.template enter_tile_n<N>(k0 - 1.0, k0 + (double)(nb - 1), rc.lgam_prev, rc.lgam_last,
-                                    rc.run_start != 0 || force_start); // (behind skipped tiles: anchored afresh)
+        // (a tile that only enters sp_j is entered on the SUM window -- streams.h enter_sum_tile: a stream is on where it
+        // matters to a sum, e^-60 -- and walked with the classes that are live)
+        const bool sums = TAIL && (ll_done || rc.all_zero != 0); // wave-uniform
+        const int n_live = sums ? st.template enter_tile_n<N, true>(k0 - 1.0, k0 + (double)(nb - 1), rc.lgam_prev, rc.lgam_last,
+                                                                    rc.run_start != 0 || force_start)
+                                : st.template enter_tile_n<N>(k0 - 1.0, k0 + (double)(nb - 1), rc.lgam_prev, rc.lgam_last,
+                                                              rc.run_start != 0 || force_start); // (behind skipped tiles: anchored afresh)
         const double *scal = tv.scal + (int64_t)t * kTileBins;
         const double *cnt = tv.cnt + (int64_t)t * kTileBins;
         double xx[S]; // squared rates, recomputed per tile (N multiplies) rather than held in 2 S registers
@@ -152,12 +157,17 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
                 xx[s] = s < N ? xs * xs : 0.0;
             }
         }
-        if (TAIL && (ll_done || rc.all_zero != 0)) {
+        if (TAIL && sums) {
             // a tile without a single count (they exist only with a tail), or one whose logs the closed form has
             // taken care of: its keys take no log, only their p_j enter sp_j (covest/models.py:103) -- add them up
-            // plainly (32 terms of one sign) and hand the compensated accumulator ONE value per tile
+            // plainly (32 terms of one sign) and hand the compensated accumulator ONE value per tile.  With the classes
+            // that are LIVE (n_live: the ones above are exact zeros in every lane of the wave): the long count-less
+            // stretch between the error k-mers and the genomic peak of a 10 000-key histogram was walked with all
+            // eight classes until the last of them had underflowed -- 27 tiles at 400 instructions -- though two are
+            // live for the first dozen and none for the rest.
             double tile_sum = 0.0;
-            if (nb == kTileBins) {
+            auto sum_full = [&](auto m_tag) __attribute__((always_inline)) {
+                constexpr int M = decltype(m_tag)::value;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     double sc[16];
@@ -167,11 +177,20 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
 #pragma unroll
                     for (int b = 0; b < 16; b += 2) {
                         double g1, g2;
-                        st.template step2n<N>(xx, g1, g2);
+                        st.template step2n<M>(xx, g1, g2);
                         tile_sum = fma(g1, sc[b], tile_sum);
                         tile_sum = fma(g2, sc[b + 1], tile_sum);
                     }
                 }
+            };
+            if (nb == kTileBins) {
+                if (N > 2 && n_live > 2)
+                    sum_full(std::integral_constant<int, N>{});
+                else if (N > 2 && n_live == 2)
+                    sum_full(std::integral_constant<int, (N > 2 ? 2 : 1)>{});
+                else if (n_live >= 1)
+                    sum_full(std::integral_constant<int, 1>{});
+                // (nothing is on: the tile adds nothing)
             } else {
                 for (int b = 0; b < nb; ++b)
                     tile_sum = fma(st.template step_n<N>(), scal[b], tile_sum);
