@@ -285,7 +285,7 @@ hipError_t launch_ll(const covest_model *m, int kernel, const PointSource &src, 
         if (name)
             *name = "ll_basic";
         hipError_t e = launch_ll_basic(m->dm, m->tv, src, n, out, sub, st);
-        return e != hipSuccess ? e : launch_ll_fix_list(m->dm, m->tv, src, out, sub, st);
+        return e != hipSuccess ? e : launch_ll_fix_list(m->dm, m->tv, src, out, sub, st, n);
     }
     if (name)
         *name = kernel == COVEST_KERNEL_DIRECT_REF ? "ll_direct_ref" : "ll_direct";
@@ -351,7 +351,8 @@ static int fix_points_host(covest_model *m, int64_t n, const double *params, dou
     src.params = m->ws_params.as<double>();
     src.t_list = P == 5 ? m->ws_t.as<int32_t>() : nullptr;
     HIP_TRY(launch_ll_fix_list(m->dm, m->tv, src, m->ws_out.as<double>(),
-                               sub_list_of(m, m->n_par == 5 ? 513 : 2, m->ws_sub_index.ptr, m->ws_sub_word.ptr, m->ws_sub_ctl.ptr), nullptr));
+                               sub_list_of(m, m->n_par == 5 ? 513 : 2, m->ws_sub_index.ptr, m->ws_sub_word.ptr, m->ws_sub_ctl.ptr), nullptr,
+                               (int64_t)na));
     HIP_TRY(hipMemcpy(sub_ll.data(), m->ws_out.ptr, na * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < na; ++k)
         out_ll[again[k]] = sub_ll[k];

@@ -93,14 +93,18 @@ __global__ __launch_bounds__(256) void argmin_stage1(const double *__restrict__ 
 // in ascending row order.  The strict p_j is K-direct's (direct_point.h) to the letter: LANE r of a wave keeps the
 // p_j of row r of a 64-row chunk; the mixture components are prepared 64 at a time (one per lane) and broadcast
 // through the scalar unit, every term rounded to a double on its own, error classes inside, copy numbers outside, both
-// ascending.  A repeats-model point is shared by the 4 waves of a workgroup -- lots of copy numbers are dealt to them in turn, the partial p_j are added through LDS (where it matters -- p_j
-// subnormal -- every sum is exact, whatever the order); a basic-model point (one copy number) takes one wave.
+// ascending.  A point takes ONE wave (NW = 1), four points a workgroup.  (Until round 5 a repeats-model point was shared
+// by the 4 waves of a workgroup -- NW = 4: lots of copy numbers dealt to them in turn, the partial p_j added through LDS,
+// where it matters, p_j subnormal, every sum is exact whatever the order.  But the points that are handed back are the
+// ones whose LAST keys underflow, which are the ones with a SMALL threshold_o -- three to six lots, most of them out
+// of the rows' reach -- and every one of the four waves repeated the point's loads, its two pows and the rows' bins:
+// C3's 5 000 points 46.8 us with four waves a point, 35.8 us with one, profiles/r05_c3_kstat_fix_one_wave_a_point.txt.)
 // Launched after every K-basic / K-factored launch, before anything reads the values; with an empty queue it costs
 // a launch and one load.  The queued points of a wide grid come in clusters (whole (c, e) rows of it) and the work
 // of one grows with its threshold_o, which is why they are compacted into a queue and spread over the chip instead
 // of being patched by whichever thread meets them.  The queue's counter is reset by whoever runs next on the
 // stream: the arg-min pass (grids) or the host (point lists).
-// NW: waves that share a point (basic model: 1 -- four points per workgroup; repeats model: 4).
+// NW: waves that share a point.
 template <int P, int NW>
 __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                           const double *__restrict__ tile_dbl,
@@ -244,6 +248,18 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
 // one above to the letter -- the terms a_s exp(key ln x_s - D_s - ln key!) added in ascending s (a component that is out
 // of reach adds an exact 0: the kernel above skips it, which is the same), b_o = 1, the contributions of a point's rows
 // in ascending order.
+// Round 5.  C2 hands 7 266 of its 10^6 points back: 908 waves, fewer than the chip has SIMDs, so the launch lasts as
+// long as ONE wave's chain of dependent loads and calls -- 16.8 us of a 188 us step.  What shortened it: the class count
+// as a compile-time 8 (SC), the loops over the classes unrolled so that a row's eight exps and their crossbar reads
+// interleave instead of following one another -- 16.5 -> 14.8 us (profiles/r05_c2_kstat_fix_classes_unrolled.txt).
+// What did not, and stays because it is less code in flight: the class's rate by multiplication
+// (error_class_rate_mul: the very products K-basic itself forms, point_fetch.h) instead of two calls of the device
+// library's pow; a queue entry's loads -- the entry, the point's axis values and value, the rows' bins of the first
+// pass -- issued together with the log table's, before its barrier, and the rows of the next pass during this one
+// (16.93 -> 16.85 us).  Measured and not kept: a wave a point with lane (row, component) holding ONE term -- an exp a lane
+// and pass instead of S -- is eight times the waves, each repeating the preparation: 36.5 us,
+// profiles/r05_c2_kstat_fix_wave_per_point_not_kept.txt.
+template <int SC> // the class count as a constant (8: every loop over the classes unrolled, their exps interleaved), or 0
 __global__ __launch_bounds__(256) void ll_fix_basic_packed_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                                   const double *__restrict__ tile_dbl,
                                                                   const int32_t *__restrict__ tile_int, const PointSource src,
@@ -254,10 +270,9 @@ __global__ __launch_bounds__(256) void ll_fix_basic_packed_kernel(const DevModel
         return; // (workgroup-uniform) the common case: a launch and one load
     __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
     load_log_table(log_tab);
-    __syncthreads();
     const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
     const int lane = threadIdx.x & (kWave - 1);
-    const int S = m.n_err;            // 8, 16, 24 or 32 (padded: comb = 0 beyond the model's classes)
+    const int S = SC ? SC : m.n_err;  // 8, 16, 24 or 32 (padded: comb = 0 beyond the model's classes)
     const int G = kWave / S;          // points a wave takes at once
     const int g = lane / S, s = lane - g * S;
     const bool in_group = g < G;
@@ -266,23 +281,46 @@ __global__ __launch_bounds__(256) void ll_fix_basic_packed_kernel(const DevModel
     const int64_t n_rows_table = (int64_t)tv.n_tiles * kTileBins;
     const unsigned wave_global = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
     const unsigned n_waves = gridDim.x * (blockDim.x / kWave);
-    for (unsigned base = wave_global * (unsigned)G; base < count; base += n_waves * (unsigned)G) { // wave-uniform
+    // A queue entry and what hangs on it by loads alone: the point, its value, this lane's row of the first pass
+    // {h_j, key, -ln key!} (h = 0: no such row, or no count)
+    bool have = false;
+    int64_t pt = 0, row_first = 0, row_last = -1;
+    double par[kMaxParams] = {0, 0, 0, 0, 0};
+    int T = 0;
+    double value = 0.0, h_n = 0.0, key_n = 0.0, nlg_n = 0.0;
+    auto fetch_row = [&](int64_t r0, double &h, double &key, double &nlg) {
+        const int64_t row = row_first + r0 + s;
+        const int bin = (have && row <= row_last && row < n_rows_table) ? tv.row_bin[row] : -1;
+        h = bin >= 0 ? m.bins.cnt[bin] : 0.0;
+        key = (bin >= 0 && h != 0.0) ? m.bins.key[bin] : 0.0;
+        nlg = (bin >= 0 && h != 0.0) ? -m.bins.lgam[bin] : 0.0;
+    };
+    auto fetch_entry = [&](unsigned base) {
         const unsigned at = base + (unsigned)(in_group ? g : 0);
-        const bool have = in_group && at < count;
-        const int64_t pt = list.index[have ? at : base];
+        have = in_group && at < count;
+        pt = list.index[have ? at : base];
         const unsigned long long word = have ? list.word[at] : 0ull;
-        double par[kMaxParams];
-        int T;
-        fetch_point<2>(src, pt, par, T);
-        clamp_point<2>(m, par);
         const bool units16 = sub_units16(word);
-        const int64_t row_first = units16 ? (int64_t)sub_first(word) * 16 : (int64_t)sub_first(word);
-        const int64_t row_last = units16 ? (int64_t)sub_last(word) * 16 + 15 : (int64_t)sub_last(word);
-        // ---- component s of point g: covest/models.py:85-90, as K-direct prepares it (direct_point.h) ----
-        const double x = error_class_rate(m, par[0], par[1], s); // o = 1
+        row_first = units16 ? (int64_t)sub_first(word) * 16 : (int64_t)sub_first(word);
+        row_last = units16 ? (int64_t)sub_last(word) * 16 + 15 : (int64_t)sub_last(word);
+        fetch_row(0, h_n, key_n, nlg_n);
+        fetch_point<2>(src, pt, par, T);
+        value = have ? ll[pt] : 0.0;
+    };
+    const unsigned base0 = wave_global * (unsigned)G;
+    if (base0 < count) // (wave-uniform) the first entry's loads and the table's are in flight together
+        fetch_entry(base0);
+    __syncthreads(); // the table is readable
+    for (unsigned base = base0; base < count; base += n_waves * (unsigned)G) { // wave-uniform
+        if (base != base0)
+            fetch_entry(base);
+        clamp_point<2>(m, par);
+        // ---- component s of point g: covest/models.py:85-90, as K-basic prepares it (ll_basic.hip) ----
+        const double x = error_class_rate_mul(m, par[0], par[1], s, S); // o = 1
         const bool live = have && T > 1;
         const double n_os = comb_s * (1.0 - exp_neg_rn(x));
         double tot = 0.0;
+#pragma unroll
         for (int t = 0; t < S; ++t) // naive sum in s order
             tot += __shfl(n_os, first_lane + t, kWave);
         if (tot == 0.0)
@@ -295,7 +333,6 @@ __global__ __launch_bounds__(256) void ll_fix_basic_packed_kernel(const DevModel
         }
         if (!live)
             a_s = 0.0;
-        double value = have ? ll[pt] : 0.0;
         // ---- the point's rows, S at a time ----
         const int64_t my_rows = have ? row_last - row_first + 1 : 0;
         int64_t most = my_rows;
@@ -303,13 +340,12 @@ __global__ __launch_bounds__(256) void ll_fix_basic_packed_kernel(const DevModel
         for (int off = 32; off >= 1; off >>= 1)
             most = max(most, __shfl_xor(most, off, kWave)); // wave-uniform trip count
         for (int64_t r0 = 0; r0 < most; r0 += S) {
-            const int64_t row = row_first + r0 + s;
-            const int bin = (have && row <= row_last && row < n_rows_table) ? tv.row_bin[row] : -1;
-            const double h = bin >= 0 ? m.bins.cnt[bin] : 0.0;
-            const bool counted = bin >= 0 && h != 0.0;
-            const double key = counted ? m.bins.key[bin] : 0.0;
-            const double nlg = counted ? -m.bins.lgam[bin] : 0.0;
+            const double h = h_n, key = key_n, nlg = nlg_n;
+            if (r0 + S < most)
+                fetch_row(r0 + S, h_n, key_n, nlg_n);
+            const bool counted = h != 0.0;
             double pj = 0.0;
+#pragma unroll
             for (int t = 0; t < S; ++t) { // error classes, ascending
                 const double a_t = __shfl(a_s, first_lane + t, kWave);
                 const double lx_t = __shfl(lx, first_lane + t, kWave);
@@ -319,6 +355,7 @@ __global__ __launch_bounds__(256) void ll_fix_basic_packed_kernel(const DevModel
             }
             const bool fix = counted && pj < list.p_clamp;
             const double contrib = fix ? h * ((pj <= 0.0 ? -INFINITY : log(pj)) - list.log_p_clamp) : 0.0;
+#pragma unroll
             for (int t = 0; t < S; ++t) { // ascending rows of the group's point
                 const double c_t = __shfl(contrib, first_lane + t, kWave);
                 const bool f_t = __shfl((int)fix, first_lane + t, kWave) != 0;
@@ -541,18 +578,24 @@ hipError_t launch_argmin_scan(const double *ll, int64_t n, int64_t flat_begin, d
 }
 
 hipError_t launch_ll_fix_list(const DevModel &m, const TileView &tv, const PointSource &src, double *ll,
-                              const SubList &list, hipStream_t stream)
+                              const SubList &list, hipStream_t stream, int64_t n_points)
 {
     // enough workgroups to spread a few thousand queued points over the chip; an empty queue is the common case
     const dim3 grid(2048), block(256);
-    if (m.kind == 0 && m.n_err <= 32)
-        hipLaunchKernelGGL(ll_fix_basic_packed_kernel, dim3(512), block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+    // (the packed kernel: 64 / S points a wave; no more workgroups than the launch before can have queued points for -- an
+    // optimize_grid search launches this hundreds of times on an empty queue)
+    const int packed_blocks = (int)std::min<int64_t>(512, std::max<int64_t>(16, n_points > 0 ? (n_points + 31) / 32 : 512));
+    if (m.kind == 0 && m.n_err == 8)
+        hipLaunchKernelGGL(ll_fix_basic_packed_kernel<8>, dim3(packed_blocks), block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+                           tv.int_base, src, ll, list);
+    else if (m.kind == 0 && m.n_err <= 32)
+        hipLaunchKernelGGL(ll_fix_basic_packed_kernel<0>, dim3(packed_blocks), block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
                            tv.int_base, src, ll, list);
     else if (m.kind == 0)
         hipLaunchKernelGGL((ll_fix_list_kernel<2, 1>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
                            tv.int_base, src, ll, list);
     else
-        hipLaunchKernelGGL((ll_fix_list_kernel<5, 4>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+        hipLaunchKernelGGL((ll_fix_list_kernel<5, 1>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
                            tv.int_base, src, ll, list);
     return hipGetLastError();
 }

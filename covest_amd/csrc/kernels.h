@@ -46,8 +46,9 @@ hipError_t launch_ll_finish_dense(const DevModel &m, const TileView &tv, const P
 // The pass after every K-basic / K-factored launch: one wave per point of the queue `list` (direct_point.h) adds
 // the strict evaluation of the rows named in its side word to ll[], in place.  The queue's counter must be zero
 // before the NEXT recurrence launch: launch_argmin resets it (grids), the host does for point lists.
+// n_points: how many points the launch before evaluated (the queue cannot be longer; 0: unknown) -- sizes the launch.
 hipError_t launch_ll_fix_list(const DevModel &m, const TileView &tv, const PointSource &src, double *ll,
-                              const SubList &list, hipStream_t stream);
+                              const SubList &list, hipStream_t stream, int64_t n_points = 0);
 
 // (min -LL, lowest index) over ll[n]: two-stage reduction (argmin.hip).
 // partial_val/partial_idx need kArgminBlocks entries; result[0] = {min, bits of idx}.

@@ -398,7 +398,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         const TileRec rc = tv.rec[t]; // (the tile's constants: one scalar load of one cache line, tiles.h)
         const double k0 = rc.k0;
         const int nb = rc.nb;
-        // n_live: streams above it are zero in every lane of this wave (streams.h) -- most of them, for most tiles
+        // n_live: streams above it are zero in every lane of this wave (streams.h) -- most of them, for most tiles.
+        // (Measured and not kept, round 5: the entry compiled for one and for two classes as well and picked by `gone` --
+        // C3 0.671 against 0.661 ms, the trimmed histogram with a tail 0.395 against 0.396:
+        // profiles/r05_c3_ab_entry_by_live_classes_not_kept.txt.  The gone classes' tests are scalar and cost little;
+        // three copies of the entry cost the instruction cache more.)
         const int n_live = st.enter_tile(k0 - 1.0, k0 + (double)(nb - 1), rc.lgam_prev, rc.lgam_last,
                                          rc.run_start != 0 || seg_start); // (a key segment starts like a run: every stream anchored)
         if (diag) { // (diagnostic builds: entering the tile apart from walking it)

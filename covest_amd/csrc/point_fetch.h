@@ -64,6 +64,29 @@ __device__ __forceinline__ double error_class_rate(const DevModel &m, double c, 
     return v;
 }
 
+// ONE class's rate by multiplication, for a kernel whose lanes are classes (ll_fix_basic_packed_kernel): the products of
+// error_class_rates<S> below in the same order -- (1 - e)^max(k - S + 1, 0) by squaring, one more factor a class down to
+// s, e^s factor by factor -- so the strict re-evaluation of a K-basic point works with the very rates K-basic had.
+__device__ __forceinline__ double error_class_rate_mul(const DevModel &m, double c, double err, int s, int S)
+{
+    const double ck = c * (double)(m.r - m.k + 1) / (double)m.r;
+    const double q = 1.0 - err;
+    const int n_low = m.k - (S - 1) > 0 ? m.k - (S - 1) : 0;
+    double pw = 1.0, sq = q;
+    for (int n = n_low; n > 0; n >>= 1) { // q^n_low by squaring (wave-uniform)
+        if (n & 1)
+            pw *= sq;
+        sq *= sq;
+    }
+    for (int t = S - 1; t > s; --t) // q^max(k - s, 0): class t - 1 has one more factor than class t, where k - t >= 0
+        if (m.k - t >= 0)
+            pw *= q;
+    double pe = 1.0; // e^s (0^0 = 1: the error-free class at e = 0)
+    for (int t = 0; t < s; ++t)
+        pe *= err;
+    return ((ck * m.pow3neg[s]) * pw) * pe; // the reference's order of evaluation, covest/models.py:76-79
+}
+
 // ALL S error classes' rates of one point at once, for a kernel whose every lane is a point of its own (K-basic):
 // (1 - e)^(k - s) and e^s by multiplication -- (1 - e)^(k - S + 1) by squaring, then one multiply a class -- instead of
 // two calls of pow a class.  Round 4: the device library's pow is 210 instructions, and sixteen of them were HALF of
