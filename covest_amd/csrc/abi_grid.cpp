@@ -361,6 +361,25 @@ static int grid_eval(covest_grid *g, int32_t kernel, void *stream, bool scan, do
             }
             std::fprintf(stderr, "covest_grid_eval: rows named per point: min %lld mean %.1f max %lld; mean first row %.1f\n", mn,
                          sum / queued, mx, (double)first_sum / queued);
+            if (g->src.t_table) { // the queued points' threshold_o
+                const int64_t n_q = g->src.len[2] * g->src.len[3] * g->src.len[4];
+                std::vector<int32_t> tt((size_t)n_q);
+                std::vector<int64_t> idx(queued);
+                HIP_TRY(hipMemcpy(tt.data(), g->src.t_table, (size_t)n_q * sizeof(int32_t), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(idx.data(), g->sub_index.ptr, (size_t)queued * sizeof(int64_t), hipMemcpyDeviceToHost));
+                long long tmin = 1 << 30, tmax = 0;
+                double tsum = 0;
+                long long hist[6] = {0, 0, 0, 0, 0, 0}; // T <= 16, 32, 64, 128, 256, more
+                for (int64_t i : idx) {
+                    const long long T = tt[(size_t)((g->src.flat_begin + i) % n_q)];
+                    tmin = std::min(tmin, T);
+                    tmax = std::max(tmax, T);
+                    tsum += (double)T;
+                    hist[T <= 16 ? 0 : T <= 32 ? 1 : T <= 64 ? 2 : T <= 128 ? 3 : T <= 256 ? 4 : 5]++;
+                }
+                std::fprintf(stderr, "covest_grid_eval: threshold_o of the queued points: min %lld mean %.1f max %lld; <=16 %lld <=32 %lld <=64 %lld <=128 %lld <=256 %lld more %lld\n",
+                             tmin, tsum / queued, tmax, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+            }
         }
     }
 #endif

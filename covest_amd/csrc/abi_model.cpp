@@ -219,7 +219,7 @@ static hipError_t launch_factored_grid(covest_grid *g, double *out, const SubLis
         hipError_t e = launch_ll_factored(m->dm, m->tv, g->plan, out, sub, st);
         if (e != hipSuccess)
             return e;
-        e = launch_ll_fix_list(m->dm, m->tv, g->src, out, sub, st);
+        e = launch_ll_fix_list(m->dm, m->tv, g->src, out, sub, st, g->flat_end - g->flat_begin);
         if (e != hipSuccess)
             return e;
     }

@@ -105,6 +105,11 @@ __global__ __launch_bounds__(256) void argmin_stage1(const double *__restrict__ 
 // of being patched by whichever thread meets them.  The queue's counter is reset by whoever runs next on the
 // stream: the arg-min pass (grids) or the host (point lists).
 // NW: waves that share a point.
+// (Measured and not kept, round 5: the kernel held to 96 registers for five waves a SIMD -- it takes 155, three waves --
+// spills 27 of them and is slower, 42.9 against 35.8 us on C3's 2 962 queued points (threshold_o 11 .. 87, 27 rows
+// each); to 128 for four waves, 36.4.  The launch is one trip of every wave: by the counters a point is 2 750 vector
+// instructions at 17 cycles apiece -- the two pows of its rates, the preparation of the one or two lots of copy numbers
+// that reach its rows, an exp per component kept -- profiles/r05_c3_kstat_fix_occupancy_not_kept.txt.)
 template <int P, int NW>
 __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                           const double *__restrict__ tile_dbl,
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
 // (16.93 -> 16.85 us).  Measured and not kept: a wave a point with lane (row, component) holding ONE term -- an exp a lane
 // and pass instead of S -- is eight times the waves, each repeating the preparation: 36.5 us,
 // profiles/r05_c2_kstat_fix_wave_per_point_not_kept.txt.
-template <int SC> // the class count as a constant (8: every loop over the classes unrolled, their exps interleaved), or 0
+template <int SC> // the class count as a constant: every loop over the classes unrolled, a row's exps interleaved
 __global__ __launch_bounds__(256) void ll_fix_basic_packed_kernel(const DevModel m, const int32_t n_tiles, const int32_t n_items,
                                                                   const double *__restrict__ tile_dbl,
                                                                   const int32_t *__restrict__ tile_int, const PointSource src,
@@ -272,8 +277,8 @@ __global__ __launch_bounds__(256) void ll_fix_basic_packed_kernel(const DevModel
     load_log_table(log_tab);
     const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
     const int lane = threadIdx.x & (kWave - 1);
-    const int S = SC ? SC : m.n_err;  // 8, 16, 24 or 32 (padded: comb = 0 beyond the model's classes)
-    const int G = kWave / S;          // points a wave takes at once
+    constexpr int S = SC;             // m.n_err: 8, 16, 24 or 32 (padded: comb = 0 beyond the model's classes)
+    constexpr int G = kWave / S;      // points a wave takes at once
     const int g = lane / S, s = lane - g * S;
     const bool in_group = g < G;
     const int first_lane = (in_group ? g : 0) * S; // the group's lane 0 (idle lanes shadow group 0 and store nothing)
@@ -580,18 +585,24 @@ hipError_t launch_argmin_scan(const double *ll, int64_t n, int64_t flat_begin, d
 hipError_t launch_ll_fix_list(const DevModel &m, const TileView &tv, const PointSource &src, double *ll,
                               const SubList &list, hipStream_t stream, int64_t n_points)
 {
-    // enough workgroups to spread a few thousand queued points over the chip; an empty queue is the common case
-    const dim3 grid(2048), block(256);
+    // enough workgroups to spread a few thousand queued points over the chip -- four points a workgroup, no more of them
+    // than the launch before can have queued points for; an empty queue is the common case
+    const dim3 grid((unsigned)std::min<int64_t>(2048, std::max<int64_t>(64, n_points > 0 ? (n_points + 3) / 4 : 2048))), block(256);
     // (the packed kernel: 64 / S points a wave; no more workgroups than the launch before can have queued points for -- an
     // optimize_grid search launches this hundreds of times on an empty queue)
     const int packed_blocks = (int)std::min<int64_t>(512, std::max<int64_t>(16, n_points > 0 ? (n_points + 31) / 32 : 512));
-    if (m.kind == 0 && m.n_err == 8)
-        hipLaunchKernelGGL(ll_fix_basic_packed_kernel<8>, dim3(packed_blocks), block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
-                           tv.int_base, src, ll, list);
-    else if (m.kind == 0 && m.n_err <= 32)
-        hipLaunchKernelGGL(ll_fix_basic_packed_kernel<0>, dim3(packed_blocks), block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
-                           tv.int_base, src, ll, list);
-    else if (m.kind == 0)
+    if (m.kind == 0 && m.n_err <= 32 && m.n_err % 8 == 0) {
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(packed_blocks), block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base, tv.int_base, src,
+                               ll, list);
+        };
+        switch (m.n_err) {
+        case 8: go(ll_fix_basic_packed_kernel<8>); break;
+        case 16: go(ll_fix_basic_packed_kernel<16>); break;
+        case 24: go(ll_fix_basic_packed_kernel<24>); break;
+        default: go(ll_fix_basic_packed_kernel<32>); break;
+        }
+    } else if (m.kind == 0)
         hipLaunchKernelGGL((ll_fix_list_kernel<2, 1>), grid, block, 0, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
                            tv.int_base, src, ll, list);
     else
