@@ -151,7 +151,10 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
         const bool units16 = sub_units16(word);
         const int64_t row_first = units16 ? (int64_t)sub_first(word) * 16 : (int64_t)sub_first(word);
         const int64_t row_last = units16 ? (int64_t)sub_last(word) * 16 + 15 : (int64_t)sub_last(word);
-        const double lam = error_class_rate(m, par[0], par[1], s);
+        // (the products the recurrence kernels form, point_fetch.h error_class_rate_mul: a few 1e-16 relative from the
+        // pow-made rates of K-direct -- far below the grain of the subnormal terms this kernel exists for -- and 40
+        // instructions a point instead of the two pows' 420)
+        const double lam = error_class_rate_mul(m, par[0], par[1], s, S);
         const int o_hi = T;
         double value = ll[pt];
         for (int64_t chunk = row_first; chunk <= row_last; chunk += kWave) { // workgroup-uniform
@@ -209,17 +212,44 @@ __global__ __launch_bounds__(256) void ll_fix_list_kernel(const DevModel m, cons
                     const double top = fmax(fma(k_lo, lx, nd + g_lo), fma(k_hi, lx, nd + g_hi));
                     const uint64_t keep = __ballot(a_os != 0.0 && (inside || top >= -745.2));
                     // ---- every lane accumulates the kept ones for its own row ----
-                    for (int g = 0; g < OT; ++g) {
-                        uint64_t gm = (keep >> (g * S)) & ((1ull << S) - 1ull);
-                        if (gm == 0)
-                            continue;
+                    // inner = the classes of one copy number in ascending order, pj += b_o * inner per copy number that
+                    // has any (covest/models.py:237) -- the TERMS four at a time (round 5): an exp is a chain of forty-five
+                    // dependent instructions, and one wave a SIMD (a launch of this kernel is one trip of every wave) does
+                    // not hide one behind another unless they are written side by side.  The sums are the same sums: a
+                    // batch's terms are added one by one, in order, to the copy number they belong to.
+                    {
+                        uint64_t km = keep;
+                        int cur_end = 0; // one past the last lane of the copy number `inner` belongs to (0: none yet)
                         double inner = 0.0;
-                        while (gm) { // error classes, ascending
-                            const int i = g * S + __builtin_ctzll(gm);
-                            gm &= gm - 1;
-                            inner += wave_bcast(a_os, i) * exp(fma(key, wave_bcast(lx, i), wave_bcast(nd, i) + nlg));
+                        while (km) { // wave-uniform
+                            int idx[4];
+                            int n = 0;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                idx[u] = km ? __builtin_ctzll(km) : idx[0]; // (a short batch repeats its first term and drops it)
+                                n += km ? 1 : 0;
+                                km &= km - 1; // (0 stays 0)
+                            }
+                            double t[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                t[u] = wave_bcast(a_os, idx[u]) * exp(fma(key, wave_bcast(lx, idx[u]), wave_bcast(nd, idx[u]) + nlg));
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (u >= n)
+                                    break;
+                                if (idx[u] >= cur_end) { // the first kept class of another copy number
+                                    if (cur_end > 0)
+                                        pj += wave_bcast(b_o, cur_end - S) * inner;
+                                    inner = 0.0;
+                                    while (idx[u] >= cur_end)
+                                        cur_end += S;
+                                }
+                                inner += t[u];
+                            }
                         }
-                        pj += wave_bcast(b_o, g * S) * inner; // covest/models.py:237
+                        if (cur_end > 0)
+                            pj += wave_bcast(b_o, cur_end - S) * inner;
                     }
                 }
             }

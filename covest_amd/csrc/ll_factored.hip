@@ -186,8 +186,11 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const bool finite = isfinite(par[0]) && isfinite(par[1]);
     // the rates of ALL error classes (padded to a multiple of 8; comb = 0 beyond the model's: such a class weighs 0)
     const int n_pass = PLAIN ? 1 : plan.n_pass; // lanes per copy number: one per 8 error classes (1 when max_error <= 8)
+    // (by multiplication, as K-basic forms them -- point_fetch.h error_class_rate_mul, round 5: the device library's two
+    // pows were 420 dependent instructions that every wave of the workgroup waited for at the barrier below; the strict
+    // re-evaluation of the rows handed back, argmin.hip, forms the same products)
     if (tid < 8 * n_pass)
-        Gs[tid] = error_class_rate(m, par[0], par[1], tid);
+        Gs[tid] = error_class_rate_mul(m, par[0], par[1], tid, m.n_err);
     if (wave == NW - 1) { // the items' constants: one load per lane and 64 items, added in a fixed order
         double lc = 0.0;
         for (int t = t_begin + lane; t < t_end; t += kWave)
