@@ -42,19 +42,21 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
 {
     const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
     __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
-    load_log_table(log_tab);
-    __syncthreads();
     // (Measured and not kept, round 5: the workgroups in another order -- the grid's rows from the last (large c: the
     // longest walks) to the first, 0.1627 against 0.1587 ms; strided through the grid so that cheap and dear rows mix,
-    // stride 17: 0.1623, stride 1531: 0.1834.  Presumably: neighbouring workgroups take the same paths through the code and share
-    // its cache lines: profiles/r05_c2_ab_block_order_not_kept.txt.)
+    // stride 17: 0.1623, stride 1531: 0.1834.  Presumably: neighbouring workgroups take the same paths through the code
+    // and share its cache lines: profiles/r05_c2_ab_block_order_not_kept.txt.)
     const int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = pt < n;
     const int64_t ptc = live ? pt : n - 1; // idle lanes shadow the last point: every lane stays in the wave ops
 
+    // (the point's axis values are asked for BEFORE the log table is copied and its barrier rather than behind it -- one
+    // round trip to the cache less at a workgroup's start; no difference that C2's timing shows, round 5)
     double par[kMaxParams];
     int T;
     fetch_point<2>(src, ptc, par, T);
+    load_log_table(log_tab);
+    __syncthreads();
     clamp_point<2>(m, par);
     const bool finite = isfinite(par[0]) && isfinite(par[1]);
 

@@ -117,6 +117,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                                                          double *__restrict__ out_ll, const SubList sub_list)
 {
     const TileView tv = tile_view_from(n_tiles, n_items, tile_dbl, tile_int);
+#ifdef COVEST_DIAG // (COVEST_FACTORED_DIAG=4: where a workgroup's time OUTSIDE the walk goes -- stamps at the stages' ends)
+    const long long dgx_0 = (long long)clock64();
+    long long dgx_1 = 0, dgx_2 = 0, dgx_3 = 0, dgx_4 = 0;
+#endif
     constexpr int NW = NT / kWave;
     constexpr int MU = 2 * HU; // accumulator slots per wave (6: the specialised step loops below assume it)
     static_assert(MU == 6, "contract loops are written for 6 slots");
@@ -136,14 +140,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const int LD = LDC ? LDC : plan.ld; // G row stride in doubles: 4 dwords (mod 64) -> conflict-free A reads
     extern __shared__ double Gs[]; // [n_buf][kTileBins][LD]; reused for the final per-q combine
     __shared__ __attribute__((aligned(16))) double log_tab[kLogTableDoubles];
-    load_log_table(log_tab);
     // rows handed back (direct_point.h), per accumulator slot and weight vector: first unit, last unit + 1 (0: none;
     // a unit = the 16 rows of a half tile: index 2 * tile + half).  One writer per entry: the lane with kq == 0.
     __shared__ unsigned sub_rec[NW * MU * 16 * 2];
-    for (int i = threadIdx.x; i < NW * MU * 16; i += NT) {
-        sub_rec[2 * i] = 0xFFFFFFFFu;
-        sub_rec[2 * i + 1] = 0;
-    }
     // per row of the key tile being logged and of the next one: {h_j, p_clamp in the row's units (0: no count -- such
     // a row is never "low")}, and the row's scale where p_j itself is needed.  Every unit reads the 4 rows of its lanes
     // from here (LDS, addressed by the unit's half) instead of selecting between two register sets per row.
@@ -152,8 +151,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // {(1-q)^16, -, (1-q)^4, (1-q)^(-4 nsh)} of every slot with shared steps (tiles.h): wave-uniform, read back as LDS broadcasts
     __shared__ __attribute__((aligned(16))) double rho_tab[PLAIN ? NW * MU * 4 : 4];
     __shared__ double lconst_s; // the constant the rows' scales add to every point's sum (tiles.h item_lconst)
-    if (PLAIN && threadIdx.x < NW * MU * 4)
-        rho_tab[threadIdx.x] = plan.unit_rho[(int64_t)blockIdx.y * NW * MU * 4 + threadIdx.x];
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -181,7 +178,34 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     const bool list = list_mode == 1 || list_mode == 2; // (3 is a dense grid's chunk: addressed like mode 0)
     const int64_t ic = list ? ce : ce / plan.n_e;
     const int64_t ie = list ? ce : ce - ic * plan.n_e;
+    // A workgroup's start (round 5): everything it fetches before its first barrier -- the point, the log table, the
+    // shared steps' constants, the items' constants -- is ASKED FOR first and written to LDS afterwards.  In the order
+    // of their uses each fetch stood behind the LDS store of the one before (a loop or a branch between them: the
+    // compiler moves no load across those), four round trips to the cache one after the other in front of every
+    // workgroup's first barrier (the stage stamps of the diagnostic build, profiles/r05_c3_factored_stage_stamps.txt).
     double par[kMaxParams] = {plan.c_axis[ic], plan.e_axis[ie], 0, 0, 0};
+    constexpr int kLogPerThread = (kLogTableDoubles + NT - 1) / NT;
+    double log_v[kLogPerThread];
+#pragma unroll
+    for (int u = 0; u < kLogPerThread; ++u)
+        log_v[u] = kLogTable[min(tid + u * NT, kLogTableDoubles - 1)];
+    const double rho_v = PLAIN ? plan.unit_rho[(int64_t)blockIdx.y * NW * MU * 4 + min(tid, NW * MU * 4 - 1)] : 0.0;
+    // (the items' constants: the last wave's, one load per lane and 64 items, added in a fixed order below)
+    double lc_first = 0.0;
+    if (wave == NW - 1 && t_begin + lane < t_end)
+        lc_first = tv.item_lconst[t_begin + lane];
+#pragma unroll
+    for (int u = 0; u < kLogPerThread; ++u)
+        if (tid + u * NT < kLogTableDoubles)
+            log_tab[tid + u * NT] = log_v[u];
+    if (PLAIN && tid < NW * MU * 4)
+        rho_tab[tid] = rho_v;
+#pragma unroll
+    for (int u = 0; u < (NW * MU * 16 + NT - 1) / NT; ++u)
+        if (tid + u * NT < NW * MU * 16) {
+            sub_rec[2 * (tid + u * NT)] = 0xFFFFFFFFu;
+            sub_rec[2 * (tid + u * NT) + 1] = 0;
+        }
     clamp_point<2>(m, par);
     const bool finite = isfinite(par[0]) && isfinite(par[1]);
     // the rates of ALL error classes (padded to a multiple of 8; comb = 0 beyond the model's: such a class weighs 0)
@@ -192,8 +216,8 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     if (tid < 8 * n_pass)
         Gs[tid] = error_class_rate_mul(m, par[0], par[1], tid, m.n_err);
     if (wave == NW - 1) { // the items' constants: one load per lane and 64 items, added in a fixed order
-        double lc = 0.0;
-        for (int t = t_begin + lane; t < t_end; t += kWave)
+        double lc = 0.0 + lc_first; // (the first 64 items' were asked for above)
+        for (int t = t_begin + lane + kWave; t < t_end; t += kWave)
             lc += tv.item_lconst[t];
         lc = wave_sum(lc);
         if (lane == 0) // (PLAIN: the logs come with the exponent's bias on, fastmath.h RAW -- off again for the whole sum:
@@ -201,6 +225,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             lconst_s = PLAIN ? lc - kLogRawBias<kScaleBits> * tv.suf_h[0] : lc;
     }
     __syncthreads();
+#ifdef COVEST_DIAG
+    dgx_1 = (long long)clock64(); // the table, the point, the classes' rates, the items' constants; the first barrier
+#endif
 
     // ---- phase-A state: lane = (pass, copy number): column pass * pass_stride + (o - o_base - 1) of G ----
     // With more than 8 error classes a copy number's classes are dealt to n_pass lanes, 8 each, whose columns the
@@ -231,8 +258,14 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         // (the stream constants by the reference's own route for every lane: the lanes of a wave are copy numbers, their
         // rates o x lambda_s span all three regimes of StreamSet::init's shortcut, and a wave that takes all three pays more
         // than the one route costs -- measured, round 5: C3 0.675 against 0.667 ms with the shortcut)
+        // (measured and not kept, round 5: the constants stage by stage over the classes, four streams side by side -- exp(-x)
+        // with both of its routes evaluated and one selected, the two logs and the division -- and the normaliser stream by
+        // stream (without its branches the kernel spills 40 to 56 registers): the first four builder waves' constants
+        // 15.3 k -> 13.4 k cycles by the stage stamps, the LAST builder wave's -- copy numbers beyond 256, every route of
+        // every class taken, the one the first barrier waits for -- 17.3 k -> 20.2 k: C3 0.647 against 0.640 ms,
+        // profiles/r05_c3_ab_staged_stream_constants_not_kept.txt)
         st.template init<false>(m, lam, o_mine, finite && my_pass < n_pass && o_local < plan.max_o, log_tab,
-                                                        log_tab, 8 * my_pass, n_total);
+                                log_tab, 8 * my_pass, n_total);
     } else {
         st.gone = 0u;
 #pragma unroll
@@ -242,6 +275,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             st.an.set(s, 0.0, -INFINITY);
         }
     }
+#ifdef COVEST_DIAG
+    dgx_2 = (long long)clock64(); // the streams' constants (builder waves)
+#endif
     const bool lane_in_row = tid < LD - 2; // columns of G that exist (waves past them build nothing)
     if (tid < 64)
         Gs[(size_t)plan.n_buf * kTileBins * LD + tid] = 0.0; // the slack behind the buffers (see launch)
@@ -272,27 +308,49 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         return (int)blockIdx.y * NW + w;
     };
     const int slot_base = wave_block(wave) * MU;
+    // The slots' entries of the unit tables in THREE rounds of loads, each round's in flight together (round 5): every
+    // table holds a harmless entry for a slot without a unit (tile -1, lengths 0, first copy number 1 -- tiles.h), so
+    // nothing needs to wait for the slot's tile to know whether it may be read.  Until then every load of a slot stood
+    // behind `on ? ... : 0`, the slot's tile came first and the six slots one after the other: a dozen round trips to
+    // the cache, 7 000 cycles of a builder wave between its streams' constants and the first key tile (the stage
+    // stamps of the diagnostic build, profiles/r05_c3_factored_stage_stamps.txt).
+    int u_qt[MU], u_s0[MU], u_len[MU], u_cont[MU], u_half[MU], u_nsh[MU], u_o0[MU], u_T[MU];
 #pragma unroll
     for (int k = 0; k < MU; ++k) {
         const int at = slot_base + k;
-        const int qt = __builtin_amdgcn_readfirstlane(plan.unit_tile[at]);
+        u_qt[k] = plan.unit_tile[at];
+        u_s0[k] = plan.unit_s0[at];
+        u_len[k] = plan.unit_len[at];
+        u_cont[k] = plan.unit_cont[at];
+        u_half[k] = plan.unit_half[at];
+        u_nsh[k] = PLAIN ? plan.unit_nsh[at] : 0;
+        u_o0[k] = plan.unit_o0[at];
+    }
+#pragma unroll
+    for (int k = 0; k < MU; ++k) {
+        const int qt = __builtin_amdgcn_readfirstlane(u_qt[k]);
         const bool on = qt >= 0;
         const int slot = (on ? qt : 0) * 16 + col;
-        const int first_step = __builtin_amdgcn_readfirstlane(on ? plan.unit_s0[at] : 0);
         qslot[k] = on ? slot : -1;
-        len[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_len[at] : 0);
-        cont[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_cont[at] : 0);
-        uhalf[k] = __builtin_amdgcn_readfirstlane(on ? plan.unit_half[at] : 0);
+        u_T[k] = plan.q_T[slot];
+        r4[k] = plan.q_r4[slot];
+    }
+#pragma unroll
+    for (int k = 0; k < MU; ++k) {
+        const bool on = qslot[k] >= 0;
+        const int first_step = __builtin_amdgcn_readfirstlane(u_s0[k]);
+        len[k] = __builtin_amdgcn_readfirstlane(u_len[k]);
+        cont[k] = __builtin_amdgcn_readfirstlane(u_cont[k]);
+        uhalf[k] = __builtin_amdgcn_readfirstlane(u_half[k]);
         // shared steps (tiles.h): steps 1 .. nsh of the unit are summed on the vector unit; the MFMA loops below
         // then run over step 0 and the steps AFTER them, which is what a_off, cut and len are counted in
-        nsh[k] = PLAIN ? __builtin_amdgcn_readfirstlane(on ? plan.unit_nsh[at] : 0) : 0;
+        nsh[k] = PLAIN ? __builtin_amdgcn_readfirstlane(u_nsh[k]) : 0;
         a_off0[k] = (16 * uhalf[k] + col) * LD + kq + 4 * first_step; // this lane's A fragment of the piece's first step
         // iterations of the piece during which this lane's copy number o0 + 4 i + kq (o0: the piece's first one,
         // counted from the chunk's start) is below T (the chunk's local one)
-        const int t_lane = on ? plan.q_T[slot] : 0;
-        const int o0 = __builtin_amdgcn_readfirstlane(on ? plan.unit_o0[at] : 1);
+        const int t_lane = on ? u_T[k] : 0;
+        const int o0 = __builtin_amdgcn_readfirstlane(u_o0[k]);
         cut[k] = ((t_lane - (o0 + kq) + 3) >> 2) - nsh[k];
-        r4[k] = plan.q_r4[slot];
         llacc[k] = 0.0;
         dead[k] = 0;
         spacc[(TAIL && !SPO) ? k : 0].hi = 0.0;
@@ -596,6 +654,9 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
     if (diag)
         dg_t0 = (long long)clock64();
+#ifdef COVEST_DIAG
+    dgx_3 = (long long)clock64(); // the units' tables and first weights
+#endif
 
     // With two buffers the builders fill item t+1 while every wave contracts item t: one barrier per item, and the
     // host's unit assignment charges the builders for phase A.  ONE loop for both set-ups (and ONE copy of phase A in
@@ -959,7 +1020,10 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
         STAMP(dg_w)
     }
 
-    if (diag && lane == 0 && !(plan.skip_phases & 0x10000)) {
+#ifdef COVEST_DIAG
+    dgx_4 = (long long)clock64(); // the walk
+#endif
+    if (diag && lane == 0 && !(plan.skip_phases & 0x50000)) {
         long long *d = plan.diag + ((int64_t)(blockIdx.x * gridDim.y + blockIdx.y) * NW + wave) * 8;
         d[0] = dg_a;
         d[1] = dg_b;
@@ -976,12 +1040,40 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     // ---- per-q results: sum the 4 row groups of the accumulator layout, then the two
     //      halves of each q-tile (they may live on different waves) through LDS ----
     const double lconst = lconst_s; // (read before the buffer below is reused: lconst_s is static LDS of its own)
+    // The unit-table words of the entries this thread finishes below -- the four words of an entry, then its weight
+    // vector's place in the grid: two round trips to the cache -- asked for together (round 5: entry after entry, word
+    // after word behind `||`, they stood between the last barrier and every workgroup's stores).  With a tail they are
+    // asked for HERE, and pass during the sums and the barrier below; without one, behind the barrier in the loop as
+    // before: the walk's register allocation hangs on the shape of this epilogue, and the tail-less kernel measured
+    // 0.6384 and 0.6500 against 0.6354 ms with two forms of the early fetch (the trimmed C3 with its tail: 0.3817 and
+    // 0.3851 against 0.3861) -- profiles/r05_c3_ab_result_entries_early.txt.
+    constexpr int kEntries = (NW * MU * 16 + NT - 1) / NT;
+    constexpr bool kEntriesEarly = TAIL;
+    int en_qt[kEntries], en_half[kEntries], en_cont[kEntries], en_pair[kEntries], en_qo[kEntries];
+    auto fetch_entries = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < kEntries; ++u) {
+            const int e = min(tid + u * NT, NW * MU * 16 - 1);
+            const int at = wave_block(e / (MU * 16)) * MU + (e / 16) % MU;
+            en_qt[u] = plan.unit_tile[at];
+            en_half[u] = plan.unit_half[at];
+            en_cont[u] = plan.unit_cont[at];
+            en_pair[u] = plan.unit_pair[at];
+        }
+#pragma unroll
+        for (int u = 0; u < kEntries; ++u)
+            en_qo[u] = plan.q_orig[max(en_qt[u], 0) * 16 + (tid & 15)]; // (NT is a multiple of 16: the entry's column is tid & 15)
+    };
+    if (kEntriesEarly)
+        fetch_entries();
     double *part_ll = Gs;                               // [NW][MU][16]
     // compensated sp_j parts (SPO: where the last contraction left them -- behind part_ll if that is buffer 0)
     double *part_hi = !SPO ? Gs + (size_t)NW * MU * 16
                            : (plan.n_buf == 2 ? Gs + ((t_end + 1) & 1) * kTileBins * LD : Gs + 2 * LD) + NW * MU * 16;
     double *part_lo = part_hi + (size_t)NW * MU * 16;
-    load_weights(); // (the slots' first weights once more: a NaN column is a NaN in them)
+    // (the slots' first weights are in the registers: they do not depend on the key tile, and every interval that used
+    // them up fetched them again behind its logs -- until round 5 they were loaded once more here, a round trip to the
+    // cache in front of every workgroup's results.  A NaN column is a NaN in them)
 #pragma unroll
     for (int k = 0; k < MU; ++k) {
         double ll = llacc[k];
@@ -1015,15 +1107,12 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
     }
     __syncthreads();
     // one thread per (wave, unit, q) entry of a half-0 unit; it looks up the half-1 partner
-    for (int e = tid; e < NW * MU * 16; e += NT) {
-        const int w = e / (MU * 16), k = (e / 16) % MU, c = e & 15;
-        const int at = wave_block(w) * MU + k;
-        const int qt = plan.unit_tile[at];
-        if (qt < 0 || plan.unit_half[at] != 0 || plan.unit_cont[at])
-            continue;
+    auto finish_entry = [&](int e, int qt, int e_half, int e_cont, int pslot, int qo_early) __attribute__((always_inline)) {
+        const int c = e & 15;
+        if (qt < 0 || e_half != 0 || e_cont)
+            return;
         // the unit with the same tile and half 1 (always in the same workgroup): named by the host (tiles.h unit_pair;
         // until round 4 every thread searched the 48 slots for it, three dependent loads a slot)
-        const int pslot = plan.unit_pair[at];
         const int pe = pslot >= 0 ? pslot * 16 + c : -1;
         // + the constant of the rows' scales (see the kernel's header): sum_j h_j ln((k0-1)!/(k0+b)!) over this
         // workgroup's items
@@ -1046,15 +1135,16 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                 lo += part_lo[pe] + err;
             }
         }
+        const int32_t qo = kEntriesEarly ? qo_early : plan.q_orig[qt * 16 + c];
         if (list_mode == 1) { // a key segment of a point: {LL part, sp_j part (hi, lo)}; the host adds the segments
-            if (plan.q_orig[qt * 16 + c] >= 0) {
+            if (qo >= 0) {
                 double *o = plan.partial + ((int64_t)ce * n_seg + seg) * 4;
                 o[0] = finite ? ll : NAN;
                 o[1] = hi;
                 o[2] = lo;
                 o[3] = __longlong_as_double((long long)(finite ? word : 0ull)); // (bits; the host merges the segments' words)
             }
-            continue;
+            return;
         }
         if (TAIL) {
             double s = hi + lo;
@@ -1063,7 +1153,6 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
             if (s < 1.0)
                 tail_term = m.tail * log(1.0 - s);
         }
-        const int32_t qo = plan.q_orig[qt * 16 + c];
         if (qo >= 0) {
             const int64_t flat = ce * plan.n_q + qo;
             if (flat >= plan.flat_begin && flat < plan.flat_end) {
@@ -1073,7 +1162,34 @@ __global__ __launch_bounds__(NT) void ll_factored_kernel(const DevModel m, const
                     sub_list.push(flat - plan.flat_begin, word);
             }
         }
+    };
+    if (kEntriesEarly) {
+#pragma unroll
+        for (int u = 0; u < kEntries; ++u)
+            if (tid + u * NT < NW * MU * 16)
+                finish_entry(tid + u * NT, en_qt[u], en_half[u], en_cont[u], en_pair[u], en_qo[u]);
+    } else {
+        for (int e = tid; e < NW * MU * 16; e += NT) {
+            const int at = wave_block(e / (MU * 16)) * MU + (e / 16) % MU;
+            // (the entry's four words fetched together: behind `||` each waited for the one before)
+            const int qt = plan.unit_tile[at], e_half = plan.unit_half[at], e_cont = plan.unit_cont[at];
+            finish_entry(e, qt, e_half, e_cont, plan.unit_pair[at], 0);
+        }
     }
+#ifdef COVEST_DIAG
+    if (plan.diag && (plan.skip_phases & 0x40000) && lane == 0) {
+        long long *d = plan.diag + ((int64_t)(blockIdx.x * gridDim.y + blockIdx.y) * NW + wave) * 8;
+        const long long end = (long long)clock64();
+        d[0] = dgx_1 - dgx_0;
+        d[1] = dgx_2 - dgx_1;
+        d[2] = dgx_3 - dgx_2;
+        d[3] = dgx_4 - dgx_3;
+        d[4] = end - dgx_4;
+        d[5] = end - dgx_0;
+        d[6] = dgx_0; // (absolute: a workgroup's start against the others')
+        d[7] = end;
+    }
+#endif
 }
 
 #ifndef COVEST_FACTORED_VARIANT // (the finishing kernels live in the common translation unit only)

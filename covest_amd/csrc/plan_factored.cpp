@@ -394,6 +394,8 @@ int build_plan_part(covest_grid *g, const double *const *axes, const std::vector
                     pl.skip_phases |= 0x10000; // the barrier waits by eighths of the walk instead of the phase sums
                 if (std::atoi(std::getenv("COVEST_FACTORED_DIAG")) == 3)
                     pl.skip_phases |= 0x20000; // ... of the first seven intervals one by one, the rest in the eighth
+                if (std::atoi(std::getenv("COVEST_FACTORED_DIAG")) == 4)
+                    pl.skip_phases = (pl.skip_phases & ~0x10000) | 0x40000; // the stages outside the walk
                 std::fprintf(stderr, "COVEST_FACTORED_DIAG %p %zu\n", dp, bytes);
             }
         }

@@ -22,6 +22,21 @@ L = _capi.lib()
 n = L.covest_grid_diag(g._handle, None, 0)
 buf = np.zeros(n, dtype=np.int64)
 L.covest_grid_diag(g._handle, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n)
+if os.environ.get("COVEST_FACTORED_DIAG") == "4":  # the stages OUTSIDE the walk, per wave (ll_factored.hip dgx_*)
+    st = buf.reshape(-1, 8, 8).astype(np.float64)
+    print("workgroups", st.shape[0])
+    print("mean cycles per wave: start -> first barrier | streams' constants | units' tables, first weights | the walk | "
+          "per-q results | whole workgroup")
+    for w in range(8):
+        print("wave %d: %8.0f %8.0f %8.0f %9.0f %8.0f %9.0f" % ((w,) + tuple(st[:, w, k].mean() for k in range(6))))
+    t0, t1 = buf.reshape(-1, 8, 8)[:, 0, 6], buf.reshape(-1, 8, 8)[:, 0, 7]
+    span = float(t1.max() - t0.min())
+    print("launch: first start to last end %.0f cycles; workgroup length mean %.0f; sum of lengths / (256 CUs x span) = %.3f" % (
+        span, float((t1 - t0).mean()), float((t1 - t0).sum()) / (256.0 * span)))
+    order = np.argsort(t0)
+    gaps = t0[order][256:] - np.sort(t1)[:len(t0) - 256]  # k-th start past the first round against the k-th end
+    print("start of workgroup 256 + k minus the k-th end: mean %.0f, median %.0f cycles" % (float(gaps.mean()), float(np.median(gaps))))
+    sys.exit(0)
 d = buf.reshape(-1, 8, 8)[:, :, :4].astype(np.float64)  # [wg][wave][build, contract, log, barrier]
 extra = buf.reshape(-1, 8, 8)
 print("workgroups", d.shape[0])
