@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void argmin_stage1(const double *__restrict__ 
 // where it matters, p_j subnormal, every sum is exact whatever the order.  But the points that are handed back are the
 // ones whose LAST keys underflow, which are the ones with a SMALL threshold_o -- three to six lots, most of them out
 // of the rows' reach -- and every one of the four waves repeated the point's loads, its two pows and the rows' bins:
-// C3's 5 000 points 46.8 us with four waves a point, 35.8 us with one, profiles/r05_c3_kstat_fix_one_wave_a_point.txt.)
+// C3's 2 962 queued points 46.8 us with four waves a point, 35.8 us with one, profiles/r05_c3_kstat_fix_one_wave_a_point.txt.)
 // Launched after every K-basic / K-factored launch, before anything reads the values; with an empty queue it costs
 // a launch and one load.  The queued points of a wide grid come in clusters (whole (c, e) rows of it) and the work
 // of one grows with its threshold_o, which is why they are compacted into a queue and spread over the chip instead

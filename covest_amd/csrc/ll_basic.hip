@@ -404,13 +404,24 @@ __device__ __forceinline__ void ll_basic_body(const DevModel &m, const int32_t n
 }
 
 // The case the reference's `main` builds (max_error = 8): 4 waves per SIMD at 128 registers.
+// TWO waves a workgroup (round 5; four until then).  A workgroup's LDS -- the lanes' anchors and the log table, 36 KB for
+// four waves: four workgroups to a CU -- stays allocated until its LAST wave has ended, and the waves of a workgroup end
+// at very different times: 44 % of C2's are doomed and leave at once, the others walk as many tiles as their error rates
+// keep classes alive.  By the counters the launch held 1.5 waves a SIMD on average (SQ_WAVE_CYCLES over the launch's
+// SIMD-cycles) where the registers allow four: the slots of the waves that had left could not be refilled.  With 128
+// threads (20 KB: eight workgroups to a CU, the same sixteen waves) a slot comes free when two waves are done instead of
+// four: C2 0.159 -> 0.145 ms, the trimmed C2 with its tail 0.197 -> 0.169; with 64 threads (every wave its own
+// workgroup, thirteen to a CU by the LDS) 0.150 and 0.166 -- profiles/r05_c2_ab_threads_per_workgroup.txt.
+#ifndef COVEST_BASIC_BD
+#define COVEST_BASIC_BD 128
+#endif
 template <bool TAIL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ? 3 : 4, TAIL ? 3 : 4))) void ll_basic_kernel(
+__global__ __launch_bounds__(COVEST_BASIC_BD) __attribute__((amdgpu_waves_per_eu(TAIL ? 3 : 4, TAIL ? 3 : 4))) void ll_basic_kernel(
     const DevModel m, const int32_t n_tiles, const int32_t n_items, const double *__restrict__ tile_dbl,
     const int32_t *__restrict__ tile_int, const PointSource src, const int64_t n, double *__restrict__ out_ll,
     SubList sub_list)
 {
-    ll_basic_body<8, TAIL, 256>(m, n_tiles, n_items, tile_dbl, tile_int, src, n, out_ll, sub_list);
+    ll_basic_body<8, TAIL, COVEST_BASIC_BD>(m, n_tiles, n_items, tile_dbl, tile_int, src, n, out_ll, sub_list);
 }
 
 // More error classes (max_error = k + 1 = 22 when a model is built directly, covest/models.py:28-31): the same walk
@@ -433,8 +444,8 @@ void launch_ll_basic_variant(dim3 grid, hipStream_t stream, const DevModel &m, c
                              int64_t cnt, double *out, const SubList &sl)
 {
     if (S == 8) {
-        const size_t lds8 = (size_t)2 * 8 * 256 * sizeof(double);
-        hipLaunchKernelGGL((ll_basic_kernel<TAIL>), grid, dim3(256), lds8, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
+        const size_t lds8 = (size_t)2 * 8 * COVEST_BASIC_BD * sizeof(double);
+        hipLaunchKernelGGL((ll_basic_kernel<TAIL>), grid, dim3(COVEST_BASIC_BD), lds8, stream, m, tv.n_tiles, tv.n_items, tv.dbl_base,
                            tv.int_base, part, cnt, out, sl);
     } else {
         const size_t lds = (size_t)2 * S * 64 * sizeof(double);
@@ -477,7 +488,7 @@ hipError_t launch_ll_basic(const DevModel &m, const TileView &tv, const PointSou
     if (m.n_err > 32 || m.kind != 0)
         return hipErrorInvalidValue;
     const int s_pad = ((m.n_err + 7) / 8) * 8;
-    const int bd = s_pad == 8 ? 256 : 64;
+    const int bd = s_pad == 8 ? COVEST_BASIC_BD : 64;
     // HIP wraps a grid of more than 2^32 threads silently: at most 2^23 workgroups per launch
     const int64_t per_launch = (int64_t)bd << 23;
     for (int64_t first = 0; first < n; first += per_launch) {
