@@ -1,4 +1,6 @@
-mkdir -p gpurun_out/r5ah
-timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee gpurun_out/r5ah/tests.txt
-timeout -k 10 200 bash tools/kstat_ab.sh c2 tools/bin/lib_r5fin.so covest_amd/lib/libcovest_amd.so 2>&1 | tee gpurun_out/r5ah/kstat_c2.txt
-timeout -k 10 120 python tools/time_tail.py 2>&1 | tee gpurun_out/r5ah/tail.txt
+out=gpurun_out/r5fin2
+mkdir -p $out
+timeout -k 10 600 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err || echo "default bench failed"
+for w in c3 c2 c3t c2t; do timeout -k 10 200 python3 bench.py --workload $w --no-variants > $out/bench_$w.json 2> $out/bench_$w.err || echo "bench $w failed"; done
+timeout -k 10 100 python3 tools/latency.py > $out/latency_single_evaluation.txt 2>&1
+tail -c 300 $out/bench_default.json
