@@ -577,8 +577,9 @@ def strong_variant(cls, hist, args, world, rank, local_rank, xdev, on_device, st
            "exchange": "device-resident pair -> RCCL all-gather -> device scan -> 16-byte copy" if on_device
                        else "host pair -> all-gather (%s) -> scan" % args.backend}
     # the N = 1 time of the same grid, from this repository's own one-GPU bench line (newest round first)
-    for name in ("r03_bench_c3_strong_1gpu.json", "r02_bench_c3_strong_1gpu.json"):
-        path = os.path.join(REPO, "profiles", name)
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_bench_c3_strong_1gpu.json")), reverse=True):
+        name = os.path.basename(path)
         if os.path.exists(path):
             try:
                 with open(path) as f:

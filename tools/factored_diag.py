@@ -30,12 +30,20 @@ if os.environ.get("COVEST_FACTORED_DIAG") == "4":  # the stages OUTSIDE the walk
     for w in range(8):
         print("wave %d: %8.0f %8.0f %8.0f %9.0f %8.0f %9.0f" % ((w,) + tuple(st[:, w, k].mean() for k in range(6))))
     t0, t1 = buf.reshape(-1, 8, 8)[:, 0, 6], buf.reshape(-1, 8, 8)[:, 0, 7]
-    span = float(t1.max() - t0.min())
-    print("launch: first start to last end %.0f cycles; workgroup length mean %.0f; sum of lengths / (256 CUs x span) = %.3f" % (
-        span, float((t1 - t0).mean()), float((t1 - t0).sum()) / (256.0 * span)))
-    order = np.argsort(t0)
-    gaps = t0[order][256:] - np.sort(t1)[:len(t0) - 256]  # k-th start past the first round against the k-th end
-    print("start of workgroup 256 + k minus the k-th end: mean %.0f, median %.0f cycles" % (float(gaps.mean()), float(np.median(gaps))))
+    # a CU's turnover: the stamps are one clock per XCD and workgroup i runs on XCD i mod 8 -- within an XCD (32 CUs,
+    # one workgroup each) the k-th start past the first 32 against the k-th end
+    wg = np.arange(len(t0))
+    for x in range(8):
+        sel = wg % 8 == x
+        a, b = np.sort(t0[sel]), np.sort(t1[sel])
+        n_cu = 32
+        if len(a) <= n_cu:
+            continue
+        gap = a[n_cu:] - b[:len(a) - n_cu]
+        print("XCD %d: %d workgroups, first start to last end %.0f cycles, lengths mean %.0f; start of the (32 + k)-th minus the "
+              "k-th end: mean %.0f, median %.0f, max %.0f; first 32 starts spread over %.0f" % (
+                  x, int(sel.sum()), float(b[-1] - a[0]), float((t1[sel] - t0[sel]).mean()), float(gap.mean()),
+                  float(np.median(gap)), float(gap.max()), float(a[n_cu - 1] - a[0])))
     sys.exit(0)
 d = buf.reshape(-1, 8, 8)[:, :, :4].astype(np.float64)  # [wg][wave][build, contract, log, barrier]
 extra = buf.reshape(-1, 8, 8)
