@@ -888,12 +888,14 @@ def test_round4_shortcuts_on_awkward_shapes(hip_lib, oracle):
             g.close()
             m.close()
     # the strict kernel of the basic model with several points a wave: a key with a SUBNORMAL p_j (as in
-    # test_subnormal_pj_goes_to_the_strict_kernel) under 8, 16 and 24 error classes, list and grid
+    # test_subnormal_pj_goes_to_the_strict_kernel) under 8, 16, 24 and (k = 31) 32 error classes -- one instantiation of
+    # the packed kernel each --, list and grid
     hist = {1: 1000, 2: 500, 150: 6000, 151: 40, 153: 7}
     cs = np.linspace(0.50, 0.85, 141)
-    for max_error in (8, 16, 24):
-        m = BasicModel(21, 100, hist, 0, max_error=max_error)
-        g = DenseGrid(m, [cs, [0.01, 0.02]])
+    for k, max_error in ((21, 8), (21, 16), (21, 24), (31, 32)):
+        m = BasicModel(k, 100, hist, 0, max_error=max_error)
+        # (k = 31: the same error-free rates c (r - k + 1) / r (1 - e)^k as k = 21 has on `cs`)
+        g = DenseGrid(m, [cs * (1.265 if k == 31 else 1.0), [0.01, 0.02]])
         g.evaluate(kernel="recur")
         fast = g.loglikelihoods()
         g.evaluate(kernel="direct")

@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r5aj
-timeout -k 10 300 python tools/time_rounds.py 2>&1 | tee gpurun_out/r5aj/rounds.txt
+# scratch: the command of the moment for one gpurun call (`gpurun -- 'bash tools/job.sh'`); overwritten at will
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3
