@@ -638,6 +638,9 @@ def other_configs(args):
             c["passes_ms"] = roof.get("passes_ms")
         if "argmin" in r:
             c["argmin"] = r["argmin"]
+        for k in ("warmup", "spinup_steps"):
+            if k in r:
+                c[k] = r[k]
         if "cases" in r:
             c["cases"] = [{k: case[k] for k in ("histogram", "iterations", "points_evaluated", "time_to_argmin_s", "split_ms")}
                           for case in r["cases"]]
@@ -789,9 +792,22 @@ def main():
     # W untimed warm-up steps as asked, preceded by a fixed spin-up that is not counted either: the device
     # needs a few milliseconds of work before its clocks settle (at --warmup 1 the first timed steps ran 13 %
     # slower than steady state).  The timed steps follow the warm-up DIRECTLY.
+    # (round 5: the spin-up is a stretch of WORK, 20 ms of steps and 25 steps at least -- `r04_clock_ramp.txt`: the clocks
+    # settle 14 ms in; 25 steps of the basic-model grid are 4.5 ms, and its child line of the default run read 0.178 to
+    # 0.185 ms a step from run to run where 400 steps read 0.170.  The count is in the line: spinup_steps)
     spinup_steps = int(os.environ.get("COVEST_BENCH_SPINUP", "25"))
-    for _ in range(spinup_steps + args.warmup):
-        step()
+    if "COVEST_BENCH_SPINUP" not in os.environ and world == 1:  # (N > 1: a step holds a collective -- the same count on every rank)
+        t_probe = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        per_step = (time.perf_counter() - t_probe) / 5
+        spinup_steps = max(25, min(400, int(0.020 / max(per_step, 1e-6)) + 1)) + 5
+        for _ in range(spinup_steps - 5 + args.warmup):
+            step()
+    else:
+        for _ in range(spinup_steps + args.warmup):
+            step()
     grid.profile(True)
     if world > 1:
         dist.barrier()
